@@ -1,0 +1,187 @@
+/*
+ * monopsr_hip.h -- C ABI of libmonopsr_hip.so: MonoPSR's per-instance hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain device pointers and sizes,
+ * an explicit HIP stream (passed as void* so this header needs no HIP include), returns an int status
+ * (MPSR_OK == 0) and never allocates, frees or synchronises.  Outputs and scratch are caller-allocated; the
+ * *_bytes / *_floats helpers say how much.  All tensors are contiguous; floats are fp32, indices int32,
+ * images/activations NHWC.  Thread-safe and stateless (the last error string is thread-local).
+ *
+ * Each declaration cites the reference interface it replaces (paths under /root/reference/src).
+ * The first five keep the argument order of the reference's launcher functions so the reference's TF op
+ * shells (tf_nndistance.cpp:168,208 / tf_approxmatch.cpp:141-143) could bind to them with the stream appended;
+ * INTEGRATION.md shows that binding and the ctypes one used by monopsr_amd.
+ */
+#ifndef MONOPSR_HIP_H
+#define MONOPSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mpsr_stream_t; /* a hipStream_t; NULL = the null stream */
+
+enum {
+    MPSR_OK = 0,
+    MPSR_ERR_INVALID_ARG = 1, /* shape / pointer check failed (the reference raises errors::InvalidArgument) */
+    MPSR_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
+    MPSR_ERR_WORKSPACE = 3,   /* caller-provided scratch is too small */
+    MPSR_ERR_UNSUPPORTED = 4  /* configuration outside what the kernels implement */
+};
+
+/* Human-readable description of the last non-OK status returned on the calling thread ("" if none). */
+const char *mpsr_last_error(void);
+/* ABI version, bumped on any signature change. */
+int mpsr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------ Chamfer */
+
+/* Replaces NmDistanceKernelLauncher (tf_ops/nn_distance/tf_nndistance.cpp:168, tf_nndistance_g.cu:128-131),
+ * i.e. op NnDistance (tf_nndistance.cpp:3-9).  xyz1 (b,n,3), xyz2 (b,m,3) -> dist1 (b,n), idx1 (b,n),
+ * dist2 (b,m), idx2 (b,m).  Squared distances; ties resolve to the lowest index; bit-exact with the
+ * reference's CPU kernel (tf_nndistance.cpp:21-43).  b, n or m == 0 is a no-op. */
+int mpsr_nn_distance_fwd(int b, int n, const float *xyz1, int m, const float *xyz2,
+                         float *dist1, int *idx1, float *dist2, int *idx2, mpsr_stream_t stream);
+
+/* Replaces NmDistanceGradKernelLauncher (tf_nndistance.cpp:208, tf_nndistance_g.cu:152-157), op
+ * NnDistanceGrad (tf_nndistance.cpp:10-18).  Overwrites grad_xyz1 (b,n,3) and grad_xyz2 (b,m,3) (no
+ * pre-zeroing needed).  idx values must lie in [0,m) / [0,n). */
+int mpsr_nn_distance_bwd(int b, int n, const float *xyz1, int m, const float *xyz2,
+                         const float *grad_dist1, const int *idx1, const float *grad_dist2, const int *idx2,
+                         float *grad_xyz1, float *grad_xyz2, mpsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ EMD */
+
+/* Scratch floats mpsr_approx_match needs in `temp` (the reference uses b*(n+m)*2, tf_approxmatch.cpp:168;
+ * this implementation keeps per-level ratios so that match is written exactly once). */
+size_t mpsr_approx_match_temp_floats(int b, int n, int m);
+
+/* Replaces approxmatchLauncher (tf_approxmatch.cpp:141, tf_approxmatch_g.cu:1-182), op ApproxMatch
+ * (tf_approxmatch.cpp:7-10).  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n), GPU-kernel semantics: 10 annealing
+ * levels, fp32 state. */
+int mpsr_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                      mpsr_stream_t stream);
+
+/* Replaces matchcostLauncher (tf_approxmatch.cpp:142, tf_approxmatch_g.cu:183-228), op MatchCost.
+ * -> out (b). */
+int mpsr_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
+                    mpsr_stream_t stream);
+
+/* Replaces matchcostgradLauncher (tf_approxmatch.cpp:143, tf_approxmatch_g.cu:229-295), op MatchCostGrad.
+ * -> grad1 (b,n,3), grad2 (b,m,3); both fully overwritten. */
+int mpsr_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                         float *grad1, float *grad2, mpsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ image ops */
+
+/* tf.image.crop_and_resize (bilinear, extrapolation_value) as called at monopsr_model.py:222-226 and
+ * net_builder.py:54-59.  image (nimg,H,W,C), boxes (nb,4) = [y1,x1,y2,x2] normalised, box_ind (nb) or NULL
+ * (= all 0) -> out (nb,ch,cw,C). */
+int mpsr_crop_and_resize(const float *image, int nimg, int H, int W, int C, const float *boxes,
+                         const int *box_ind, int nb, int ch, int cw, float extrapolation_value, float *out,
+                         mpsr_stream_t stream);
+
+/* tf.image.resize_bilinear (TF-1.8 legacy kernel, no half-pixel centres) as called at monopsr_model.py:228-233,
+ * net_builder.py:72-83 and img_preprocessor.py:32.  in (B,H,W,C) -> out (B,OH,OW,C). */
+int mpsr_resize_bilinear(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners,
+                         float *out, mpsr_stream_t stream);
+
+/* slim.max_pool2d: window k, stride s, padding SAME (pad_same=1, TF pads bottom/right first) or VALID.
+ * resnet_v1.py:235 (3x3/2 SAME), net_builder.py:60,68 (2x2/2 VALID). */
+int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int pad_same, float *out,
+                  mpsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ conv / FC */
+
+/* One stride-1 SAME convolution (optionally atrous) or fully-connected layer as an fp32-MFMA implicit GEMM with
+ * a fused epilogue: y = act(conv(x, w) + bias + residual).  Serves every slim.conv2d / slim.fully_connected on
+ * the path (resnet_v1.py:116-127, resnet_utils.py:112, net_builder.py:67,77,85, monopsr_output_builder.py:101,
+ * 140,166,253,...) with BatchNorm folded into w/bias by the caller.
+ *   x        (B,H,W,C) NHWC, C % 32 == 0
+ *   w        (N, KH*KW*C) row-major: w[n][(ky*KW+kx)*C + c]  (the TF HWIO tensor transposed to O,HWI)
+ *   bias     (N) or NULL;  residual (B,H,W,N) or NULL;  relu 0/1
+ *   y        (B,H,W,N)
+ *   split_k  >= 1; when > 1, `ws` must hold split_k*B*H*W*N floats (partial sums, reduced by a second kernel)
+ * A fully-connected layer is H=W=KH=KW=1. */
+int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
+                         const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
+                         int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream);
+
+/* Explicit im2col for the ResNet root: explicit zero pad 3 + 7x7 stride-2 VALID (resnet_utils.py:115-122 via
+ * resnet_v1.py:234).  x (B,H,W,3) -> cols (B*OH*OW, kpad) with OH=(H+6-7)/2+1; column (ky*7+kx)*3+c, columns
+ * 147..kpad-1 zero.  kpad % 32 == 0, kpad >= 147. */
+int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols, int kpad, mpsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ network */
+
+/* One packed convolution / FC layer inside a weight blob (offsets in floats from the blob base). */
+typedef struct mpsr_layer {
+    int32_t cin, cout, kh, kw, dilation, relu;
+    int64_t w_off; /* (cout, kh*kw*cin) BN-folded weights */
+    int64_t b_off; /* (cout) folded bias, or -1 */
+} mpsr_layer;
+
+#define MPSR_TRUNK_LAYERS 94 /* root + 30 bottleneck units x 3 + 3 projection shortcuts */
+
+/* Scratch bytes for mpsr_trunk_fwd on a (B,H,W,3) input. */
+size_t mpsr_trunk_workspace_bytes(int B, int H, int W);
+
+/* ResNet-101 v1 to block3 at output stride 4 (rates 1/2/4), frozen BatchNorm folded, as
+ * FasterRCNNResnet101FeatureExtractor._extract_proposal_features builds it
+ * (faster_rcnn_resnet_v1_feature_extractor.py:197-245; resnet_v1.py:79-139,221-236,310-330;
+ * resnet_utils.py:176-219).  img (B,H,W,3) -> out (B,H/4,W/4,1024).  layers[] in execution order:
+ * root(as 1x1 over im2col, cin=160), then per unit [shortcut?], conv1, conv2, conv3. */
+int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
+                   int n_layers, float *out, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
+
+#define MPSR_DECODER_LAYERS 6 /* squash 1x1, conv2 x2, conv3 x2, xyz 3x3 */
+
+size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, int mw);
+
+/* net_builder.py:62-89 + monopsr_output_builder.py:95-104: concat(crop_feat, full_feat) -> 1x1 conv 512 + ReLU
+ * (features_squashed) -> 2x2 max-pool (features_for_box_3d) ; bilinear to (mh/2,mw/2) -> 2x[3x3 conv 256,BN,ReLU]
+ * -> bilinear to (mh,mw) -> 2x[3x3 conv 128,BN,ReLU] (features_for_map) -> 3x3 conv 3 (inst_xyz_map_local).
+ * crop_feat, full_feat (B,fh,fw,1024).  Outputs: feat_box3d (B,fh/2,fw/2,512), feat_map (B,mh,mw,128) or NULL to
+ * skip storing it separately, xyz_map (B,mh,mw,3). */
+int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh, int mw,
+                            const float *blob, const mpsr_layer *layers, int n_layers, float *feat_box3d,
+                            float *feat_map, float *xyz_map, void *workspace, size_t workspace_bytes,
+                            mpsr_stream_t stream);
+
+#define MPSR_HEAD_LAYERS 10 /* img_fc(x2 fused), prop fc0,fc1, lwh, alpha, reg fc0,fc1, cen_y, cen_z (see heads) */
+
+typedef struct mpsr_head_consts {
+    float image_h, image_w;   /* model_config.image_input_shape (320, 1216) */
+    float max_depth;          /* dataset depth_range[1] (45) */
+    float cen_y_norm;         /* 1.666754, monopsr_output_builder.py:246 */
+    float cen_y_class_offset; /* 0.0648 for Car/kitti, instance_utils.py:933-937 */
+    int32_t num_classes;      /* len(dataset_config.classes) */
+    int32_t num_alpha_bins;   /* 12 */
+} mpsr_head_consts;
+
+size_t mpsr_heads_workspace_bytes(int B, int feat_elems);
+
+/* monopsr_output_builder.py:126-302,407-438,457-488,509-661 wired as monopsr_model.py:320-413 with
+ * output_config {lwh: offset, alpha: dc, view_ang: est, cen_x: from_view_ang_and_z, cen_y: offset, cen_z: offset}.
+ *   feat_box3d (B,feat_elems) flattened NHWC features_for_box_3d
+ *   boxes_2d (B,4) [y1,x1,y2,x2] pixels; cam_p (12) row-major 3x4; view_angs (B); class_idx (B) int32;
+ *   mean_lwh (B,3); cen_z_offset (B)
+ * Outputs (any may be NULL): lwh (B,3), lwh_offs (B,3), alpha_bins (B,nb), alpha_regs (B,nb), prop_cen_z (B),
+ * cen_y (B), cen_y_offs (B), cen_z (B), cen_z_offs (B), cen_x (B), centroids (B,3). */
+typedef struct mpsr_head_outputs {
+    float *lwh, *lwh_offs, *alpha_bins, *alpha_regs, *prop_cen_z, *cen_y, *cen_y_offs, *cen_z, *cen_z_offs,
+        *cen_x, *centroids;
+} mpsr_head_outputs;
+
+int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d, const float *cam_p,
+                   const float *view_angs, const int *class_idx, const float *mean_lwh, const float *cen_z_offset,
+                   const mpsr_head_consts *consts, const float *blob, const mpsr_layer *layers, int n_layers,
+                   const mpsr_head_outputs *outs, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOPSR_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libmonopsr_hip.so (C ABI declared in include/monopsr_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonopsr_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class MpsrError(RuntimeError):
+    """A libmonopsr_hip.so call returned a non-zero status."""
+
+
+class InvalidArgumentError(MpsrError, ValueError):
+    """Shape/argument check failed -- the analogue of the tf.errors.InvalidArgumentError the reference's
+    OP_REQUIRES checks raise (tf_nndistance.cpp:51-58, tf_approxmatch.cpp:152-165)."""
+
+
+c_f = ctypes.c_void_p  # device pointers travel as integers
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+
+
+class Layer(ctypes.Structure):
+    """struct mpsr_layer"""
+    _fields_ = [("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
+                ("dilation", ctypes.c_int32), ("relu", ctypes.c_int32), ("w_off", ctypes.c_int64),
+                ("b_off", ctypes.c_int64)]
+
+
+class HeadConsts(ctypes.Structure):
+    """struct mpsr_head_consts"""
+    _fields_ = [("image_h", ctypes.c_float), ("image_w", ctypes.c_float), ("max_depth", ctypes.c_float),
+                ("cen_y_norm", ctypes.c_float), ("cen_y_class_offset", ctypes.c_float),
+                ("num_classes", ctypes.c_int32), ("num_alpha_bins", ctypes.c_int32)]
+
+
+class HeadOutputs(ctypes.Structure):
+    """struct mpsr_head_outputs"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ("lwh", "lwh_offs", "alpha_bins", "alpha_regs", "prop_cen_z", "cen_y", "cen_y_offs", "cen_z",
+                 "cen_z_offs", "cen_x", "centroids")]
+
+
+# name -> (restype, argtypes); must list every symbol include/monopsr_hip.h declares (tests/test_cabi.py checks).
+SIGNATURES = {
+    "mpsr_last_error": (ctypes.c_char_p, []),
+    "mpsr_abi_version": (c_i, []),
+    "mpsr_nn_distance_fwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_approx_match_temp_floats": (c_sz, [c_i, c_i, c_i]),
+    "mpsr_approx_match": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_match_cost": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_match_cost_grad": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_crop_and_resize": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f]),
+    "mpsr_resize_bilinear": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_max_pool": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_conv2d_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
+                                   c_sz, c_f]),
+    "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
+    "mpsr_trunk_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
+    "mpsr_decoder_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "mpsr_squash_decoder_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f,
+                                      c_f, c_f, c_sz, c_f]),
+    "mpsr_heads_workspace_bytes": (c_sz, [c_i, c_i]),
+    "mpsr_heads_fwd": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(HeadConsts), c_f,
+                             ctypes.POINTER(Layer), c_i, ctypes.POINTER(HeadOutputs), c_f, c_sz, c_f]),
+}
+
+
+def lib():
+    """Load libmonopsr_hip.so once.  Import torch first in GPU processes so both share one HIP runtime."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpsrError(
+                "libmonopsr_hip.so is not built (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C monopsr_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+        if missing and not os.environ.get("MPSR_PARTIAL_LIB"):
+            raise MpsrError("libmonopsr_hip.so lacks declared symbols %s; rebuild (make -C monopsr_amd/csrc)"
+                            % missing)
+        for name, (res, args) in SIGNATURES.items():
+            if name in missing:
+                continue
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.mpsr_abi_version()
+        if got != ABI_VERSION:
+            raise MpsrError("libmonopsr_hip.so ABI %d != expected %d; rebuild" % (got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    if status == 0:
+        return
+    msg = lib().mpsr_last_error().decode("utf-8", "replace")
+    if status == 1:
+        raise InvalidArgumentError(msg)
+    raise MpsrError("status %d: %s" % (status, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MpsrError("expected a tensor on the GPU; monopsr_amd has no CPU path")
+    if not t.is_contiguous():
+        raise MpsrError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

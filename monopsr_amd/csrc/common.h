@@ -1,0 +1,48 @@
+// Shared host-side helpers for libmonopsr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "monopsr_hip.h"
+
+namespace mpsr {
+
+// Thread-local last-error buffer behind mpsr_last_error().
+char *error_buffer();
+constexpr int kErrorBufferBytes = 512;
+
+inline int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), kErrorBufferBytes, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline hipStream_t as_stream(mpsr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Launch check: kernel launches report configuration errors through hipGetLastError().
+#define MPSR_CHECK_LAUNCH(what)                                                                       \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) return ::mpsr::fail(MPSR_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+#define MPSR_CHECK_HIP(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return ::mpsr::fail(MPSR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define MPSR_REQUIRE(cond, ...)                                                    \
+    do {                                                                           \
+        if (!(cond)) return ::mpsr::fail(MPSR_ERR_INVALID_ARG, __VA_ARGS__);       \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace mpsr
