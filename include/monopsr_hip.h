@@ -100,7 +100,7 @@ int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int
  * a fused epilogue: y = act(conv(x, w) + bias + residual).  Serves every slim.conv2d / slim.fully_connected on
  * the path (resnet_v1.py:116-127, resnet_utils.py:112, net_builder.py:67,77,85, monopsr_output_builder.py:101,
  * 140,166,253,...) with BatchNorm folded into w/bias by the caller.
- *   x        (B,H,W,C) NHWC, C % 32 == 0
+ *   x        (B,H,W,C) NHWC, C % 4 == 0, 16-byte aligned
  *   w        (N, KH*KW*C) row-major: w[n][(ky*KW+kx)*C + c]  (the TF HWIO tensor transposed to O,HWI)
  *   bias     (N) or NULL;  residual (B,H,W,N) or NULL;  relu 0/1
  *   y        (B,H,W,N)
@@ -137,7 +137,7 @@ size_t mpsr_trunk_workspace_bytes(int B, int H, int W);
 int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
                    int n_layers, float *out, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
 
-#define MPSR_DECODER_LAYERS 6 /* squash 1x1, conv2 x2, conv3 x2, xyz 3x3 */
+#define MPSR_DECODER_LAYERS 7 /* squash 1x1 as two K-halves (crop, full), conv2 x2, conv3 x2, xyz 3x3 */
 
 size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, int mw);
 
@@ -151,7 +151,7 @@ int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int 
                             float *feat_map, float *xyz_map, void *workspace, size_t workspace_bytes,
                             mpsr_stream_t stream);
 
-#define MPSR_HEAD_LAYERS 10 /* img_fc(x2 fused), prop fc0,fc1, lwh, alpha, reg fc0,fc1, cen_y, cen_z (see heads) */
+#define MPSR_HEAD_LAYERS 7 /* img_fc (both heads fused along N), prop fc0, fc1, lwh+alpha, reg fc0, fc1, cen_y+cen_z */
 
 typedef struct mpsr_head_consts {
     float image_h, image_w;   /* model_config.image_input_shape (320, 1216) */

@@ -1,0 +1,180 @@
+"""Device-resident packed weights and scratch for the network entry points of libmonopsr_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from monopsr_amd import _lib
+from monopsr_amd.core import weights as W
+
+
+def _layer_array(records):
+    arr = (_lib.Layer * len(records))()
+    for i, r in enumerate(records):
+        arr[i] = _lib.Layer(r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"], r["relu"], r["w_off"], r["b_off"])
+    return arr
+
+
+class PackedPart:
+    def __init__(self, blob, records, device):
+        self.blob = torch.from_numpy(blob).to(device)
+        self.records = records
+        self.layers = _layer_array(records)
+        self.n = len(records)
+
+
+class Workspace:
+    """Grow-only scratch buffer on one device (allocation stays outside the C ABI)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class DeviceNet:
+    """Packs a TF-named weight dict (monopsr_amd.core.weights) and runs trunk / decoder / heads through the C ABI."""
+
+    def __init__(self, weights, device="cuda", width_div=1, full_trunk=False):
+        self.device = torch.device(device)
+        self.width_div = width_div
+        self.crop_trunk = PackedPart(*W.pack_trunk(weights, W.CROP_SCOPE, width_div), self.device)
+        self.full_trunk = (PackedPart(*W.pack_trunk(weights, W.FULL_SCOPE, width_div), self.device)
+                           if full_trunk else None)
+        self.decoder = PackedPart(*W.pack_decoder(weights, width_div), self.device)
+        feat_elems = weights["output/proposal_fc/proposal_fc/img_fc/weights"].shape[0]
+        self.heads = PackedPart(*W.pack_heads(weights, feat_elems), self.device)
+        self.feat_elems = feat_elems
+        self.ws_trunk = Workspace(self.device)
+        self.ws_dec = Workspace(self.device)
+        self.ws_heads = Workspace(self.device)
+
+    # ------------------------------------------------------------------ trunk
+    def trunk(self, img, which="crop"):
+        """img (B,H,W,3) -> block3 (B,H/4,W/4,C)."""
+        part = self.crop_trunk if which == "crop" else self.full_trunk
+        if part is None:
+            raise _lib.MpsrError("DeviceNet was built without the full-image trunk")
+        img = img.contiguous()
+        B, H, Wd, _ = img.shape
+        oh, ow = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
+        ph, pw = (oh + 1) // 2, (ow + 1) // 2
+        cout = part.records[-1]["cout"]
+        out = torch.empty((B, ph, pw, cout), dtype=torch.float32, device=self.device)
+        lib = _lib.lib()
+        nbytes = lib.mpsr_trunk_workspace_bytes(B, H, Wd)
+        ws = self.ws_trunk.get(nbytes)
+        _lib.check(lib.mpsr_trunk_fwd(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
+                                      _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        return out
+
+    # ------------------------------------------------------------------ squash + decoder (+ xyz head)
+    def squash_decoder(self, crop_feat, full_feat, map_size=(48, 48), want_feat_map=True, want_xyz=True):
+        crop_feat, full_feat = crop_feat.contiguous(), full_feat.contiguous()
+        B, fh, fw, _ = crop_feat.shape
+        mh, mw = map_size
+        recs = self.decoder.records
+        csq, c3 = recs[1]["cout"], recs[5]["cout"]
+        feat_box = torch.empty((B, fh // 2, fw // 2, csq), dtype=torch.float32, device=self.device)
+        feat_map = torch.empty((B, mh, mw, c3), dtype=torch.float32, device=self.device) if want_feat_map else None
+        xyz = torch.empty((B, mh, mw, recs[6]["cout"]), dtype=torch.float32, device=self.device)
+        lib = _lib.lib()
+        nbytes = lib.mpsr_decoder_workspace_bytes(B, fh, fw, mh, mw)
+        ws = self.ws_dec.get(nbytes)
+        _lib.check(lib.mpsr_squash_decoder_fwd(_lib.ptr(crop_feat), _lib.ptr(full_feat), B, fh, fw, mh, mw,
+                                               _lib.ptr(self.decoder.blob), self.decoder.layers, self.decoder.n,
+                                               _lib.ptr(feat_box), _lib.ptr(feat_map), _lib.ptr(xyz), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream()))
+        return feat_box, feat_map, xyz
+
+    # ------------------------------------------------------------------ heads
+    def heads_fwd(self, feat_box3d, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset,
+                  image_shape=(320, 1216), max_depth=45.0, num_classes=1, num_alpha_bins=12,
+                  cen_y_norm=1.666754, cen_y_class_offset=0.0648):
+        B = feat_box3d.shape[0]
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        feat = feat_box3d.contiguous().reshape(B, -1)
+        boxes_2d = boxes_2d.to(**f32).contiguous()
+        cam_p = cam_p.to(**f32).contiguous().reshape(12)
+        view = view_angs.to(**f32).contiguous().reshape(B)
+        cls = class_idx.to(dtype=torch.int32, device=dev).contiguous().reshape(B)
+        mean_lwh = mean_lwh.to(**f32).contiguous()
+        z_off = cen_z_offset.to(**f32).contiguous().reshape(B)
+        nb = num_alpha_bins
+        out = {
+            "lwh": torch.empty((B, 3), **f32), "lwh_offs": torch.empty((B, 3), **f32),
+            "alpha_bins": torch.empty((B, nb), **f32), "alpha_regs": torch.empty((B, nb), **f32),
+            "prop_cen_z": torch.empty((B, 1), **f32), "cen_y": torch.empty((B, 1), **f32),
+            "cen_y_offs": torch.empty((B, 1), **f32), "cen_z": torch.empty((B, 1), **f32),
+            "cen_z_offs": torch.empty((B, 1), **f32), "cen_x": torch.empty((B, 1), **f32),
+            "centroids": torch.empty((B, 3), **f32),
+        }
+        consts = _lib.HeadConsts(float(image_shape[0]), float(image_shape[1]), float(max_depth), float(cen_y_norm),
+                                 float(cen_y_class_offset), int(num_classes), int(nb))
+        outs = _lib.HeadOutputs(*[_lib.ptr(out[k]) for k, _ in _lib.HeadOutputs._fields_])
+        lib = _lib.lib()
+        nbytes = lib.mpsr_heads_workspace_bytes(B, feat.shape[1])
+        ws = self.ws_heads.get(nbytes)
+        _lib.check(lib.mpsr_heads_fwd(_lib.ptr(feat), B, feat.shape[1], _lib.ptr(boxes_2d), _lib.ptr(cam_p),
+                                      _lib.ptr(view), _lib.ptr(cls), _lib.ptr(mean_lwh), _lib.ptr(z_off),
+                                      ctypes.byref(consts), _lib.ptr(self.heads.blob), self.heads.layers, self.heads.n,
+                                      ctypes.byref(outs), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        out["view_ang"] = view.reshape(B, 1)
+        return out
+
+
+# ---------------------------------------------------------------------- single-layer helpers (tests, tools)
+
+def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1):
+    """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C)."""
+    x, w_ok = x.contiguous(), w_ok.contiguous()
+    B, H, Wd, C = x.shape
+    N = w_ok.shape[0]
+    y = torch.empty((B, H, Wd, N), dtype=torch.float32, device=x.device)
+    ws = torch.empty((split_k * B * H * Wd * N,), dtype=torch.float32, device=x.device) if split_k > 1 else None
+    _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32(
+        _lib.ptr(x), B, H, Wd, C, _lib.ptr(w_ok), _lib.ptr(bias.contiguous()) if bias is not None else None,
+        _lib.ptr(residual.contiguous()) if residual is not None else None, _lib.ptr(y), N, kh, kw, dilation,
+        int(relu), split_k, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()))
+    return y
+
+
+def crop_and_resize(image, boxes, box_ind, crop_size, extrapolation_value=0.0):
+    image, boxes = image.contiguous(), boxes.to(torch.float32).contiguous()
+    nimg, H, Wd, C = image.shape
+    nb = boxes.shape[0]
+    ind = box_ind.to(torch.int32).contiguous() if box_ind is not None else None
+    out = torch.empty((nb, crop_size[0], crop_size[1], C), dtype=torch.float32, device=image.device)
+    _lib.check(_lib.lib().mpsr_crop_and_resize(_lib.ptr(image), nimg, H, Wd, C, _lib.ptr(boxes), _lib.ptr(ind), nb,
+                                               crop_size[0], crop_size[1], float(extrapolation_value), _lib.ptr(out),
+                                               _lib.stream()))
+    return out
+
+
+def resize_bilinear(x, size, align_corners=False):
+    x = x.contiguous()
+    B, H, Wd, C = x.shape
+    if (H, Wd) == tuple(size):
+        return x
+    out = torch.empty((B, size[0], size[1], C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mpsr_resize_bilinear(_lib.ptr(x), B, H, Wd, C, size[0], size[1], int(align_corners),
+                                               _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def max_pool(x, k, s, padding="VALID"):
+    x = x.contiguous()
+    B, H, Wd, C = x.shape
+    if padding == "SAME":
+        oh, ow = -(-H // s), -(-Wd // s)
+    else:
+        oh, ow = (H - k) // s + 1, (Wd - k) // s + 1
+    out = torch.empty((B, oh, ow, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mpsr_max_pool(_lib.ptr(x), B, H, Wd, C, k, s, int(padding == "SAME"), _lib.ptr(out),
+                                        _lib.stream()))
+    return out

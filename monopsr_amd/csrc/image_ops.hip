@@ -1,0 +1,251 @@
+// Gather-type image operators of the MonoPSR instance path for gfx950: crop_and_resize, bilinear resize,
+// max-pool and the root-convolution im2col.  All are HBM/L2-bound streaming kernels: one thread per output
+// float4 (channels innermost, NHWC), fully coalesced stores, 16-byte loads when C % 4 == 0.
+//
+// Coordinate arithmetic is float32 in the order TensorFlow 1.8's kernels use (restated in oracle/net.py), and the
+// file is built with -ffp-contract=off so source coordinates round exactly as there.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    using type = float4;
+};
+template <>
+struct Vec<1> {
+    using type = float;
+};
+
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float t)
+{
+    return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+__device__ __forceinline__ float lerp4(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float4 splat(float v, float4) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float splat(float v, float) { return v; }
+__device__ __forceinline__ float4 vmax(float4 a, float4 b)
+{
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+
+// tf.image.crop_and_resize, bilinear.  Thread = one output pixel x V channels.
+template <int V>
+__global__ __launch_bounds__(256) void crop_and_resize_kernel(const float *__restrict__ image, int H, int W, int C,
+                                                              const float *__restrict__ boxes,
+                                                              const int *__restrict__ box_ind, int nimg, int ch,
+                                                              int cw, float extrap, float *__restrict__ out,
+                                                              long long total)
+{
+    using T = typename Vec<V>::type;
+    const int cv = C / V;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int x = (int)(r % cw);
+        r /= cw;
+        const int y = (int)(r % ch);
+        const int bi = (int)(r / ch);
+        const float y1 = boxes[4 * bi], x1 = boxes[4 * bi + 1], y2 = boxes[4 * bi + 2], x2 = boxes[4 * bi + 3];
+        const int img = box_ind ? box_ind[bi] : 0;
+        T res = splat(extrap, T());
+        const float hs = ch > 1 ? (y2 - y1) * (float)(H - 1) / (float)(ch - 1) : 0.f;
+        const float ws = cw > 1 ? (x2 - x1) * (float)(W - 1) / (float)(cw - 1) : 0.f;
+        const float in_y = ch > 1 ? y1 * (float)(H - 1) + (float)y * hs : 0.5f * (y1 + y2) * (float)(H - 1);
+        const float in_x = cw > 1 ? x1 * (float)(W - 1) + (float)x * ws : 0.5f * (x1 + x2) * (float)(W - 1);
+        if (img >= 0 && img < nimg && !(in_y < 0.f) && !(in_y > (float)(H - 1)) && !(in_x < 0.f) &&
+            !(in_x > (float)(W - 1)) && in_y == in_y && in_x == in_x) {
+            const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+            const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+            const float yl = in_y - (float)top, xl = in_x - (float)left;
+            const T *base = reinterpret_cast<const T *>(image + (size_t)img * H * W * C);
+            const T tl = base[((size_t)top * W + left) * cv + c], tr = base[((size_t)top * W + right) * cv + c];
+            const T bl = base[((size_t)bot * W + left) * cv + c], br = base[((size_t)bot * W + right) * cv + c];
+            res = lerp4(lerp4(tl, tr, xl), lerp4(bl, br, xl), yl);
+        }
+        reinterpret_cast<T *>(out)[i] = res;
+    }
+}
+
+// tf.image.resize_bilinear (TF 1.8 kernel).  Thread = one output pixel x V channels.
+template <int V>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ in, int H, int W, int C,
+                                                              int OH, int OW, float hscale, float wscale,
+                                                              float *__restrict__ out, long long total)
+{
+    using T = typename Vec<V>::type;
+    const int cv = C / V;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const float sy = (float)oy * hscale, sx = (float)ox * wscale;
+        const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float yl = sy - (float)y0, xl = sx - (float)x0;
+        const T *base = reinterpret_cast<const T *>(in + (size_t)b * H * W * C);
+        const T tl = base[((size_t)y0 * W + x0) * cv + c], tr = base[((size_t)y0 * W + x1) * cv + c];
+        const T bl = base[((size_t)y1 * W + x0) * cv + c], br = base[((size_t)y1 * W + x1) * cv + c];
+        reinterpret_cast<T *>(out)[i] = lerp4(lerp4(tl, tr, xl), lerp4(bl, br, xl), yl);
+    }
+}
+
+// slim.max_pool2d; pad_top/pad_left are the SAME-padding offsets (0 for VALID); padded cells never win.
+template <int V>
+__global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__ in, int H, int W, int C, int OH,
+                                                       int OW, int k, int s, int pad_top, int pad_left,
+                                                       float *__restrict__ out, long long total)
+{
+    using T = typename Vec<V>::type;
+    const int cv = C / V;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const T *base = reinterpret_cast<const T *>(in + (size_t)b * H * W * C);
+        T best = splat(-__builtin_inff(), T());
+        for (int ky = 0; ky < k; ++ky) {
+            const int y = oy * s - pad_top + ky;
+            if (y < 0 || y >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int x = ox * s - pad_left + kx;
+                if (x < 0 || x >= W) continue;
+                best = vmax(best, base[((size_t)y * W + x) * cv + c]);
+            }
+        }
+        reinterpret_cast<T *>(out)[i] = best;
+    }
+}
+
+// Root im2col: explicit pad 3, 7x7 window, stride 2; row = output pixel, column (ky*7+kx)*3+c, zero tail to kpad.
+__global__ __launch_bounds__(256) void im2col_root_kernel(const float *__restrict__ x, int H, int W, int OH, int OW,
+                                                          int kpad, float *__restrict__ cols, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % kpad);
+        long long r = i / kpad;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        float v = 0.f;
+        if (j < 147) {
+            const int c = j % 3, t = j / 3;
+            const int kx = t % 7, ky = t / 7;
+            const int yy = oy * 2 + ky - 3, xx = ox * 2 + kx - 3;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[(((size_t)b * H + yy) * W + xx) * 3 + c];
+        }
+        cols[i] = v;
+    }
+}
+
+inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mpsr_crop_and_resize(const float *image, int nimg, int H, int W, int C, const float *boxes,
+                                    const int *box_ind, int nb, int ch, int cw, float extrapolation_value, float *out,
+                                    mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(nimg > 0 && H > 0 && W > 0 && C > 0 && nb >= 0 && ch > 0 && cw > 0,
+                 "crop_and_resize: bad shape (nimg=%d H=%d W=%d C=%d nb=%d crop=%dx%d)", nimg, H, W, C, nb, ch, cw);
+    if (nb == 0) return MPSR_OK;
+    MPSR_REQUIRE(image && boxes && out, "crop_and_resize: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    if (C % 4 == 0 && aligned16(image) && aligned16(out)) {
+        const long long total = (long long)nb * ch * cw * (C / 4);
+        hipLaunchKernelGGL(crop_and_resize_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, image, H, W, C, boxes,
+                           box_ind, nimg, ch, cw, extrapolation_value, out, total);
+    } else {
+        const long long total = (long long)nb * ch * cw * C;
+        hipLaunchKernelGGL(crop_and_resize_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, image, H, W, C, boxes,
+                           box_ind, nimg, ch, cw, extrapolation_value, out, total);
+    }
+    MPSR_CHECK_LAUNCH("crop_and_resize_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_resize_bilinear(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners,
+                                    float *out, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "resize_bilinear: bad shape");
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(in && out, "resize_bilinear: null pointer");
+    const float hscale = (align_corners && OH > 1) ? (float)(H - 1) / (float)(OH - 1) : (float)H / (float)OH;
+    const float wscale = (align_corners && OW > 1) ? (float)(W - 1) / (float)(OW - 1) : (float)W / (float)OW;
+    hipStream_t s = mpsr::as_stream(stream);
+    if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
+        const long long total = (long long)B * OH * OW * (C / 4);
+        hipLaunchKernelGGL(resize_bilinear_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, in, H, W, C, OH, OW,
+                           hscale, wscale, out, total);
+    } else {
+        const long long total = (long long)B * OH * OW * C;
+        hipLaunchKernelGGL(resize_bilinear_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, in, H, W, C, OH, OW,
+                           hscale, wscale, out, total);
+    }
+    MPSR_CHECK_LAUNCH("resize_bilinear_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s_, int pad_same, float *out,
+                             mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && k > 0 && s_ > 0, "max_pool: bad shape");
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(in && out, "max_pool: null pointer");
+    int OH, OW, pt = 0, pl = 0;
+    if (pad_same) {
+        OH = mpsr::ceil_div(H, s_);
+        OW = mpsr::ceil_div(W, s_);
+        const int th = (OH - 1) * s_ + k - H, tw = (OW - 1) * s_ + k - W;
+        pt = (th > 0 ? th : 0) / 2;
+        pl = (tw > 0 ? tw : 0) / 2;
+    } else {
+        MPSR_REQUIRE(H >= k && W >= k, "max_pool: VALID window %d larger than input %dx%d", k, H, W);
+        OH = (H - k) / s_ + 1;
+        OW = (W - k) / s_ + 1;
+    }
+    hipStream_t s = mpsr::as_stream(stream);
+    if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
+        const long long total = (long long)B * OH * OW * (C / 4);
+        hipLaunchKernelGGL(max_pool_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, in, H, W, C, OH, OW, k, s_, pt,
+                           pl, out, total);
+    } else {
+        const long long total = (long long)B * OH * OW * C;
+        hipLaunchKernelGGL(max_pool_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, in, H, W, C, OH, OW, k, s_, pt,
+                           pl, out, total);
+    }
+    MPSR_CHECK_LAUNCH("max_pool_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols, int kpad, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H >= 1 && W >= 1, "im2col_root: bad shape");
+    MPSR_REQUIRE(kpad >= 147 && kpad % 32 == 0, "im2col_root: kpad=%d must be a multiple of 32 and >= 147", kpad);
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && cols, "im2col_root: null pointer");
+    const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+    const long long total = (long long)B * OH * OW * kpad;
+    hipLaunchKernelGGL(im2col_root_kernel, dim3(grid_for(total)), dim3(256), 0, mpsr::as_stream(stream), x, H, W, OH,
+                       OW, kpad, cols, total);
+    MPSR_CHECK_LAUNCH("im2col_root_kernel");
+    return MPSR_OK;
+}

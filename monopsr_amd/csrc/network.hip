@@ -1,0 +1,386 @@
+// Network-level entry points: ResNet-101 trunk to block3 (output stride 4), squash + map decoder + xyz-map head,
+// centroid / shape regression heads.  Host-side layer sequencing in C++ over the kernels of conv_mfma.hip and
+// image_ops.hip; no allocation, no synchronisation, everything on the caller's stream, scratch carved from the
+// caller's workspace.
+#include <vector>
+
+#include "common.h"
+
+namespace mpsr {
+int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
+           float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
+           hipStream_t stream);
+}
+
+namespace {
+
+// bump allocator over the caller's workspace; 256-byte aligned pieces
+struct Arena {
+    char *base;
+    size_t size, used = 0;
+    bool ok = true;
+    Arena(void *p, size_t n) : base(static_cast<char *>(p)), size(n) {}
+    float *floats(size_t n)
+    {
+        const size_t bytes = mpsr::align_up(n * sizeof(float), 256);
+        if (used + bytes > size) {
+            ok = false;
+            return nullptr;
+        }
+        float *r = reinterpret_cast<float *>(base + used);
+        used += bytes;
+        return r;
+    }
+};
+
+inline size_t fbytes(size_t n) { return mpsr::align_up(n * sizeof(float), 256); }
+
+int run_layer(const float *blob, const mpsr_layer &L, const float *x, int B, int H, int W, const float *residual,
+              float *y, int split_k, float *ws, size_t ws_floats, hipStream_t s)
+{
+    return mpsr::conv2d(x, B, H, W, L.cin, blob + L.w_off, L.b_off >= 0 ? blob + L.b_off : nullptr, residual, y, L.cout,
+                        L.kh, L.kw, L.dilation, L.relu, split_k, ws, ws_floats, s);
+}
+
+constexpr int kTrunkUnits[3] = {3, 4, 23};
+
+struct TrunkDims {
+    int OH, OW, PH, PW;
+};
+inline TrunkDims trunk_dims(int H, int W)
+{
+    TrunkDims d;
+    d.OH = (H + 6 - 7) / 2 + 1;
+    d.OW = (W + 6 - 7) / 2 + 1;
+    d.PH = (d.OH + 1) / 2;
+    d.PW = (d.OW + 1) / 2;
+    return d;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ trunk
+
+extern "C" size_t mpsr_trunk_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const TrunkDims d = trunk_dims(H, W);
+    const size_t Mr = (size_t)B * d.OH * d.OW, Mp = (size_t)B * d.PH * d.PW;
+    // cols, root, pooled, 3 x (Mp x 1024) ping/pong/shortcut, 2 x (Mp x 256) bottleneck temporaries
+    return fbytes(Mr * 160) + fbytes(Mr * 64) + fbytes(Mp * 64) + 3 * fbytes(Mp * 1024) + 2 * fbytes(Mp * 256);
+}
+
+extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
+                              int n_layers, float *out, void *workspace, size_t workspace_bytes, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H >= 7 && W >= 7, "trunk_fwd: bad input shape (B=%d H=%d W=%d)", B, H, W);
+    MPSR_REQUIRE(n_layers == MPSR_TRUNK_LAYERS, "trunk_fwd: expected %d layer records, got %d", MPSR_TRUNK_LAYERS,
+                 n_layers);
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(img && blob && layers && out && workspace, "trunk_fwd: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    const TrunkDims d = trunk_dims(H, W);
+    const size_t Mr = (size_t)B * d.OH * d.OW, Mp = (size_t)B * d.PH * d.PW;
+    const mpsr_layer &root = layers[0];
+    MPSR_REQUIRE(root.kh == 1 && root.kw == 1 && root.cin >= 147 && root.cin % 32 == 0,
+                 "trunk_fwd: layer 0 must be the root as a 1x1 layer over im2col columns (cin=%d)", root.cin);
+    // widest tensors (narrow test copies of the graph scale with the records)
+    int cmax = 0, bmax = 0;
+    for (int i = 1; i < n_layers; ++i) {
+        if (layers[i].kh == 3 && layers[i].cout > bmax) bmax = layers[i].cout;
+        if (layers[i].cout > cmax) cmax = layers[i].cout;
+    }
+    Arena ar(workspace, workspace_bytes);
+    float *cols = ar.floats(Mr * root.cin);
+    float *rootout = ar.floats(Mr * root.cout);
+    float *pooled = ar.floats(Mp * root.cout);
+    float *ping = ar.floats(Mp * cmax), *pong = ar.floats(Mp * cmax), *scut = ar.floats(Mp * cmax);
+    float *t1 = ar.floats(Mp * bmax), *t2 = ar.floats(Mp * bmax);
+    if (!ar.ok)
+        return mpsr::fail(MPSR_ERR_WORKSPACE, "trunk_fwd: workspace %zu bytes too small (see mpsr_trunk_workspace_bytes)",
+                          workspace_bytes);
+
+    int rc;
+    if ((rc = mpsr_im2col_root(img, B, H, W, cols, root.cin, stream))) return rc;
+    if ((rc = run_layer(blob, root, cols, (int)Mr, 1, 1, nullptr, rootout, 1, nullptr, 0, s))) return rc;
+    if ((rc = mpsr_max_pool(rootout, B, d.OH, d.OW, root.cout, 3, 2, 1, pooled, stream))) return rc;
+
+    const float *cur = pooled;
+    int cur_c = root.cout;
+    int li = 1;
+    for (int blk = 0; blk < 3; ++blk) {
+        for (int u = 0; u < kTrunkUnits[blk]; ++u) {
+            const bool last = (blk == 2 && u == kTrunkUnits[blk] - 1);
+            const float *residual = cur;
+            if (u == 0) {  // projection shortcut: 1x1, BN folded, no activation
+                const mpsr_layer &S = layers[li++];
+                MPSR_REQUIRE(S.kh == 1 && S.cin == cur_c && !S.relu, "trunk_fwd: record %d is not a shortcut", li - 1);
+                if ((rc = run_layer(blob, S, cur, B, d.PH, d.PW, nullptr, scut, 1, nullptr, 0, s))) return rc;
+                residual = scut;
+            }
+            const mpsr_layer &c1 = layers[li], &c2 = layers[li + 1], &c3 = layers[li + 2];
+            li += 3;
+            MPSR_REQUIRE(c1.kh == 1 && c1.cin == cur_c && c2.kh == 3 && c2.cin == c1.cout && c3.kh == 1 &&
+                             c3.cin == c2.cout && (u == 0 || c3.cout == cur_c),
+                         "trunk_fwd: records %d..%d do not form a bottleneck unit", li - 3, li - 1);
+            float *dst = last ? out : (cur == ping ? pong : ping);
+            if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 1, nullptr, 0, s))) return rc;
+            if ((rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 1, nullptr, 0, s))) return rc;
+            if ((rc = run_layer(blob, c3, t2, B, d.PH, d.PW, residual, dst, 1, nullptr, 0, s))) return rc;
+            cur = dst;
+            cur_c = c3.cout;
+        }
+    }
+    return MPSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+
+extern "C" size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, int mw)
+{
+    if (B <= 0) return 0;
+    const size_t Mf = (size_t)B * fh * fw, Mh = (size_t)B * (mh / 2) * (mw / 2), Mm = (size_t)B * mh * mw;
+    return 2 * fbytes(Mf * 512) + fbytes(Mh * 512) + 2 * fbytes(Mh * 256) + fbytes(Mm * 256) + 2 * fbytes(Mm * 128);
+}
+
+extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh,
+                                       int mw, const float *blob, const mpsr_layer *L, int n_layers,
+                                       float *feat_box3d, float *feat_map, float *xyz_map, void *workspace,
+                                       size_t workspace_bytes, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && fh >= 2 && fw >= 2 && mh >= 2 && mw >= 2 && mh % 2 == 0 && mw % 2 == 0,
+                 "squash_decoder_fwd: bad shape");
+    MPSR_REQUIRE(n_layers == MPSR_DECODER_LAYERS, "squash_decoder_fwd: expected %d layer records, got %d",
+                 MPSR_DECODER_LAYERS, n_layers);
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(crop_feat && full_feat && blob && L && feat_box3d && workspace,
+                 "squash_decoder_fwd: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    const int hh = mh / 2, hw = mw / 2;
+    const size_t Mf = (size_t)B * fh * fw, Mh = (size_t)B * hh * hw, Mm = (size_t)B * mh * mw;
+    const int csq = L[1].cout, c2 = L[2].cout, c3 = L[4].cout;
+    MPSR_REQUIRE(L[0].cout == csq && L[2].cin == csq && L[3].cin == c2 && L[4].cin == c2 && L[5].cin == c3 &&
+                     L[6].cin == c3,
+                 "squash_decoder_fwd: layer records are not squash_a, squash_b, conv2_1, conv2_2, conv3_1, conv3_2, xyz");
+    Arena ar(workspace, workspace_bytes);
+    float *part = ar.floats(Mf * csq), *sq = ar.floats(Mf * csq);
+    float *r1 = ar.floats(Mh * csq), *a = ar.floats(Mh * c2), *b = ar.floats(Mh * c2);
+    float *r2 = ar.floats(Mm * c2), *c = ar.floats(Mm * c3);
+    float *fm = feat_map ? feat_map : ar.floats(Mm * c3);
+    if (!ar.ok)
+        return mpsr::fail(MPSR_ERR_WORKSPACE, "squash_decoder_fwd: workspace %zu bytes too small", workspace_bytes);
+    int rc;
+    // 1x1 over concat([crop, full]) == two GEMMs over the halves of K; the second adds the first as its residual
+    if ((rc = run_layer(blob, L[0], crop_feat, B, fh, fw, nullptr, part, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[1], full_feat, B, fh, fw, part, sq, 1, nullptr, 0, s))) return rc;
+    if ((rc = mpsr_max_pool(sq, B, fh, fw, csq, 2, 2, 0, feat_box3d, stream))) return rc;
+    if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
+    if ((rc = run_layer(blob, L[2], r1, B, hh, hw, nullptr, a, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[3], a, B, hh, hw, nullptr, b, 1, nullptr, 0, s))) return rc;
+    if ((rc = mpsr_resize_bilinear(b, B, hh, hw, c2, mh, mw, 1, r2, stream))) return rc;
+    if ((rc = run_layer(blob, L[4], r2, B, mh, mw, nullptr, c, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[5], c, B, mh, mw, nullptr, fm, 1, nullptr, 0, s))) return rc;
+    if (xyz_map && (rc = run_layer(blob, L[6], fm, B, mh, mw, nullptr, xyz_map, 1, nullptr, 0, s))) return rc;
+    return MPSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ heads
+
+namespace {
+
+struct HeadIn {
+    const float *boxes, *cam_p, *view, *mean_lwh, *z_off;
+    const int *cls;
+    mpsr_head_consts k;
+};
+
+// scalar features shared by both concat rows (monopsr_output_builder.py:147-158,228-240):
+// index 0..3 box coords in film coordinates / half image size, 4 box height / image height, 5 view angle,
+// 6..6+nc-1 class one-hot
+__device__ __forceinline__ float common_feature(const HeadIn &in, int b, int j)
+{
+    const float *bx = in.boxes + 4 * b;
+    const float cu = in.cam_p[2], cv = in.cam_p[6];
+    if (j < 4) {
+        const float centre = (j & 1) ? cu : cv;
+        const float half = ((j & 1) ? in.k.image_w : in.k.image_h) / 2.0f;
+        return (bx[j] - centre) / half;
+    }
+    if (j == 4) return (bx[2] - bx[0]) / in.k.image_h;
+    if (j == 5) return in.view[b];
+    return (in.cls[b] == j - 6) ? 1.0f : 0.0f;
+}
+
+__constant__ float kCamNorm[12] = {1000.f, 1.f, 1000.f, 100.f, 1.f, 1000.f, 1000.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+
+// row b of the proposal FC input: [img_fc(1024) | common | cam_p / norm (12) | zero pad]
+__global__ __launch_bounds__(256) void head_concat_prop_kernel(HeadIn in, const float *__restrict__ imgfc,
+                                                               int imgfc_stride, int nfc, int kpad, int B,
+                                                               float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * kpad) return;
+    const int b = i / kpad, col = i - b * kpad;
+    const int ncommon = 6 + in.k.num_classes;
+    float v = 0.f;
+    if (col < nfc) v = imgfc[(size_t)b * imgfc_stride + col];
+    else if (col < nfc + ncommon) v = common_feature(in, b, col - nfc);
+    else if (col < nfc + ncommon + 12) v = in.cam_p[col - nfc - ncommon] / kCamNorm[col - nfc - ncommon];
+    out[i] = v;
+}
+
+// per box: lwh / alpha outputs, centroid proposals (get_prop_cen_z :407-431, tf_est_y_from_box_2d_and_depth
+// instance_utils.py:907-953).  pout row = [lwh_offs(3) | alpha_bins(nb) | alpha_regs(nb)].  prop = [y, z] per box.
+__global__ __launch_bounds__(256) void head_prop_outputs_kernel(HeadIn in, const float *__restrict__ pout, int B,
+                                                                mpsr_head_outputs o, float *__restrict__ prop)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int nb = in.k.num_alpha_bins, stride = 3 + 2 * nb;
+    const float *p = pout + (size_t)b * stride;
+    float lwh[3];
+    for (int j = 0; j < 3; ++j) {
+        lwh[j] = in.mean_lwh[3 * b + j] + p[j];
+        if (o.lwh) o.lwh[3 * b + j] = lwh[j];
+        if (o.lwh_offs) o.lwh_offs[3 * b + j] = p[j];
+    }
+    for (int j = 0; j < nb; ++j) {
+        if (o.alpha_bins) o.alpha_bins[(size_t)b * nb + j] = p[3 + j];
+        if (o.alpha_regs) o.alpha_regs[(size_t)b * nb + j] = p[3 + nb + j];
+    }
+    const float *bx = in.boxes + 4 * b;
+    const float focal = in.cam_p[0], cv = in.cam_p[6];
+    const float z = focal * lwh[2] / (bx[2] - bx[0]) + in.z_off[b];
+    const float centre_v = (bx[2] + bx[0]) / 2.0f - cv;
+    const float y = centre_v * (z / focal) - in.k.cen_y_class_offset;
+    if (o.prop_cen_z) o.prop_cen_z[b] = z;
+    prop[2 * b] = y;
+    prop[2 * b + 1] = z;
+}
+
+// row b of the regression FC input: [img_fc_r(1024) | common | lwh_offs(3) | bins | regs | y/norm | z/max_depth | pad]
+__global__ __launch_bounds__(256) void head_concat_reg_kernel(HeadIn in, const float *__restrict__ imgfc,
+                                                              int imgfc_stride, int nfc, int kpad, int B,
+                                                              const float *__restrict__ pout,
+                                                              const float *__restrict__ prop, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * kpad) return;
+    const int b = i / kpad, col = i - b * kpad;
+    const int ncommon = 6 + in.k.num_classes, nout = 3 + 2 * in.k.num_alpha_bins;
+    float v = 0.f;
+    if (col < nfc) v = imgfc[(size_t)b * imgfc_stride + nfc + col];
+    else if (col < nfc + ncommon) v = common_feature(in, b, col - nfc);
+    else if (col < nfc + ncommon + nout) v = pout[(size_t)b * nout + (col - nfc - ncommon)];
+    else if (col == nfc + ncommon + nout) v = prop[2 * b] / in.k.cen_y_norm;
+    else if (col == nfc + ncommon + nout + 1) v = prop[2 * b + 1] / in.k.max_depth;
+    out[i] = v;
+}
+
+// per box: centroid = proposal + regressed offsets; x from the viewing angle (add_cen_x_output :551-571)
+__global__ __launch_bounds__(256) void head_final_kernel(HeadIn in, const float *__restrict__ rout,
+                                                         const float *__restrict__ prop, int B, mpsr_head_outputs o)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float yo = rout[2 * b], zo = rout[2 * b + 1];
+    const float y = prop[2 * b] + yo, z = prop[2 * b + 1] + zo;
+    const float x = z * tanf(in.view[b]) + (-in.cam_p[3] / in.cam_p[0]);
+    if (o.cen_y) o.cen_y[b] = y;
+    if (o.cen_y_offs) o.cen_y_offs[b] = yo;
+    if (o.cen_z) o.cen_z[b] = z;
+    if (o.cen_z_offs) o.cen_z_offs[b] = zo;
+    if (o.cen_x) o.cen_x[b] = x;
+    if (o.centroids) {
+        o.centroids[3 * b] = x;
+        o.centroids[3 * b + 1] = y;
+        o.centroids[3 * b + 2] = z;
+    }
+}
+
+inline int img_fc_splits(int B, int nout, int ksteps)
+{
+    const int tiles = mpsr::ceil_div(B, 64) * mpsr::ceil_div(nout, 64);
+    int s = 768 / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    if (s > ksteps) s = ksteps;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t mpsr_heads_workspace_bytes(int B, int feat_elems)
+{
+    if (B <= 0 || feat_elems <= 0) return 0;
+    const size_t b = (size_t)B;
+    // img_fc (2 x 1024 wide) + its split-K partials, two concat rows, four hidden activations, small outputs
+    return fbytes(b * 2048) + fbytes(16 * b * 2048) + 2 * fbytes(b * 1152) + 4 * fbytes(b * 1024) + fbytes(b * 64) +
+           fbytes(b * 2) + fbytes(b * 2);
+}
+
+extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d,
+                              const float *cam_p, const float *view_angs, const int *class_idx, const float *mean_lwh,
+                              const float *cen_z_offset, const mpsr_head_consts *consts, const float *blob,
+                              const mpsr_layer *L, int n_layers, const mpsr_head_outputs *outs, void *workspace,
+                              size_t workspace_bytes, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && feat_elems > 0 && feat_elems % 4 == 0, "heads_fwd: bad shape (B=%d feat=%d)", B, feat_elems);
+    MPSR_REQUIRE(n_layers == MPSR_HEAD_LAYERS, "heads_fwd: expected %d layer records, got %d", MPSR_HEAD_LAYERS,
+                 n_layers);
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(feat_box3d && boxes_2d && cam_p && view_angs && class_idx && mean_lwh && cen_z_offset && consts &&
+                     blob && L && outs && workspace,
+                 "heads_fwd: null pointer");
+    const int nfc = L[0].cout / 2;  // width of each img_fc
+    const int nb = consts->num_alpha_bins, nc = consts->num_classes;
+    const int prop_in = nfc + 6 + nc + 12, reg_in = nfc + 6 + nc + 3 + 2 * nb + 2;
+    MPSR_REQUIRE(L[0].cin == feat_elems && L[1].cin >= prop_in && L[1].cin % 4 == 0 && L[3].cout == 3 + 2 * nb &&
+                     L[4].cin >= reg_in && L[4].cin % 4 == 0 && L[6].cout == 2 && L[1].cin <= 1152 && L[4].cin <= 1152 &&
+                     L[1].cout <= 1024 && L[2].cout <= 1024 && L[4].cout <= 1024 && L[5].cout <= 1024 && nfc <= 1024 &&
+                     3 + 2 * nb <= 64,
+                 "heads_fwd: layer records do not match the head graph");
+    hipStream_t s = mpsr::as_stream(stream);
+    Arena ar(workspace, workspace_bytes);
+    const size_t b = (size_t)B;
+    const int ksteps = mpsr::ceil_div(feat_elems, 32);
+    const int splits = img_fc_splits(B, L[0].cout, ksteps);
+    float *imgfc = ar.floats(b * L[0].cout);
+    float *skws = ar.floats((size_t)splits * b * L[0].cout);
+    float *cat_p = ar.floats(b * L[1].cin), *cat_r = ar.floats(b * L[4].cin);
+    float *h1 = ar.floats(b * L[1].cout), *h2 = ar.floats(b * L[2].cout);
+    float *g1 = ar.floats(b * L[4].cout), *g2 = ar.floats(b * L[5].cout);
+    float *pout = ar.floats(b * L[3].cout), *rout = ar.floats(b * 2), *prop = ar.floats(b * 2);
+    if (!ar.ok) return mpsr::fail(MPSR_ERR_WORKSPACE, "heads_fwd: workspace %zu bytes too small", workspace_bytes);
+
+    HeadIn in;
+    in.boxes = boxes_2d; in.cam_p = cam_p; in.view = view_angs; in.mean_lwh = mean_lwh; in.z_off = cen_z_offset;
+    in.cls = class_idx; in.k = *consts;
+    int rc;
+    // both img_fc layers share the flattened features: one GEMM, N = 2 x 1024, split along K = 18432
+    if ((rc = run_layer(blob, L[0], feat_box3d, B, 1, 1, nullptr, imgfc, splits, skws, (size_t)splits * b * L[0].cout, s)))
+        return rc;
+    {
+        const int total = B * L[1].cin;
+        hipLaunchKernelGGL(head_concat_prop_kernel, dim3(mpsr::ceil_div(total, 256)), dim3(256), 0, s, in, imgfc,
+                           L[0].cout, nfc, L[1].cin, B, cat_p);
+        MPSR_CHECK_LAUNCH("head_concat_prop_kernel");
+    }
+    if ((rc = run_layer(blob, L[1], cat_p, B, 1, 1, nullptr, h1, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[2], h1, B, 1, 1, nullptr, h2, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[3], h2, B, 1, 1, nullptr, pout, 1, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(head_prop_outputs_kernel, dim3(mpsr::ceil_div(B, 256)), dim3(256), 0, s, in, pout, B, *outs, prop);
+    MPSR_CHECK_LAUNCH("head_prop_outputs_kernel");
+    {
+        const int total = B * L[4].cin;
+        hipLaunchKernelGGL(head_concat_reg_kernel, dim3(mpsr::ceil_div(total, 256)), dim3(256), 0, s, in, imgfc,
+                           L[0].cout, nfc, L[4].cin, B, pout, prop, cat_r);
+        MPSR_CHECK_LAUNCH("head_concat_reg_kernel");
+    }
+    if ((rc = run_layer(blob, L[4], cat_r, B, 1, 1, nullptr, g1, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[5], g1, B, 1, 1, nullptr, g2, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[6], g2, B, 1, 1, nullptr, rout, 1, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(head_final_kernel, dim3(mpsr::ceil_div(B, 256)), dim3(256), 0, s, in, rout, prop, B, *outs);
+    MPSR_CHECK_LAUNCH("head_final_kernel");
+    return MPSR_OK;
+}
