@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- instance-crops/s through MonoPSR's per-instance hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic instances per GPU (BASELINE.json config 3):
+    256 synthetic 48x48 RGB crops  -> ResNet-101 trunk to block3 (output stride 4)
+    + synthetic (256,12,12,1024) full-image feature crop -> 1x1 squash, map decoder, xyz-map head (N x 3 cloud)
+    -> centroid / lwh / alpha heads
+    -> Chamfer (nn_distance) forward + backward between the first 1024 predicted points and a 1024-point GT cloud.
+Everything runs through the C ABI of libmonopsr_hip.so on the current HIP stream; inputs and weights are resident
+in HBM before the timed region.  Multi-GPU: instances are sharded, one process per GPU, no data-path collective
+(weak scaling; `--allreduce-grads` adds an RCCL all-reduce of a gradient-sized buffer per step).
+
+Prints ONE JSON line on rank 0 (contract in the task description); `roofline` and `cpu_baseline` are extra objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_CROP = 2 * 6196658176  # trunk + squash + decoder + xyz + heads, MACs x 2
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791],
+               [0.0, 0.0, 1.0, 0.002745884]], np.float32)  # a KITTI P2 (values of training/calib/000000.txt)
+
+
+def make_inputs(B, npts, rank, device):
+    """Seeded synthetic inputs of SURVEY.md 8(d) cfg 2/3 (seeds offset by rank)."""
+    def rng(seed):
+        return np.random.default_rng(seed + 1000 * rank)
+    crops = (rng(1).standard_normal((B, 48, 48, 3), dtype=np.float32) * 50)
+    full_feat = np.maximum(rng(2).standard_normal((B, 12, 12, 1024), dtype=np.float32), 0)
+    r = rng(3)
+    h, w = r.uniform(20, 200, B), r.uniform(20, 200, B)
+    y1, x1 = r.uniform(0, 375 - h), r.uniform(0, 1242 - w)
+    boxes = np.stack([y1, x1, y1 + h, x1 + w], 1).astype(np.float32)
+    view = np.arctan2((boxes[:, 1] + boxes[:, 3]) / 2 - P2[0, 2], P2[0, 0]).astype(np.float32)
+    gt = rng(5).standard_normal((B, npts, 3), dtype=np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return dict(crops=t(crops), full_feat=t(full_feat), boxes=t(boxes), cam_p=t(P2), view=t(view),
+                cls=torch.ones((B, 1), dtype=torch.int32, device=device),
+                mean_lwh=t(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                z_off=torch.full((B,), 2.17799973487854, dtype=torch.float32, device=device), gt=t(gt)), \
+        dict(crops=crops, full_feat=full_feat, boxes=boxes, view=view, gt=gt)
+
+
+class Step:
+    """One hot-path pass; all launches go to torch's current stream through the C ABI."""
+
+    def __init__(self, net, inp, npts):
+        from monopsr_amd.tf_ops.nn_distance import tf_nndistance
+        self.net, self.inp, self.npts, self.nnd = net, inp, npts, tf_nndistance
+        B = inp["crops"].shape[0]
+        self.ones = torch.ones((B, npts), dtype=torch.float32, device=inp["crops"].device)
+
+    def forward_net(self):
+        i = self.inp
+        crop_feat = self.net.trunk(i["crops"])
+        fb, _, xyz = self.net.squash_decoder(crop_feat, i["full_feat"], (48, 48), want_feat_map=False)
+        out = self.net.heads_fwd(fb, i["boxes"], i["cam_p"], i["view"], i["cls"], i["mean_lwh"], i["z_off"])
+        return xyz, out
+
+    def __call__(self):
+        xyz, out = self.forward_net()
+        B = xyz.shape[0]
+        pred = xyz.reshape(B, -1, 3)[:, :self.npts].contiguous()
+        with torch.no_grad():
+            d1, i1, d2, i2 = self.nnd.nn_distance(pred, self.inp["gt"])
+            g1, g2 = self.nnd.nn_distance_grad(pred, self.inp["gt"], self.ones, i1, self.ones, i2)
+        return out["centroids"], d1, d2, g1, g2
+
+
+def conv_replay(net, B):
+    """Every conv/FC launch of one step (same shapes, same order) with nothing in between, so that HIP events
+    around it time the dominant kernel alone.  Returns (callable, launches per call)."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    dev = net.device
+    jobs = []
+
+    def add(part, idx, M_hw, alg_cin=None):
+        r = part.records[idx]
+        Bq, H, W = M_hw
+        x = torch.empty((Bq * H * W * r["cin"],), dtype=torch.float32, device=dev).normal_()
+        y = torch.empty((Bq * H * W * r["cout"],), dtype=torch.float32, device=dev)
+        jobs.append((x, y, part.blob, r, Bq, H, W, alg_cin or r["cin"]))  # alg_cin: K without zero padding
+
+    tr = net.crop_trunk
+    add(tr, 0, (B * 576, 1, 1), 147)
+    for k in range(1, tr.n):
+        add(tr, k, (B, 12, 12))
+    dec = net.decoder
+    for k, hw in enumerate([(12, 12), (12, 12), (24, 24), (24, 24), (48, 48), (48, 48), (48, 48)]):
+        add(dec, k, (B, hw[0], hw[1]))
+    hd = net.heads
+    for k in range(1, hd.n):  # img_fc (split-K + reduce kernel) is left out: it is not a pure conv launch
+        add(hd, k, (B, 1, 1), {1: 1043, 4: 1060}.get(k))
+
+    def run():
+        s = _lib.stream()
+        for x, y, blob, r, Bq, H, W, _ in jobs:
+            bias = blob.data_ptr() + 4 * r["b_off"] if r["b_off"] >= 0 else None
+            _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), Bq, H, W, r["cin"], blob.data_ptr() + 4 * r["w_off"],
+                                                bias, None, y.data_ptr(), r["cout"], r["kh"], r["kw"], r["dilation"],
+                                                r["relu"], 1, None, 0, s))
+    flops = sum(2.0 * Bq * H * W * cin * r["kh"] * r["kw"] * r["cout"] for _, _, _, r, Bq, H, W, cin in jobs)
+    return run, len(jobs), flops
+
+
+def cpu_baseline(weights, host, sample, npts):
+    """The CPU restatement (oracle/net.py on torch CPU, all host cores) + the C Chamfer oracle (1 thread) on the
+    first `sample` instances of the same workload.  Reported baseline only."""
+    from oracle import net as onet
+    from oracle import ops as orc
+    if sample <= 0:  # size the sample for roughly 15 s of CPU work from a 2-instance probe
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            onet.resnet101_block3(torch.from_numpy(host["crops"][:2]), weights,
+                                  "FirstStageFeatureExtractor_crop/resnet_v1_101")
+        per = (time.perf_counter() - t0) / 2 * 1.6  # trunk is ~64 % of the per-crop work
+        sample = int(max(4, min(host["crops"].shape[0], 15.0 / per)))
+    s = slice(0, sample)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = onet.instance_path(host["crops"][s], host["full_feat"][s], host["boxes"][s], P2, host["view"][s],
+                                 np.ones((sample, 1), np.int32), np.tile(np.array([[3.88, 1.63, 1.53]], np.float32),
+                                                                         (sample, 1)),
+                                 np.full((sample,), 2.17799973487854, np.float32), weights)
+    pred = ref["inst_xyz_map_local"].reshape(sample, -1, 3)[:, :npts].contiguous().numpy()
+    d1, i1, d2, i2 = orc.nn_distance(pred, host["gt"][s])
+    orc.nn_distance_grad(pred, host["gt"][s], np.ones_like(d1), i1, np.ones_like(d2), i2)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "first %d instances of the same workload: oracle/net.py (PyTorch-CPU fp32 restatement of the "
+                      "TF1 graph, %d threads) + oracle C Chamfer fwd/bwd (1 thread), %.1f s" %
+                      (sample, torch.get_num_threads(), dt)}, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="instances per GPU")
+    ap.add_argument("--points", type=int, default=1024, help="points per cloud for Chamfer")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="instances timed on the host CPU (0 = skip, -1 = size for ~15 s of CPU work)")
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="also all-reduce a 100,204,832-float buffer per step (size of the model's gradient)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    n_gpus = world
+
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    weights = W.synthetic_weights(seed=0)
+    net = dn.DeviceNet(weights, device=device)
+    inp, host = make_inputs(args.batch, args.points, rank, device)
+    step = Step(net, inp, args.points)
+    grad_buf = torch.zeros((100204832,), dtype=torch.float32, device=device) if args.allreduce_grads else None
+
+    def one_step():
+        out = step()
+        if grad_buf is not None and dist is not None:
+            dist.all_reduce(grad_buf)
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = {
+        "metric": "instance-crops/sec (fwd+Chamfer)",
+        "value": round(args.batch * n_gpus * args.steps / elapsed, 2),
+        "unit": "crops/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE cfg3: batch=%d/GPU synthetic 48x48 crops -> ResNet-101 trunk(block3, os4) + "
+                               "squash/map-decoder/xyz + heads fwd, + %d-pt nn_distance Chamfer fwd/bwd" %
+                               (args.batch, args.points),
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * n_gpus, "points": args.points,
+                   "sharding": "instances/%d, no data-path collective" % n_gpus +
+                               (" + all-reduce(401 MB synthetic grad buffer)" if args.allreduce_grads else "")},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel alone: every conv/FC launch of one step, timed with events on the launch stream
+        run, launches, flops = conv_replay(net, args.batch)
+        run()
+        torch.cuda.synchronize()
+        reps = max(3, min(10, args.steps))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * launches)
+        achieved = flops / launches / avg_s / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM)",
+                              "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                              "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
+                              "flops_per_launch": round(flops / launches)}
+    if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
+        result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
