@@ -193,11 +193,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 
     // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     const int col = lane & 31, rsub = (lane >> 5) * 4;
+    float *dst = p.splits == 1 ? p.y : p.ws + (size_t)si * p.M * p.N;
+    const bool fused = p.splits == 1;
+    if ((p.N & 3) == 0) {
+        // Vector path: each wave transposes one 32x32 accumulator tile at a time through its own 4.5 KiB LDS
+        // slice so that a lane owns 4 consecutive channels of a pixel: 16-byte residual loads / output stores
+        // (4x fewer memory instructions than the element-per-lane layout; the K = 256 conv3 layers are
+        // epilogue-bound otherwise).
+        __syncthreads();  // every wave is done with the last A/B tile
+        float *ep = lds + wave * (32 * LDS_STRIDE);
+        const int erow = lane >> 3, ecol = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + ecol;
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fused && p.bias && n < p.N) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + rsub) * LDS_STRIDE + col] = acc[i][j][e];
+                __builtin_amdgcn_wave_barrier();
+                const int mb = m0 + (wm * TM + i) * 32 + erow;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    float4 v = *reinterpret_cast<const float4 *>(&ep[(erow + 8 * it) * LDS_STRIDE + ecol]);
+                    const int m = mb + 8 * it;
+                    if (m < p.M && n < p.N) {
+                        const size_t o = (size_t)m * p.N + n;
+                        if (fused) {
+                            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                            if (p.residual) {
+                                const float4 r = *reinterpret_cast<const float4 *>(p.residual + o);
+                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                            }
+                            if (p.relu) {
+                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            }
+                        }
+                        *reinterpret_cast<float4 *>(dst + o) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    // scalar path (N not a multiple of 4: the 3-channel xyz head, the 27- and 2-wide head outputs)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + col;
         if (n >= p.N) continue;
-        const float bias = (p.splits == 1 && p.bias) ? p.bias[n] : 0.f;
+        const float bias = (fused && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + rsub;
@@ -207,14 +253,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
                 if (m >= p.M) continue;
                 const size_t o = (size_t)m * p.N + n;
                 float v = acc[i][j][e];
-                if (p.splits == 1) {
+                if (fused) {
                     v += bias;
                     if (p.residual) v += p.residual[o];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
-                } else {
-                    p.ws[(size_t)si * p.M * p.N + o] = v;
                 }
+                dst[o] = v;
             }
         }
     }
@@ -293,9 +337,11 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     int rc;
     int sel = tile_override();
     if (sel < 0) {
+        // measured on MI355X (tools/conv_layer_bench.py, profiles/): 128x128 wins once there are >= ~18 tiles per CU
+        // (the 24x24 / 48x48 decoder layers, 130-137 TFLOP/s); the 12x12 trunk layers (M = 36864 at B = 256) only
+        // make 2.25 tiles of 128x128 per CU, so 64x64 tiles (9 per CU, 7 waves/SIMD) balance and overlap better
         if (N <= 32) sel = 4;
-        else if (p.M <= 1024) sel = 3;
-        else if (N <= 64) sel = 1;
+        else if (p.M < 131072) sel = 3;
         else sel = 0;
     }
     switch (sel) {

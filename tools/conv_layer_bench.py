@@ -1,0 +1,89 @@
+"""Per-layer-shape timing of mpsr_conv2d_nhwc_f32 on the GPU for every tile configuration.
+
+    python tools/conv_layer_bench.py [--batch 256] [--tiles 0,1,2,3]
+
+Prints, per distinct layer shape of the instance path, launches per step, GFLOP, and TFLOP/s for each tile
+configuration (the knob is mpsr_debug_set_conv_tile; -1 = the library's heuristic).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monopsr_amd import _lib  # noqa: E402
+
+# (name, count per step, M spatial (H, W), C, N, k, dilation, residual)
+SHAPES = [
+    ("root 1x1 over im2col", 1, (576, 1), 160, 64, 1, 1, False),
+    ("b1 conv1 256->64", 2, (12, 12), 256, 64, 1, 1, False),
+    ("b1 conv2 3x3 64", 3, (12, 12), 64, 64, 3, 1, False),
+    ("b1 conv3 64->256 +res", 3, (12, 12), 64, 256, 1, 1, True),
+    ("b2 conv1 512->128", 3, (12, 12), 512, 128, 1, 1, False),
+    ("b2 conv2 3x3 128 d2", 4, (12, 12), 128, 128, 3, 2, False),
+    ("b2 conv3 128->512 +res", 4, (12, 12), 128, 512, 1, 1, True),
+    ("b3 shortcut 512->1024", 1, (12, 12), 512, 1024, 1, 1, False),
+    ("b3 conv1 1024->256", 22, (12, 12), 1024, 256, 1, 1, False),
+    ("b3 conv2 3x3 256 d4", 23, (12, 12), 256, 256, 3, 4, False),
+    ("b3 conv3 256->1024 +res", 23, (12, 12), 256, 1024, 1, 1, True),
+    ("squash half 1024->512", 2, (12, 12), 1024, 512, 1, 1, False),
+    ("dec conv2_1 3x3 512->256", 1, (24, 24), 512, 256, 3, 1, False),
+    ("dec conv2_2 3x3 256->256", 1, (24, 24), 256, 256, 3, 1, False),
+    ("dec conv3_1 3x3 256->128", 1, (48, 48), 256, 128, 3, 1, False),
+    ("dec conv3_2 3x3 128->128", 1, (48, 48), 128, 128, 3, 1, False),
+    ("xyz 3x3 128->3", 1, (48, 48), 128, 3, 3, 1, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--tiles", default="-1,0,1,2,3")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    tiles = [int(t) for t in args.tiles.split(",")]
+    lib = _lib.lib()
+    dev = torch.device("cuda")
+    B = args.batch
+    print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("tile%2d TF/s (us)" % t for t in tiles)))
+    total = {t: 0.0 for t in tiles}
+    for name, count, (H, W), C, N, k, dil, res in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn((B, H, W, C), device=dev)
+        w = torch.randn((N, k * k * C), device=dev) * 0.05
+        bias = torch.randn((N,), device=dev)
+        r = torch.randn((B, H, W, N), device=dev) if res else None
+        y = torch.empty((B, H, W, N), device=dev)
+        flop = 2.0 * B * H * W * C * k * k * N
+        cells = []
+        for t in tiles:
+            if t == 4 and N > 32:
+                cells.append("      -        ")
+                continue
+            lib.mpsr_debug_set_conv_tile(t)
+
+            def run():
+                _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
+                                                    r.data_ptr() if res else None, y.data_ptr(), N, k, k, dil, 1, 1,
+                                                    None, 0, _lib.stream()))
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.reps
+            total[t] += us * count
+            cells.append("%6.1f (%7.1f)" % (flop / us / 1e6, us))
+        lib.mpsr_debug_set_conv_tile(-1)
+        print("%-28s %3d %9.2f | %s" % (name, count, flop / 1e9, "  ".join(cells)))
+    print("per-step conv time (ms): " + "  ".join("tile%d %.2f" % (t, total[t] / 1e3) for t in tiles))
+
+
+if __name__ == "__main__":
+    main()
