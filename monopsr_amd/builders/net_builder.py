@@ -1,0 +1,55 @@
+"""Feature extraction of the instance path, mirroring builders/net_builder.py:17-96 of the reference.
+
+Same entry point, arguments and returned dict keys; the graph underneath is libmonopsr_hip.so:
+two ResNet-101 trunks (crop, full image) -> feature crop + 2x2 max-pool -> [concat] -> 1x1 squash ->
+2x2 max-pool (FEATURES_FOR_BOX_3D) / map decoder (FEATURES_FOR_MAP).
+"""
+from monopsr_amd.core import constants
+from monopsr_amd.core import device_net as dn
+
+
+def get_net_config(model_config):
+    net_type = model_config.net_type
+    return getattr(model_config.net_config, net_type)
+
+
+def extract_features(model, net_type, model_config, input_dict, is_training):
+    """model: object with `device_net` (DeviceNet), `pl_boxes_2d_norm` (B,4), `num_boxes`, `map_roi_size`,
+    `is_training`.  input_dict: NET_IN_RGB_CROP (B,h,w,3) and either NET_IN_FULL_IMG (1,H,W,3) or
+    NET_IN_FULL_IMG_FEATURE_CROP (B, map_h/4, map_w/4, 1024)."""
+    features_dict = {}
+    if net_type == 'resnet101_4x_squash':
+        return build_resnet101_4x_squash(getattr(model_config, 'net_config', None), net_type, model, input_dict,
+                                         features_dict)
+    raise ValueError('Invalid net_type', net_type)
+
+
+def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_dict):
+    net = model.device_net
+    crop_img = input_dict[constants.NET_IN_RGB_CROP]
+
+    # BatchNorm runs on its moving statistics everywhere: the trunks are frozen in the reference too
+    # (faster_rcnn_resnet_v1_feature_extractor.py:63,238); the decoder's train-mode batch statistics
+    # (net_builder.py:78-79,86-87) are not implemented -- see DESIGN.md "out of scope".
+    crop_img_encoder_out = net.trunk(crop_img, 'crop')
+
+    if constants.NET_IN_FULL_IMG_FEATURE_CROP in input_dict:
+        full_img_feature_crop = input_dict[constants.NET_IN_FULL_IMG_FEATURE_CROP]
+    else:
+        full_img = input_dict[constants.NET_IN_FULL_IMG]
+        full_img_encoder_out = net.trunk(full_img, 'full')
+        # Crop and resize, then max pool the feature map from the full image (net_builder.py:54-60)
+        half = (model.map_roi_size[0] // 2, model.map_roi_size[1] // 2)
+        full_img_feature_large_crop = dn.crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
+        full_img_feature_crop = dn.max_pool(full_img_feature_large_crop, 2, 2, "VALID")
+
+    # concat + 1x1 squash + pool + map decoder in one native call; the xyz-map head (a 3x3 conv on the map
+    # features, monopsr_output_builder.py:95-104) rides along and is handed to the output builder
+    features_pooled, map_features, xyz = net.squash_decoder(crop_img_encoder_out, full_img_feature_crop,
+                                                            tuple(model.map_roi_size))
+    features_dict.update({
+        constants.FEATURES_FOR_MAP: map_features,
+        constants.FEATURES_FOR_BOX_3D: features_pooled,
+        '_' + constants.KEY_INST_XYZ_MAP_LOCAL: xyz,
+    })
+    return features_dict

@@ -52,6 +52,31 @@ class DeviceNet:
         self.ws_trunk = Workspace(self.device)
         self.ws_dec = Workspace(self.device)
         self.ws_heads = Workspace(self.device)
+        self._weights = weights
+        self._fc_cache = {}
+
+    # ------------------------------------------------------------------ single FC layers (output builder)
+    def fully_connected(self, x, name, relu):
+        """slim.fully_connected `name` on x (B, fin) through the HIP GEMM; the input is zero-padded to a multiple
+        of 4 channels (the kernel's 16-byte load granularity)."""
+        if name not in self._fc_cache:
+            w = self._weights[name + "/weights"]  # (in, out)
+            kpad = (w.shape[0] + 3) // 4 * 4
+            w_ok = np.zeros((w.shape[1], kpad), np.float32)
+            w_ok[:, :w.shape[0]] = w.T
+            self._fc_cache[name] = (torch.from_numpy(w_ok).to(self.device),
+                                    torch.from_numpy(self._weights[name + "/biases"].astype(np.float32)).to(self.device),
+                                    w.shape[0], kpad)
+        w_ok, bias, fin, kpad = self._fc_cache[name]
+        B = x.shape[0]
+        if x.shape[1] != fin:
+            raise _lib.InvalidArgumentError("%s expects %d input features, got %d" % (name, fin, x.shape[1]))
+        if kpad != fin:
+            xp = torch.zeros((B, kpad), dtype=torch.float32, device=self.device)
+            xp[:, :fin] = x
+            x = xp
+        split = 8 if kpad >= 8192 else 1
+        return conv2d(x.reshape(B, 1, 1, kpad), w_ok, bias, None, 1, 1, 1, relu, split_k=split).reshape(B, -1)
 
     # ------------------------------------------------------------------ trunk
     def trunk(self, img, which="crop"):

@@ -1,0 +1,239 @@
+"""Output heads of the instance path, mirroring core/models/monopsr/monopsr_output_builder.py:37-661.
+
+Method names, arguments, output_dict keys and the order of operations are the reference's; every fully connected
+layer runs through the HIP fp32-MFMA GEMM (DeviceNet.fully_connected), the per-box scalar algebra (a few flops
+per box) is plain tensor arithmetic on the GPU.  The fused native fast path for the same graph is
+mpsr_heads_fwd (DeviceNet.heads_fwd); tests check that both agree.
+Only the output types of monopsr_model_000.yaml plus their 'est' variants are implemented; 'gt' variants and the
+global-map projection / box rescoring (:663-860) are out of scope.
+"""
+import torch
+
+from monopsr_amd.core import constants
+
+PROP_CEN_Y_NORM = 1.666754  # monopsr_output_builder.py:246
+CEN_Y_CLASS_OFFSET = {('Car', 'kitti'): 0.0648, ('Car', 'mscnn'): 0.0655, ('Pedestrian', 'kitti'): 0.0145,
+                      ('Pedestrian', 'mscnn'): 0.0142, ('Cyclist', 'kitti'): 0.0239, ('Cyclist', 'mscnn'): 0.0239}
+CAM_P_NORM = [1000.0, 1.0, 1000.0, 100.0, 1.0, 1000.0, 1000.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+
+
+class UniqueKeyDict:
+    def __init__(self, init_entries=None):
+        self.dict = init_entries if init_entries is not None else {}
+
+    def __getitem__(self, key):
+        return self.dict[key]
+
+    def add_unique_to_dict(self, new_entries):
+        for key, value in new_entries.items():
+            if self.dict.get(key, None) is None:
+                self.dict.update({key: value})
+            else:
+                raise ValueError('Key {} already exists in output_dict'.format(key))
+
+
+def tf_boxes_2d_ij_fmt(boxes_2d, cam_p):
+    """datasets/kitti/obj_utils.py:1016-1034: box coordinates relative to the principal point."""
+    centre_u, centre_v = cam_p[0, 2], cam_p[1, 2]
+    return boxes_2d - torch.stack([centre_v, centre_u, centre_v, centre_u])
+
+
+def tf_est_y_from_box_2d_and_depth(cam_p, box_2d, depth, class_str=None, trend_data='kitti'):
+    """datasets/kitti/instance_utils.py:907-953."""
+    focal_length, centre_v = cam_p[0, 0], cam_p[1, 2]
+    box_2d_centre_v = ((box_2d[:, 2] + box_2d[:, 0]) / 2. - centre_v).unsqueeze(1)
+    cen_y_mid_estimate = box_2d_centre_v * (depth / focal_length)
+    if (class_str, trend_data) not in CEN_Y_CLASS_OFFSET:
+        raise ValueError('Invalid class_str', class_str)
+    return cen_y_mid_estimate - CEN_Y_CLASS_OFFSET[(class_str, trend_data)]
+
+
+class MonoPSROutputBuilder:
+
+    def __init__(self, output_config, model_config, dataset_config, features_dict, num_boxes, map_roi_size, cam_p,
+                 train_val_test, device_net=None):
+        self.output_config = output_config.__dict__ if hasattr(output_config, '__dict__') else dict(output_config)
+        self.output_types = MonoPSROutputBuilder.get_output_types_list(output_config)
+        self.model_config = model_config
+        self.dataset_config = dataset_config
+        self._output_dict = UniqueKeyDict()
+        self._features_dict = UniqueKeyDict(features_dict)
+        self._gt_dict = UniqueKeyDict()
+        self.num_boxes = num_boxes
+        self.map_roi_size = map_roi_size
+        self.cam_p = cam_p.reshape(3, 4)
+        self.features_for_map = features_dict[constants.FEATURES_FOR_MAP]
+        self.features_for_box_3d = features_dict[constants.FEATURES_FOR_BOX_3D]
+        self.train_val_test = train_val_test
+        self.is_training = train_val_test == 'train'
+        self.is_train_or_val = train_val_test in ['train', 'val']
+        self.net = device_net
+
+    @staticmethod
+    def get_output_types_list(output_config):
+        d = output_config.__dict__ if hasattr(output_config, '__dict__') else dict(output_config)
+        return sorted([k for k in d.keys() if not k.startswith('__')])
+
+    def get_output_dict(self):
+        return self._output_dict
+
+    def get_output(self):
+        return self._output_dict.dict
+
+    def get_features_dict(self):
+        return self._features_dict.dict
+
+    def get_gt_dict(self):
+        return self._gt_dict.dict
+
+    # ------------------------------------------------------------------ local xyz map (:95-108)
+    def add_inst_xyz_maps_local(self, gt_inst_xyz_maps_local):
+        output_key = constants.KEY_INST_XYZ_MAP_LOCAL
+        output = self._features_dict.dict.get('_' + output_key)
+        if output is None:
+            raise ValueError('features_dict holds no xyz map; build the features with net_builder.extract_features')
+        self._output_dict.add_unique_to_dict({output_key: output})
+        if self.is_train_or_val:
+            self._gt_dict.add_unique_to_dict({output_key: gt_inst_xyz_maps_local})
+
+    # ------------------------------------------------------------------ shared scalar features
+    def _box_features(self, boxes_2d, class_indices, image_shape):
+        box_2d_coords = tf_boxes_2d_ij_fmt(boxes_2d, self.cam_p)
+        box_2d_heights = (boxes_2d[:, 2] - boxes_2d[:, 0]).unsqueeze(1)
+        box_2d_heights_norm = box_2d_heights / image_shape[0]
+        half_img_height, half_img_width = image_shape[0] / 2.0, image_shape[1] / 2.0
+        norm = torch.tensor([half_img_height, half_img_width, half_img_height, half_img_width],
+                            dtype=torch.float32, device=boxes_2d.device)
+        box_2d_coords_norm = box_2d_coords / norm
+        num_classes = len(self.dataset_config.classes)
+        idx = class_indices.reshape(-1).to(torch.int64)
+        one_hot = torch.zeros((idx.shape[0], num_classes), dtype=torch.float32, device=boxes_2d.device)
+        ok = (idx >= 0) & (idx < num_classes)  # tf.one_hot: out-of-range index -> all off
+        one_hot[ok, idx[ok]] = 1.0
+        return box_2d_coords_norm, box_2d_heights_norm, one_hot
+
+    # ------------------------------------------------------------------ proposal FC stack (:126-194)
+    def get_proposal_fc_features(self):
+        return self._features_dict[constants.FEATURES_PROPOSAL_FC_OUT]
+
+    def add_proposal_fc_features(self, boxes_2d, view_angs, class_indices, image_shape):
+        p = 'output/proposal_fc/proposal_fc/'
+        flat_img_features = self.features_for_box_3d.reshape(self.features_for_box_3d.shape[0], -1)
+        coords_norm, heights_norm, one_hot = self._box_features(boxes_2d, class_indices, image_shape)
+        img_fc = self.net.fully_connected(flat_img_features, p + 'img_fc', True)
+        cam_p_normalized = self.cam_p.reshape(1, -1) / torch.tensor([CAM_P_NORM], dtype=torch.float32,
+                                                                    device=self.cam_p.device)
+        cam_p_tiled = cam_p_normalized.repeat(self.num_boxes, 1)
+        features_concat = torch.cat([img_fc, coords_norm, heights_norm, view_angs, one_hot, cam_p_tiled], dim=1)
+        fc_drop = features_concat
+        for fc_idx, _ in enumerate(self.model_config.proposal_fc_layers.layer_sizes):
+            fc_drop = self.net.fully_connected(fc_drop, p + 'fc{}'.format(fc_idx), True)  # dropout keep 1.0
+        self._features_dict.add_unique_to_dict({constants.FEATURES_PROPOSAL_FC_OUT: fc_drop})
+
+    # ------------------------------------------------------------------ regression FC stack (:200-274)
+    def get_regression_fc_features(self):
+        return self.get_features_dict()[constants.FEATURES_REGRESSION_FC_OUT]
+
+    def add_regression_fc_features(self, boxes_2d, view_angs, class_indices, image_shape, est_lwh_off,
+                                   est_alpha_bins, est_alpha_regs, prop_cen_y, prop_cen_z, max_depth):
+        r = 'output/regression_fc/regression_fc/'
+        flat_img_features = self.features_for_box_3d.reshape(self.features_for_box_3d.shape[0], -1)
+        coords_norm, heights_norm, one_hot = self._box_features(boxes_2d, class_indices, image_shape)
+        prop_cen_y_norm = prop_cen_y / PROP_CEN_Y_NORM
+        prop_cen_z_norm = prop_cen_z / max_depth
+        img_fc = self.net.fully_connected(flat_img_features, r + 'img_fc', True)
+        features_concat = torch.cat([img_fc, coords_norm, heights_norm, view_angs, one_hot, est_lwh_off,
+                                     est_alpha_bins, est_alpha_regs, prop_cen_y_norm, prop_cen_z_norm], dim=1)
+        fc_drop = features_concat
+        for fc_idx, _ in enumerate(self.model_config.regression_fc_layers.layer_sizes):
+            fc_drop = self.net.fully_connected(fc_drop, r + 'fc{}'.format(fc_idx), True)
+        self._features_dict.add_unique_to_dict({constants.FEATURES_REGRESSION_FC_OUT: fc_drop})
+
+    # ------------------------------------------------------------------ outputs
+    def add_alpha_output(self, features_to_use, gt_alpha, gt_alpha_dc):
+        output_type = self.output_config[constants.KEY_ALPHA]
+        if output_type != 'dc':
+            raise ValueError('Invalid output_type', output_type)
+        num_alpha_bins = self.dataset_config.num_alpha_bins
+        orientation_outputs = self.net.fully_connected(features_to_use, 'output/alpha', False)
+        self._output_dict.add_unique_to_dict({
+            constants.KEY_ALPHA_BINS: orientation_outputs[:, 0:num_alpha_bins],
+            constants.KEY_ALPHA_REGS: orientation_outputs[:, num_alpha_bins:num_alpha_bins * 2],
+        })
+        if self.is_train_or_val and gt_alpha_dc is not None:
+            self._gt_dict.add_unique_to_dict({constants.KEY_ALPHA_BINS: gt_alpha_dc[0],
+                                              constants.KEY_ALPHA_REGS: gt_alpha_dc[1]})
+
+    def add_lwh_output(self, features_to_use, est_lwh, gt_lwh):
+        output_key = constants.KEY_LWH
+        output_type = self.output_config[output_key]
+        if output_type == 'offset':
+            pred_dim_offsets = self.net.fully_connected(features_to_use, 'output/lwh/lwh', False)
+            pred_lwh = est_lwh + pred_dim_offsets
+        elif output_type == 'est':
+            pred_dim_offsets = est_lwh
+            pred_lwh = est_lwh
+        else:
+            raise ValueError('Invalid output_type', output_type)
+        self._output_dict.add_unique_to_dict({output_key + '_offs': pred_dim_offsets, output_key: pred_lwh})
+        if self.is_train_or_val and gt_lwh is not None:
+            self._gt_dict.add_unique_to_dict({output_key: gt_lwh, output_key + '_offs': gt_lwh - pred_lwh})
+        return pred_lwh
+
+    def add_view_ang_output(self, output_key, features_in, est_view_angs, gt_view_angs):
+        output_type = self.output_config[output_key]
+        if output_type != 'est':
+            raise ValueError('Invalid output_type', output_type)
+        self._output_dict.add_unique_to_dict({
+            output_key + '_offs': torch.zeros((), dtype=torch.float32, device=est_view_angs.device),
+            output_key: est_view_angs,
+        })
+        if self.is_train_or_val and gt_view_angs is not None:
+            self._gt_dict.add_unique_to_dict({output_key + '_offs': gt_view_angs - est_view_angs,
+                                              output_key: gt_view_angs})
+
+    def get_prop_cen_z(self, boxes_2d, offset):
+        f = self.cam_p[0, 0]
+        est_obj_h = self.get_output_dict()[constants.KEY_LWH][:, 2]
+        boxes_2d_h = boxes_2d[:, 2] - boxes_2d[:, 0]
+        prop_cen_z = (f * est_obj_h / boxes_2d_h + offset).unsqueeze(1)
+        self._output_dict.add_unique_to_dict({constants.KEY_PROP_CEN_Z: prop_cen_z})
+        return prop_cen_z
+
+    def get_prop_cen_y(self, boxes_2d, depth, class_name):
+        return tf_est_y_from_box_2d_and_depth(self.cam_p, boxes_2d, depth, class_name, trend_data='kitti')
+
+    def add_cen_z_output(self, output_key, features_in, prop_cen_z, gt_cen_z):
+        output_type = self.output_config[output_key]
+        assert prop_cen_z.shape[1] == 1
+        if output_type != 'offset':
+            raise ValueError('Invalid output_type', output_type)
+        pred_cen_z_offsets = self.net.fully_connected(features_in, 'output/cen_z_offs/' + output_key, False)
+        pred_cen_z = prop_cen_z + pred_cen_z_offsets
+        self._output_dict.add_unique_to_dict({output_key + '_offs': pred_cen_z_offsets, output_key: pred_cen_z})
+        if self.is_train_or_val and gt_cen_z is not None:
+            self._gt_dict.add_unique_to_dict({output_key: gt_cen_z, output_key + '_offs': gt_cen_z - prop_cen_z})
+
+    def add_cen_y_output(self, output_key, features_in, prop_cen_y, gt_cen_y):
+        output_type = self.output_config[output_key]
+        if output_type == 'offset':
+            pred_cen_y_offsets = self.net.fully_connected(features_in, 'output/cen_y/' + output_key, False)
+            pred_cen_y = prop_cen_y + pred_cen_y_offsets
+        else:
+            raise ValueError('Invalid output_type', output_type)
+        self._output_dict.add_unique_to_dict({output_key + '_offs': pred_cen_y_offsets, output_key: pred_cen_y})
+        if self.is_train_or_val and gt_cen_y is not None:
+            self._gt_dict.add_unique_to_dict({output_key + '_offs': gt_cen_y - prop_cen_y, output_key: gt_cen_y})
+
+    def add_cen_x_output(self, output_key, pred_cen_z, pred_view_angs):
+        output_type = self.output_config[output_key]
+        if output_type != 'from_view_ang_and_z':
+            raise ValueError('Invalid output_type', output_type)
+        cam2_pred_cen_x = pred_cen_z * torch.tan(pred_view_angs)
+        x_offset = -self.cam_p[0, 3] / self.cam_p[0, 0]
+        self._output_dict.add_unique_to_dict({output_key: cam2_pred_cen_x + x_offset})
+
+    def add_centroids_output(self, output_key, pred_cen_x, pred_cen_y, pred_cen_z, gt_centroids):
+        self._output_dict.add_unique_to_dict({output_key: torch.cat([pred_cen_x, pred_cen_y, pred_cen_z], dim=1)})
+        if self.is_train_or_val and gt_centroids is not None:
+            self._gt_dict.add_unique_to_dict({output_key: gt_centroids})

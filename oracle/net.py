@@ -271,3 +271,29 @@ def instance_path(rgb_crops, full_feat_crop, boxes_2d, cam_p, view_angs, class_i
     out.update({"crop_feat": crop_feat, "features_for_box_3d": feat_box, "features_for_map": feat_map,
                 "inst_xyz_map_local": xyz})
     return out
+
+
+KITTI_CHANNEL_MEANS = (92.8403, 97.7996, 93.5843)
+
+
+def full_image_path(rgb_image, boxes_2d, boxes_2d_norm, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset, W,
+                    image_input_shape=(320, 1216), resized_full_img_shape=(160, 608), img_roi_size=(48, 48),
+                    map_size=(48, 48), dtype=torch.float32):
+    """The whole per-image instance path as MonoPSRModel.build wires it (monopsr_model.py:130-131, 222-237;
+    img_preprocessor.py:12-35; net_builder.py:44-60): mean-subtract + resize the image, crop the proposals,
+    run both trunks, crop + pool the full-image features, then squash / decoder / heads."""
+    img = _t(rgb_image, dtype).to(dtype).unsqueeze(0) - torch.tensor(KITTI_CHANNEL_MEANS, dtype=dtype)
+    pre = tf_resize_bilinear(img, image_input_shape[0], image_input_shape[1], False)
+    nb = len(boxes_2d_norm)
+    crops = tf_crop_and_resize(pre, boxes_2d_norm, np.zeros(nb, np.int32), img_roi_size[0], img_roi_size[1])
+    full = tf_resize_bilinear(pre, resized_full_img_shape[0], resized_full_img_shape[1], True)
+    crop_feat = resnet101_block3(crops, W, "FirstStageFeatureExtractor_crop/resnet_v1_101")
+    full_feat = resnet101_block3(full, W, "FirstStageFeatureExtractor_full/resnet_v1_101")
+    large = tf_crop_and_resize(full_feat, boxes_2d_norm, np.zeros(nb, np.int32), map_size[0] // 2, map_size[1] // 2)
+    full_crop = tf_max_pool(large, 2, 2, "VALID")
+    feat_box, feat_map, xyz = squash_decoder(crop_feat, full_crop, W, *map_size)
+    out = heads(feat_box, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset, W,
+                image_shape=image_input_shape)
+    out.update({"rgb_crops": crops, "crop_feat": crop_feat, "full_feat": full_feat, "full_feat_crop": full_crop,
+                "features_for_box_3d": feat_box, "features_for_map": feat_map, "inst_xyz_map_local": xyz})
+    return out

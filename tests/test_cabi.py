@@ -1,0 +1,65 @@
+"""CPU checks of the drop-in boundary: libmonopsr_hip.so builds for gfx950 here (no GPU), loads, and exports every
+symbol include/monopsr_hip.h declares; the ctypes binding covers exactly that set.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "monopsr_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    names = _declared()
+    for must in ("mpsr_nn_distance_fwd", "mpsr_nn_distance_bwd", "mpsr_approx_match", "mpsr_match_cost",
+                 "mpsr_match_cost_grad", "mpsr_crop_and_resize", "mpsr_trunk_fwd", "mpsr_squash_decoder_fwd",
+                 "mpsr_heads_fwd", "mpsr_last_error"):
+        assert must in names
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "monopsr_amd", "csrc")], stdout=subprocess.DEVNULL)
+    so = os.path.join(ROOT, "monopsr_amd", "libmonopsr_hip.so")
+    assert os.path.exists(so)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    exported = set(re.findall(r" T (mpsr_[a-z0-9_]+)", out))
+    missing = [n for n in _declared() if n not in exported]
+    assert not missing, missing
+
+
+def test_ctypes_binding_matches_header_and_loads():
+    from monopsr_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.lib()  # dlopen + every symbol bound; works without a GPU
+    assert lib.mpsr_abi_version() == _lib.ABI_VERSION
+    assert lib.mpsr_last_error() == b""
+    # size helpers are pure host functions
+    assert lib.mpsr_approx_match_temp_floats(2, 5, 7) == 2 * (5 + 7) * 11
+    assert lib.mpsr_trunk_workspace_bytes(0, 48, 48) == 0
+    assert lib.mpsr_trunk_workspace_bytes(2, 48, 48) > 0
+
+
+def test_struct_layouts_match_the_header():
+    from monopsr_amd import _lib
+    assert ctypes.sizeof(_lib.Layer) == 6 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.HeadConsts) == 5 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.HeadOutputs) == 11 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    """Shape errors are reported before anything touches the device (status 1 + message)."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    assert lib.mpsr_nn_distance_fwd(-1, 4, None, 4, None, None, None, None, None, None) == 1
+    assert b"negative" in lib.mpsr_last_error()
+    assert lib.mpsr_nn_distance_fwd(0, 4, None, 4, None, None, None, None, None, None) == 0  # empty batch: no-op
+    assert lib.mpsr_nn_distance_fwd(2, 4, None, 0, None, None, None, None, None, None) == 1
+    assert lib.mpsr_conv2d_nhwc_f32(None, 1, 4, 4, 6, None, None, None, None, 8, 1, 1, 1, 0, 1, None, 0, None) == 1
+    assert b"multiple of 4" in lib.mpsr_last_error()
+    assert lib.mpsr_im2col_root(None, 1, 48, 48, None, 150, None) == 1

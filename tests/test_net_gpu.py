@@ -244,3 +244,92 @@ def test_instance_path_end_to_end():
     d1, _, d2, _ = tf_nndistance.nn_distance(xyz.reshape(B, -1, 3), _dev(gt))
     r1, _, r2, _ = orc.nn_distance(ref["inst_xyz_map_local"].reshape(B, -1, 3).numpy(), gt)
     np.testing.assert_allclose((d1.sum(1) + d2.sum(1)).cpu().numpy(), r1.sum(1) + r2.sum(1), rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- reference-API mirrors
+
+def _sample(B, seed):
+    crops, boxes, cam_p, view, cls, mean_lwh, z_off = _inputs(B, seed)
+    return dict(boxes_2d=_dev(boxes), cam_p=_dev(cam_p), est_view_angs=_dev(view), class_indices=_dev(cls),
+                mean_lwh=_dev(mean_lwh), prop_cen_z_offset=_dev(z_off)), (crops, boxes, cam_p, view, cls, mean_lwh,
+                                                                           z_off)
+
+
+def test_model_build_fused_vs_output_builder_vs_oracle():
+    """MonoPSRModel.build on pre-cropped inputs: the fused native heads and the method-by-method
+    MonoPSROutputBuilder mirror give the same output_dict, and both match the CPU restatement."""
+    from monopsr_amd.core import config_utils, constants
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
+    B = 3
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=21, width_div=2)
+    net = dn.DeviceNet(weights, width_div=2)
+    sample, (crops, boxes, cam_p, view, cls, mean_lwh, z_off) = _sample(B, 22)
+    full_feat = np.maximum(np.random.default_rng(23).standard_normal((B, 12, 12, 512)), 0).astype(np.float32)
+    sample['rgb_image_crops'] = _dev(crops)
+    sample['full_img_feature_crop'] = _dev(full_feat)
+    ref = onet.instance_path(crops, full_feat, boxes, cam_p, view, cls, mean_lwh, z_off, weights)
+    outs = []
+    for fused in (True, False):
+        model = MonoPSRModel(cfg.model_config, cfg.dataset_config, net, 'test', fused_heads=fused)
+        out, feats = model.build(dict(sample))
+        outs.append(out)
+        assert tuple(feats[constants.FEATURES_FOR_MAP].shape) == (B, 48, 48, 64)
+        assert tuple(feats[constants.FEATURES_FOR_BOX_3D].shape) == (B, 6, 6, 256)
+        for key in ("inst_xyz_map_local", "lwh", "lwh_offs", "alpha_bins", "alpha_regs", "view_ang", "prop_cen_z",
+                    "cen_y", "cen_y_offs", "cen_z", "cen_z_offs", "cen_x", "centroids"):
+            _close(out[key], ref[key], 1e-4, "%s (fused=%s)" % (key, fused))
+    _close(outs[0]["centroids"], outs[1]["centroids"], 1e-5, "fused vs builder")
+
+
+def test_model_build_full_image_path_vs_oracle():
+    """image in -> preprocess, proposal crops, both trunks, feature crop + pool -> outputs."""
+    from monopsr_amd.core import config_utils
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
+    B = 3
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=31, width_div=2, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
+    net = dn.DeviceNet(weights, width_div=2, full_trunk=True)
+    rng = np.random.default_rng(32)
+    H, Wd = 375, 1242
+    rgb = rng.integers(0, 256, (H, Wd, 3)).astype(np.float32)
+    sample, (_, boxes, cam_p, view, cls, mean_lwh, z_off) = _sample(B, 33)
+    boxes[:, 2] = np.minimum(boxes[:, 2], H - 1)
+    boxes[:, 3] = np.minimum(boxes[:, 3], Wd - 1)
+    norm = (boxes / np.array([H, Wd, H, Wd], np.float32)).astype(np.float32)  # kitti_dataset.py:450
+    sample['boxes_2d'] = _dev(boxes)
+    sample['rgb_image'] = _dev(rgb)
+    sample['boxes_2d_norm'] = _dev(norm)
+    ref = onet.full_image_path(rgb, boxes, norm, cam_p, view, cls, mean_lwh, z_off, weights)
+    model = MonoPSRModel(cfg.model_config, cfg.dataset_config, net, 'test')
+    out, _ = model.build(sample)
+    for key in ("inst_xyz_map_local", "lwh", "alpha_bins", "centroids"):
+        _close(out[key], ref[key], 1e-4, key)
+
+
+def test_evaluate_predictions_metrics():
+    """Chamfer / EMD metric wiring (monopsr_model.py:1112-1170) vs the oracle ops on the same masked clouds."""
+    from monopsr_amd.core import config_utils, constants
+    from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
+    from oracle import ops as orc
+    cfg = config_utils.default_config()
+    model = MonoPSRModel(cfg.model_config, cfg.dataset_config, None, 'val')
+    rng = np.random.default_rng(41)
+    B = 4
+    pred = rng.uniform(-1, 1, (B, 16, 16, 3)).astype(np.float32)
+    gt = rng.uniform(-1, 1, (B, 16, 16, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(B, 16, 16, 1)) > 0.25).astype(np.float32)
+    m = model.evaluate_predictions({constants.KEY_INST_XYZ_MAP_LOCAL: _dev(pred)},
+                                   {constants.KEY_INST_XYZ_MAP_LOCAL: _dev(gt),
+                                    constants.KEY_VALID_MASK_MAPS: _dev(mask)}, num_objs=3)
+    p, g = (pred * mask).reshape(B, -1, 3), (gt * mask).reshape(B, -1, 3)
+    nvalid = mask.reshape(B, -1).sum(1)
+    d1, _, d2, _ = orc.nn_distance(p, g)
+    np.testing.assert_allclose(m[constants.METRIC_CHAMFER].cpu().numpy(), ((d1.sum(1) + d2.sum(1)) / nvalid)[:3],
+                               rtol=1e-5)
+    emd = orc.match_cost(p, g, orc.approx_match(p, g, "gpu"), "gpu")
+    np.testing.assert_allclose(m[constants.METRIC_EMD].cpu().numpy(), (emd / nvalid)[:3], rtol=1e-3)
