@@ -10,16 +10,23 @@
 //
 // Structure (one workgroup = 256 threads = 4 waves, BM x BN output tile, BK = 32):
 //   * A tile (BM pixels x 32 channels of one tap) is gathered straight from the NHWC activation: every thread owns
-//     fixed pixel rows for the whole K loop, so a tap is one add + bounds test per row; out-of-image taps and the
-//     K tail load zeros.  B tile (BN filters x 32) comes from the (N, K) weight matrix.  16-byte global loads.
+//     fixed pixel rows for the whole K loop, so a tap is one add + bounds test per row.  B tile (BN filters x 32)
+//     comes from the (N, K) weight matrix.  16-byte buffer loads with hardware bounds checking: out-of-image taps,
+//     rows past M / N and the K tail return zeros for one v_cndmask on the offset, so the K loop is one basic block.
 //   * Both tiles sit in LDS as [row][32 + 4 pad] floats: the 144-byte row stride makes the ds_read_b128 fragment
 //     reads and the ds_write_b128 fills bank-conflict free (MI355X_MICROARCH.md LDS table).
 //   * K ordering inside a tile is chosen so a lane's four consecutive floats feed four consecutive MFMAs: lane
 //     (i = l & 31, h = l >> 5) reads A[i][8*kb + 4*h .. +3]; MFMA step s multiplies k = 8*kb + 4*h + s.
 //   * Software pipeline: next tile's global loads are issued into registers before the current tile's MFMAs and
-//     written to LDS after them (one LDS buffer, two barriers per K step); 2-4 workgroups per CU overlap.
+//     written to LDS after them (one LDS buffer, two barriers per K step); 2-7 workgroups per CU overlap.
 //   * Workgroup ids are remapped so consecutive ids of one XCD walk the N tiles of one M panel: the activation
 //     panel is fetched from HBM once and re-read from that XCD's L2.
+//   * Border-class tiling for atrous 3x3 layers: with dilation d on an H x W map, a pixel in the first / last d rows
+//     (columns) has one row (column) of taps entirely outside the image.  Output pixels are therefore grouped into
+//     up to 9 rectangles ("classes") whose pixels share the same set of in-image taps; an M tile holds pixels of ONE
+//     class (from several images) and its K loop visits only that class's taps.  On the 12x12, d = 4 block3 layers
+//     this skips 40 % of the multiply-adds (4, 6 or 9 taps instead of 9), on block2 (d = 2) 21 % -- with results
+//     bit-identical to visiting the zero taps.
 //   * split_k > 1 writes raw partial tiles to a workspace; a second kernel reduces and applies the epilogue
 //     (used for the K = 18432 fully-connected layers where M = batch is small).
 #include "common.h"
@@ -30,6 +37,15 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats per LDS row
+constexpr int MAX_CLS = 9;
+
+// A rectangle of output pixels [y0, y0+h) x [x0, x0+w) of every image whose in-image taps are ky0..ky1 x kx0..kx1.
+struct PixelClass {
+    int y0, h, x0, w;
+    int ky0, ky1, kx0, kx1;
+    int tiles;  // M tiles of this class
+    int rows;   // B * h * w
+};
 
 struct ConvParams {
     const float *x;
@@ -40,8 +56,10 @@ struct ConvParams {
     float *ws;
     int M, H, W, C, N, KH, KW, dil, relu;
     int ksteps_total, ksteps_per_split, cblocks;
-    int mtiles, ntiles, splits;
+    int mtiles_xcd, ntiles, splits;  // mtiles_xcd: M tiles per XCD (max over XCDs)
     unsigned xbytes, wbytes;
+    int ncls;
+    PixelClass cls[MAX_CLS];
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -53,38 +71,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE];
     float *As = lds, *Bs = lds + BM * LDS_STRIDE;
 
-    // XCD-aware bijective remap: ids b, b+8, b+16, ... (one XCD) -> consecutive tiles
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ni = t % p.ntiles;
-    const int mi = (t / p.ntiles) % p.mtiles;
-    const int si = t / (p.ntiles * p.mtiles);
-    const int m0 = mi * BM, n0 = ni * BN;
+    // Tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness): XCD x takes M tiles
+    // x, x+8, x+16, ... of EVERY pixel class -- so each XCD gets the same mix of long and short K loops -- and walks
+    // them heaviest class first, the N tiles of one M tile back to back so its activation panel stays in that
+    // XCD's L2.  Workgroups past an XCD's share (classes whose tile count is not a multiple of 8) exit at once.
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int ni = l % p.ntiles;
+    int lm = (l / p.ntiles) % p.mtiles_xcd;
+    const int si = l / (p.ntiles * p.mtiles_xcd);
+    const int n0 = ni * BN;
+    int ci = -1;
+    for (int c = 0; c < p.ncls; ++c) {
+        const int cnt = p.cls[c].tiles > xcd ? (p.cls[c].tiles - xcd + 7) >> 3 : 0;
+        if (lm < cnt) {
+            ci = c;
+            break;
+        }
+        lm -= cnt;
+    }
+    if (ci < 0) return;  // block-uniform
+    const PixelClass pc = p.cls[ci];
+    const int r0 = (xcd + 8 * lm) * BM;  // first row of the tile inside its class
+    const int ppi = pc.h * pc.w;               // class pixels per image
+    const int ntx = pc.kx1 - pc.kx0 + 1;
+    const int ksteps_cls = (pc.ky1 - pc.ky0 + 1) * ntx * p.cblocks;
     const int ks_begin = si * p.ksteps_per_split;
-    const int ks_end = min(p.ksteps_total, ks_begin + p.ksteps_per_split);
+    const int ks_end = min(ksteps_cls, ks_begin + p.ksteps_per_split);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
-    // Global loads go through buffer descriptors: a voffset at/after num_records returns zeros in hardware, so an
-    // out-of-image tap, a row past M / N and the K tail cost one v_cndmask on the 32-bit offset -- no branch, no
-    // select on the data -- and the K loop stays a single basic block.  (Host guarantees both tensors < 4 GiB.)
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.wbytes, 0x00020000);
+
+    // class row -> (y, x, linear NHWC pixel index); -1 for rows past the end of the class
+    auto decode = [&](int row, int &yy, int &xx) -> int {
+        if (row >= pc.rows) {
+            yy = -(1 << 20);  // fails every bounds test
+            xx = 0;
+            return -1;
+        }
+        const int img = row / ppi, pp = row - img * ppi;
+        const int py = pp / pc.w;
+        yy = pc.y0 + py;
+        xx = pc.x0 + (pp - py * pc.w);
+        return (img * p.H + yy) * p.W + xx;
+    };
 
     // per-thread A rows: pixel coordinates and byte offset are fixed for the whole K loop
     int ay[AV], ax[AV];
     unsigned abase[AV];
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
-        const int m = m0 + lrow + 32 * j;
-        const bool valid = m < p.M;
-        const int pix = valid ? m % (p.H * p.W) : 0;
-        ay[j] = valid ? pix / p.W : -(1 << 20);  // an invalid row fails every bounds test
-        ax[j] = pix % p.W;
-        abase[j] = (unsigned)(valid ? m : 0) * (unsigned)p.C * 4u;
+        const int pix = decode(r0 + lrow + 32 * j, ay[j], ax[j]);
+        abase[j] = (unsigned)(pix < 0 ? 0 : pix) * (unsigned)p.C * 4u;
     }
     const int Ktot = p.KH * p.KW * p.C;
     unsigned bbase[BV];
@@ -94,13 +137,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         bbase[j] = n < p.N ? (unsigned)n * (unsigned)Ktot * 4u : p.wbytes;  // past the end -> zeros
     }
 
-    // K-step state, advanced incrementally (channel block fastest, then kx, then ky)
+    // K-step state, advanced incrementally (channel block fastest, then kx, then ky over the class's taps)
     int st_cb, st_kx, st_ky;
     {
         const int tap = ks_begin / p.cblocks;
         st_cb = ks_begin - tap * p.cblocks;
-        st_ky = tap / p.KW;
-        st_kx = tap - st_ky * p.KW;
+        const int ty = tap / ntx;
+        st_ky = pc.ky0 + ty;
+        st_kx = pc.kx0 + (tap - ty * ntx);
     }
     float4 ra[AV], rb[BV];
     auto load_tile = [&]() {  // loads the tile of the current K-step state, then advances the state
@@ -123,8 +167,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         }
         if (++st_cb == p.cblocks) {
             st_cb = 0;
-            if (++st_kx == p.KW) {
-                st_kx = 0;
+            if (++st_kx > pc.kx1) {
+                st_kx = pc.kx0;
                 ++st_ky;
             }
         }
@@ -195,6 +239,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     const int col = lane & 31, rsub = (lane >> 5) * 4;
     float *dst = p.splits == 1 ? p.y : p.ws + (size_t)si * p.M * p.N;
     const bool fused = p.splits == 1;
+    int dy_, dx_;
     if ((p.N & 3) == 0) {
         // Vector path: each wave transposes one 32x32 accumulator tile at a time through its own 4.5 KiB LDS
         // slice so that a lane owns 4 consecutive channels of a pixel: 16-byte residual loads / output stores
@@ -204,27 +249,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         float *ep = lds + wave * (32 * LDS_STRIDE);
         const int erow = lane >> 3, ecol = (lane & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + ecol;
-            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fused && p.bias && n < p.N) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+        for (int i = 0; i < TM; ++i) {
+            int pix[4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int it = 0; it < 4; ++it) pix[it] = decode(r0 + (wm * TM + i) * 32 + erow + 8 * it, dy_, dx_);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + ecol;
+                float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fused && p.bias && n < p.N) bias = *reinterpret_cast<const float4 *>(p.bias + n);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + rsub) * LDS_STRIDE + col] = acc[i][j][e];
                 __builtin_amdgcn_wave_barrier();
-                const int mb = m0 + (wm * TM + i) * 32 + erow;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     float4 v = *reinterpret_cast<const float4 *>(&ep[(erow + 8 * it) * LDS_STRIDE + ecol]);
-                    const int m = mb + 8 * it;
-                    if (m < p.M && n < p.N) {
-                        const size_t o = (size_t)m * p.N + n;
+                    if (pix[it] >= 0 && n < p.N) {
+                        const size_t o = (size_t)pix[it] * p.N + n;
                         if (fused) {
                             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
                             if (p.residual) {
-                                const float4 r = *reinterpret_cast<const float4 *>(p.residual + o);
-                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                                const float4 rr = *reinterpret_cast<const float4 *>(p.residual + o);
+                                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                             }
                             if (p.relu) {
                                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -240,21 +286,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     }
     // scalar path (N not a multiple of 4: the 3-channel xyz head, the 27- and 2-wide head outputs)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + col;
-        if (n >= p.N) continue;
-        const float bias = (fused && p.bias) ? p.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + rsub;
+        for (int e = 0; e < 16; ++e) {
+            const int pix = decode(r0 + (wm * TM + i) * 32 + rsub + (e & 3) + 8 * (e >> 2), dy_, dx_);
+            if (pix < 0) continue;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m >= p.M) continue;
-                const size_t o = (size_t)m * p.N + n;
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + col;
+                if (n >= p.N) continue;
+                const size_t o = (size_t)pix * p.N + n;
                 float v = acc[i][j][e];
                 if (fused) {
-                    v += bias;
+                    if (p.bias) v += p.bias[n];
                     if (p.residual) v += p.residual[o];
                     if (p.relu) v = fmaxf(v, 0.f);
                 }
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     }
 }
 
-// y = act(sum_s ws[s] + bias + residual), float4 over n when N % 4 == 0.
+// y = act(sum_s ws[s] + bias + residual)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long MN,
                                                             int N, const float *__restrict__ bias,
                                                             const float *__restrict__ residual, int relu,
@@ -281,21 +325,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch(ConvParams &p, hipStream_t s)
+// Pixel classes of a layer.  Plain layers get one class covering the image with every tap (border handled by the
+// per-row bounds tests).  Atrous 3x3 layers with room for it get up to 3 x 3 classes, longest K loops first so the
+// dispatcher starts the heavy tiles early.
+void build_classes(ConvParams &p, int B, int BM, bool use_classes)
 {
-    p.mtiles = mpsr::ceil_div(p.M, BM);
+    struct Span {
+        int o, len, k0, k1;
+    };
+    Span ys[3], xs[3];
+    int ny = 0, nx = 0;
+    const int d = p.dil, hk = p.KH >> 1, wk = p.KW >> 1;
+    if (use_classes && p.KH == 3 && p.H >= 2 * d) {
+        if (p.H - 2 * d > 0) ys[ny++] = {d, p.H - 2 * d, 0, 2};
+        ys[ny++] = {0, d, hk, 2};
+        ys[ny++] = {p.H - d, d, 0, hk};
+    } else {
+        ys[ny++] = {0, p.H, 0, p.KH - 1};
+    }
+    if (use_classes && p.KW == 3 && p.W >= 2 * d) {
+        if (p.W - 2 * d > 0) xs[nx++] = {d, p.W - 2 * d, 0, 2};
+        xs[nx++] = {0, d, wk, 2};
+        xs[nx++] = {p.W - d, d, 0, wk};
+    } else {
+        xs[nx++] = {0, p.W, 0, p.KW - 1};
+    }
+    // enumerate, then order by tap count (most first); at most 9 entries, so a selection sort will do
+    p.ncls = 0;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            PixelClass &c = p.cls[p.ncls++];
+            c.y0 = ys[a].o; c.h = ys[a].len; c.ky0 = ys[a].k0; c.ky1 = ys[a].k1;
+            c.x0 = xs[b].o; c.w = xs[b].len; c.kx0 = xs[b].k0; c.kx1 = xs[b].k1;
+            c.rows = B * c.h * c.w;
+            c.tiles = mpsr::ceil_div(c.rows, BM);
+        }
+    auto taps = [](const PixelClass &c) { return (c.ky1 - c.ky0 + 1) * (c.kx1 - c.kx0 + 1); };
+    for (int i = 0; i < p.ncls; ++i)
+        for (int j = i + 1; j < p.ncls; ++j)
+            if (taps(p.cls[j]) > taps(p.cls[i])) {
+                const PixelClass tmp = p.cls[i];
+                p.cls[i] = p.cls[j];
+                p.cls[j] = tmp;
+            }
+    p.mtiles_xcd = 0;
+    for (int i = 0; i < p.ncls; ++i) p.mtiles_xcd += mpsr::ceil_div(p.cls[i].tiles, 8);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
+{
+    build_classes(p, B, BM, use_classes);
     p.ntiles = mpsr::ceil_div(p.N, BN);
-    const long long blocks = (long long)p.mtiles * p.ntiles * p.splits;
+    const long long blocks = 8LL * p.mtiles_xcd * p.ntiles * p.splits;
     if (blocks > 0x7fffffffLL) return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv2d: grid too large");
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     MPSR_CHECK_LAUNCH("conv_igemm_kernel");
     return MPSR_OK;
 }
 
-// tuning knob (tests sweep it): -1 = heuristic, 0=128x128 1=128x64 2=64x128 3=64x64 4=128x32
+// tuning knobs (tests sweep them): tile -1 = heuristic, 0=128x128 1=128x64 2=64x128 3=64x64 4=128x32 5=96x128;
+// classes -1 = heuristic, 0 = never, 1 = whenever the geometry allows
 int g_tile_override = -1;
-int tile_override() { return g_tile_override; }
+int g_class_override = -1;
 
 }  // namespace
 
@@ -334,8 +426,13 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
             return fail(MPSR_ERR_WORKSPACE, "conv2d: split_k=%d needs %zu workspace floats, got %zu", p.splits,
                         (size_t)p.splits * p.M * N, ws_floats);
     }
+    // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little), never
+    // together with split-K (the split assumes every tile has the same K extent)
+    bool use_classes = p.splits == 1 && KH == 3 && KW == 3 && dilation > 1;
+    if (g_class_override == 0) use_classes = false;
+    if (g_class_override == 1) use_classes = p.splits == 1 && KH == 3 && KW == 3;
     int rc;
-    int sel = tile_override();
+    int sel = g_tile_override;
     if (sel < 0) {
         // measured on MI355X (tools/conv_layer_bench.py, profiles/): 128x128 wins once there are >= ~18 tiles per CU
         // (the 24x24 / 48x48 decoder layers, 130-137 TFLOP/s); the 12x12 trunk layers (M = 36864 at B = 256) only
@@ -345,11 +442,12 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         else sel = 0;
     }
     switch (sel) {
-        case 0: rc = launch<128, 128, 2, 2>(p, stream); break;
-        case 1: rc = launch<128, 64, 2, 2>(p, stream); break;
-        case 2: rc = launch<64, 128, 2, 2>(p, stream); break;
-        case 3: rc = launch<64, 64, 2, 2>(p, stream); break;
-        default: rc = launch<128, 32, 4, 1>(p, stream); break;
+        case 0: rc = launch<128, 128, 2, 2>(p, B, use_classes, stream); break;
+        case 1: rc = launch<128, 64, 2, 2>(p, B, use_classes, stream); break;
+        case 2: rc = launch<64, 128, 2, 2>(p, B, use_classes, stream); break;
+        case 3: rc = launch<64, 64, 2, 2>(p, B, use_classes, stream); break;
+        case 5: rc = launch<96, 128, 1, 4>(p, B, use_classes, stream); break;
+        default: rc = launch<128, 32, 4, 1>(p, B, use_classes, stream); break;
     }
     if (rc) return rc;
     if (p.splits > 1) {
@@ -364,9 +462,10 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 
 }  // namespace mpsr
 
-// Internal (not part of the ABI in monopsr_hip.h): force a tile configuration for tuning and for the tests that
-// sweep every instantiation.  Process-wide, not thread-safe.
+// Internal (not part of the ABI in monopsr_hip.h): force a tile configuration / the border-class tiling for tuning
+// and for the tests that sweep every instantiation.  Process-wide, not thread-safe.
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
+extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
 
 extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
                                     const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,

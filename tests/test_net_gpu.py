@@ -92,9 +92,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("classes", [-1, 0, 1])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_vs_fp64(case, tile):
+def test_conv2d_vs_fp64(case, tile, classes):
+    """Every tile instantiation x border-class tiling off / forced on (also at dilation 1) / heuristic."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
@@ -107,12 +109,33 @@ def test_conv2d_vs_fp64(case, tile):
     ref = _conv_ref(x, w, bias, res, rate, relu)
     w_ok, _ = W.fold_conv(w)
     _lib.lib().mpsr_debug_set_conv_tile(tile)
+    _lib.lib().mpsr_debug_set_conv_classes(classes)
     try:
         got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, k, k,
                         rate, relu)
     finally:
         _lib.lib().mpsr_debug_set_conv_tile(-1)
-    _close(got, ref, 2e-6, "conv %s tile %d" % (case, tile))
+        _lib.lib().mpsr_debug_set_conv_classes(-1)
+    _close(got, ref, 2e-6, "conv %s tile %d classes %d" % (case, tile, classes))
+
+
+def test_border_class_tiling_is_bit_identical():
+    """Skipping the all-zero taps of an atrous layer must not change a single bit (same products, same order)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(99)
+    for (B, H, C, N, d) in ((5, 12, 64, 96, 4), (3, 12, 32, 64, 2), (2, 9, 16, 32, 4), (2, 8, 16, 32, 4),
+                            (2, 7, 16, 32, 4), (3, 24, 16, 32, 1)):
+        x = _dev(rng.standard_normal((B, H, H, C)).astype(np.float32))
+        w = _dev((rng.standard_normal((N, 9 * C)) / np.sqrt(9 * C)).astype(np.float32))
+        outs = []
+        for mode in (0, 1):
+            _lib.lib().mpsr_debug_set_conv_classes(mode)
+            try:
+                outs.append(dn.conv2d(x, w, None, None, 3, 3, d, False).cpu().numpy())
+            finally:
+                _lib.lib().mpsr_debug_set_conv_classes(-1)
+        np.testing.assert_array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("split", [2, 3, 8, 16])

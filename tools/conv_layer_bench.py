@@ -39,12 +39,14 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--tiles", default="-1,0,1,2,3")
+    ap.add_argument("--tiles", default="-1,0,3,5")
+    ap.add_argument("--classes", type=int, default=-1)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
+    lib.mpsr_debug_set_conv_classes(args.classes)
     dev = torch.device("cuda")
     B = args.batch
     print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("tile%2d TF/s (us)" % t for t in tiles)))
