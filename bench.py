@@ -238,9 +238,20 @@ def main():
         torch.cuda.synchronize()
         avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * launches)
         achieved = flops / launches / avg_s / 1e12
+        # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes
+        # over this same command (profiles/rNN_pmc_traffic.json, bytes per conv launch), newest round first
+        traffic = None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                break
+            except Exception:
+                pass
         result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM)",
                               "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                               "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
                               "flops_per_launch": round(flops / launches)}
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
