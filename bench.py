@@ -50,6 +50,35 @@ def make_inputs(B, npts, rank, device):
         dict(crops=crops, full_feat=full_feat, boxes=boxes, view=view, gt=gt)
 
 
+class MultiStreamStep:
+    """The same pass with the batch split into `n` contiguous instance shards, each on its own HIP stream with its
+    own scratch: the short, partially filled tail of one shard's kernels overlaps the other shards' kernels
+    (instances are independent, so this is the single-GPU form of the multi-GPU sharding)."""
+
+    def __init__(self, net, inp, npts, n):
+        self.main = torch.cuda.current_stream()
+        self.streams = [torch.cuda.Stream() for _ in range(n)]
+        B = inp["crops"].shape[0]
+        per_inst = {k for k, v in inp.items() if v.dim() > 0 and v.shape[0] == B and k != "cam_p"}
+        self.steps = []
+        for i in range(n):
+            lo, hi = i * B // n, (i + 1) * B // n
+            shard = {k: (v[lo:hi].contiguous() if k in per_inst else v) for k, v in inp.items()}
+            self.steps.append(Step(net.clone_with_own_scratch(), shard, npts))
+
+    def __call__(self):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        outs = []
+        for s, step in zip(self.streams, self.steps):
+            s.wait_event(ev)
+            with torch.cuda.stream(s):
+                outs.append(step())
+        for s in self.streams:
+            self.main.wait_stream(s)
+        return outs
+
+
 class Step:
     """One hot-path pass; all launches go to torch's current stream through the C ABI."""
 
@@ -154,6 +183,8 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="also all-reduce a 100,204,832-float buffer per step (size of the model's gradient)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split each GPU's batch into this many instance shards on separate HIP streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +206,7 @@ def main():
     weights = W.synthetic_weights(seed=0)
     net = dn.DeviceNet(weights, device=device)
     inp, host = make_inputs(args.batch, args.points, rank, device)
-    step = Step(net, inp, args.points)
+    step = Step(net, inp, args.points) if args.streams <= 1 else MultiStreamStep(net, inp, args.points, args.streams)
     grad_buf = torch.zeros((100204832,), dtype=torch.float32, device=device) if args.allreduce_grads else None
 
     def one_step():
@@ -220,6 +251,7 @@ def main():
                                "squash/map-decoder/xyz + heads fwd, + %d-pt nn_distance Chamfer fwd/bwd" %
                                (args.batch, args.points),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * n_gpus, "points": args.points,
+                   "streams_per_gpu": args.streams,
                    "sharding": "instances/%d, no data-path collective" % n_gpus +
                                (" + all-reduce(401 MB synthetic grad buffer)" if args.allreduce_grads else "")},
     }

@@ -55,6 +55,15 @@ class DeviceNet:
         self._weights = weights
         self._fc_cache = {}
 
+    def clone_with_own_scratch(self):
+        """Same device weights, separate workspaces: one clone per HIP stream when instance shards run
+        concurrently on several streams."""
+        import copy
+        other = copy.copy(self)
+        other.ws_trunk, other.ws_dec, other.ws_heads = Workspace(self.device), Workspace(self.device), \
+            Workspace(self.device)
+        return other
+
     # ------------------------------------------------------------------ single FC layers (output builder)
     def fully_connected(self, x, name, relu):
         """slim.fully_connected `name` on x (B, fin) through the HIP GEMM; the input is zero-padded to a multiple

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--classes", type=int, default=-1)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", action="append", default=[],
+                    help="extra shape H,W,C,N,k,dil,res (repeatable); replaces the built-in list")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
@@ -51,7 +53,13 @@ def main():
     B = args.batch
     print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("tile%2d TF/s (us)" % t for t in tiles)))
     total = {t: 0.0 for t in tiles}
-    for name, count, (H, W), C, N, k, dil, res in SHAPES:
+    shapes = SHAPES
+    if args.shape:
+        shapes = []
+        for sp in args.shape:
+            H, W, C, N, k, dil, res = [int(v) for v in sp.split(",")]
+            shapes.append(("custom %s" % sp, 1, (H, W), C, N, k, dil, bool(res)))
+    for name, count, (H, W), C, N, k, dil, res in shapes:
         if args.only and args.only not in name:
             continue
         x = torch.randn((B, H, W, C), device=dev)
