@@ -393,6 +393,9 @@ int g_class_override = -1;
 
 namespace mpsr {
 
+int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
+                   int N, hipStream_t s);  // image_ops.hip
+
 // Shared by the network-level entry points (network.hip).
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
@@ -410,6 +413,11 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // 32-bit buffer offsets: activations and weights must each stay below 4 GiB (B=256 at 48x48x256 is 0.6 GiB)
     MPSR_REQUIRE(M64 * C * 4 < 0xfffffff0LL && (long long)N * KH * KW * C * 4 < 0xfffffff0LL && M64 < 0x7fffffffLL,
                  "conv2d: tensor exceeds the 4 GiB addressable by one launch; split the batch");
+    // N <= 4 3x3 layers (the xyz-map head) are input-bandwidth-bound: direct VALU kernel instead of a 32-wide MFMA
+    // tile (an explicit tile override keeps them on the MFMA path so tests cover both)
+    if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
+        g_tile_override < 0 && ((uintptr_t)w & 3) == 0)
+        return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;

@@ -249,3 +249,90 @@ extern "C" int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols
     MPSR_CHECK_LAUNCH("im2col_root_kernel");
     return MPSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ narrow 3x3 conv
+//
+// 3x3 stride-1 SAME convolution with a tiny output width (N <= 4): the xyz-map head (128 -> 3,
+// monopsr_output_builder.py:95-104).  On the MFMA GEMM an N = 3 layer wastes 29/32 of every tile, and the layer is
+// bound by reading its (B,48,48,128) input once (302 MB at B = 256), so it is a direct VALU kernel instead:
+// a workgroup owns a 16x16 output tile, stages the 18x18 halo of 32 channels at a time in LDS (row stride 36 floats:
+// conflict-free 16-byte reads), one thread per output pixel, weights read through the scalar cache (wave-uniform).
+namespace {
+
+constexpr int kNarrowTile = 16, kNarrowHalo = kNarrowTile + 2, kNarrowCh = 32, kNarrowStride = kNarrowCh + 4;
+
+template <int NOUT>
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float *__restrict__ x, int H, int W, int C,
+                                                             const float *__restrict__ w,
+                                                             const float *__restrict__ bias, int relu,
+                                                             float *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kNarrowHalo * kNarrowHalo * kNarrowStride];
+    const int b = blockIdx.z, ty0 = blockIdx.y * kNarrowTile, tx0 = blockIdx.x * kNarrowTile;
+    const int tid = threadIdx.x, ly = tid >> 4, lx = tid & 15;
+    const float *xb = x + (size_t)b * H * W * C;
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+    const int K = 9 * C;
+    for (int c0 = 0; c0 < C; c0 += kNarrowCh) {
+        __syncthreads();
+        for (int i = tid; i < kNarrowHalo * kNarrowHalo * (kNarrowCh / 4); i += 256) {
+            const int pix = i >> 3, q = i & 7;
+            const int py = pix / kNarrowHalo, px = pix - py * kNarrowHalo;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + q * 4 < C)
+                v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * W + gx) * C + c0 + q * 4);
+            *reinterpret_cast<float4 *>(&tile[pix * kNarrowStride + q * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float *src = &tile[((ly + t / 3) * kNarrowHalo + lx + t % 3) * kNarrowStride];
+            const float *wt = w + t * C + c0;  // + o * K ; wave-uniform -> scalar loads
+#pragma unroll
+            for (int q = 0; q < kNarrowCh / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + q * 4);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float *wo = wt + (size_t)o * K + q * 4;
+                    acc[o] = fmaf(v.x, wo[0], acc[o]);
+                    acc[o] = fmaf(v.y, wo[1], acc[o]);
+                    acc[o] = fmaf(v.z, wo[2], acc[o]);
+                    acc[o] = fmaf(v.w, wo[3], acc[o]);
+                }
+            }
+        }
+    }
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    if (oy < H && ox < W) {
+        float *dst = y + (((size_t)b * H + oy) * W + ox) * NOUT;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float v = acc[o] + (bias ? bias[o] : 0.f);
+            dst[o] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace mpsr {
+// Used by conv2d() for 3x3, dilation 1, N <= 4, C % 32 == 0 layers without residual.
+int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
+                   int N, hipStream_t s)
+{
+    dim3 grid(ceil_div(W, kNarrowTile), ceil_div(H, kNarrowTile), B);
+    if (grid.z > 65535) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: batch %d exceeds 65535", B);
+    switch (N) {
+        case 1: hipLaunchKernelGGL(conv3x3_narrow_kernel<1>, grid, dim3(256), 0, s, x, H, W, C, w, bias, relu, y); break;
+        case 2: hipLaunchKernelGGL(conv3x3_narrow_kernel<2>, grid, dim3(256), 0, s, x, H, W, C, w, bias, relu, y); break;
+        case 3: hipLaunchKernelGGL(conv3x3_narrow_kernel<3>, grid, dim3(256), 0, s, x, H, W, C, w, bias, relu, y); break;
+        case 4: hipLaunchKernelGGL(conv3x3_narrow_kernel<4>, grid, dim3(256), 0, s, x, H, W, C, w, bias, relu, y); break;
+        default: return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: N=%d", N);
+    }
+    MPSR_CHECK_LAUNCH("conv3x3_narrow_kernel");
+    return MPSR_OK;
+}
+}  // namespace mpsr

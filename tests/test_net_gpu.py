@@ -89,6 +89,12 @@ CONV_CASES = [
     (5, 1, 1, 96, 27, 1, 1, True, False, False),      # FC with a narrow N
     (7, 3, 5, 8, 3, 3, 1, True, False, False),        # xyz-like: N = 3
     (1, 48, 48, 16, 3, 3, 1, True, False, False),
+    # N <= 4, C % 32 == 0, 3x3 d1: the direct narrow-conv kernel when no tile is forced (tile -1), MFMA otherwise
+    (2, 20, 20, 64, 3, 3, 1, True, False, False),
+    (1, 48, 48, 128, 3, 3, 1, True, False, False),
+    (2, 9, 11, 32, 4, 3, 1, False, False, False),
+    (1, 17, 16, 96, 1, 3, 1, True, False, False),
+    (3, 33, 18, 64, 2, 3, 1, True, False, False),
 ]
 
 
