@@ -273,3 +273,24 @@ def pack_heads(weights, feat_elems=18432, num_classes=1, num_alpha_bins=12):
     wz, bz = _fc(weights, "output/cen_z_offs/cen_z")
     blob.add_layer(np.concatenate([wy, wz], 0), np.concatenate([by, bz]), wy.shape[1], 1, 1, 1, False)
     return blob.finish()
+
+
+def variable_shapes(scopes=(CROP_SCOPE,), feat_elems=18432, width_div=1):
+    """name -> shape of every variable synthetic_weights() would create (no data generated)."""
+    shapes = {}
+    for scope in scopes:
+        for s in scaled_trunk_specs(scope, width_div):
+            shapes[s["name"] + "/weights"] = (s["kh"], s["kw"], s["cin"], s["cout"])
+            for k in ("gamma", "beta", "moving_mean", "moving_variance"):
+                shapes[s["name"] + "/BatchNorm/" + k] = (s["cout"],)
+    for name, kh, kw, cin, cout, has_bn, has_bias, _ in scaled_decoder_specs(width_div):
+        shapes[name + "/weights"] = (kh, kw, cin, cout)
+        if has_bn:
+            for k in ("beta", "moving_mean", "moving_variance"):
+                shapes[name + "/BatchNorm/" + k] = (cout,)
+        if has_bias:
+            shapes[name + "/biases"] = (cout,)
+    for name, fin, fout, _ in head_fc_specs(feat_elems):
+        shapes[name + "/weights"] = (fin, fout)
+        shapes[name + "/biases"] = (fout,)
+    return shapes
