@@ -115,6 +115,40 @@ int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float
  * 147..kpad-1 zero.  kpad % 32 == 0, kpad >= 147. */
 int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols, int kpad, mpsr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ backward */
+/* The reference gets gradients from TensorFlow autodiff (core/trainer.py:71-81, builders/optimizer_builder.py:61-80);
+ * these entry points are what a training step of the instance path needs beyond the forward kernels. */
+
+/* dW[n][(ky*KW+kx)*C + c] += sum over pixels of dy[pixel][n] * x[pixel + tap][c] (same geometry as
+ * mpsr_conv2d_nhwc_f32).  x (B,H,W,C), dy (B,H,W,N), dw (N, KH*KW*C) must be zeroed by the caller (partial sums
+ * from pixel slices are combined with fp32 atomics).  C % 4 == 0, N % 4 == 0. */
+int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
+                          int dilation, float *dw, mpsr_stream_t stream);
+
+/* Weight re-layout for the data gradient: wd[c][((KH*KW-1-t)*N) + n] = w[n][t*C + c].  Then
+ * dx = mpsr_conv2d_nhwc_f32(dy, ..., w = wd, N := C, C := N) with the same KH, KW, dilation. */
+int mpsr_conv2d_dgrad_pack(const float *w, int N, int KH, int KW, int C, float *wd, mpsr_stream_t stream);
+
+/* db[n] += sum_m dy[m][n]; db zeroed by the caller. */
+int mpsr_bias_grad(const float *dy, long long M, int N, float *db, mpsr_stream_t stream);
+
+/* dx = dy where y > 0 else 0 (y = post-activation output of the layer).  dx may alias dy. */
+int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, mpsr_stream_t stream);
+
+/* Gradient of mpsr_max_pool w.r.t. its input (first maximum of each window takes the gradient); dx (B,H,W,C) is
+ * fully overwritten. */
+int mpsr_max_pool_grad(const float *x, const float *dy, int B, int H, int W, int C, int k, int s, int pad_same,
+                       float *dx, mpsr_stream_t stream);
+
+/* Gradient of mpsr_resize_bilinear w.r.t. its input; dy (B,OH,OW,C) -> dx (B,H,W,C), fully overwritten. */
+int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int OH, int OW, int align_corners,
+                              float *dx, mpsr_stream_t stream);
+
+/* One Adam step over flat fp32 buffers (tf.train.AdamOptimizer update rule, optimizer_builder.py:61-80):
+ * g' = grad*grad_scale; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2; p -= lr*sqrt(1-b2^step)/(1-b1^step) * m/(sqrt(v)+eps). */
+int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ network */
 
 /* One packed convolution / FC layer inside a weight blob (offsets in floats from the blob base). */

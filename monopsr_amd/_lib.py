@@ -63,6 +63,14 @@ SIGNATURES = {
     "mpsr_conv2d_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                    c_sz, c_f]),
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
+    "mpsr_conv2d_wgrad_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_bias_grad": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
+    "mpsr_relu_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_f]),
+    "mpsr_max_pool_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_resize_bilinear_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                             ctypes.c_float, c_i, ctypes.c_float, c_f]),
     "mpsr_trunk_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
     "mpsr_decoder_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),

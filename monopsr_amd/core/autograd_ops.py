@@ -1,0 +1,134 @@
+"""Differentiable wrappers (torch.autograd.Function) over the HIP forward / backward kernels.
+
+Weights are NOT autograd leaves: a layer's weight and bias live in a flat parameter buffer and their gradients are
+accumulated by the wgrad / bias-grad kernels straight into the matching slice of a flat gradient buffer (the buffer
+the data-parallel all-reduce and the Adam kernel run over).  Autograd only routes activation gradients.
+The caller zeroes the flat gradient buffer once per step.
+"""
+import torch
+import torch.nn.functional as F
+
+from monopsr_amd import _lib
+from monopsr_amd.core import device_net as dn
+
+
+class LayerRef:
+    """One conv / FC layer: views into the flat parameter and gradient buffers (BatchNorm already folded)."""
+
+    def __init__(self, w, b, dw, db, cin, cout, kh, kw, dilation, relu):
+        self.w, self.b, self.dw, self.db = w, b, dw, db
+        self.cin, self.cout, self.kh, self.kw, self.dilation, self.relu = cin, cout, kh, kw, dilation, relu
+
+
+def _relu_grad(dy, y):
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.lib().mpsr_relu_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dx), dy.numel(), _lib.stream()))
+    return dx
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv(x, L.w) + L.b + residual); backward deposits dW, db into L.dw, L.db."""
+
+    @staticmethod
+    def forward(ctx, x, residual, layer, token):
+        # `token` is a dummy scalar that requires grad: it puts the layer into the autograd graph even when neither
+        # x nor residual needs a gradient (first layer), so that backward still deposits dW / db
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        y = dn.conv2d(x, layer.w, layer.b, res, layer.kh, layer.kw, layer.dilation, layer.relu)
+        ctx.layer = layer
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if layer.relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = ctx.layer
+        x, y = ctx.saved_tensors
+        g = dy.contiguous()
+        if L.relu:
+            g = _relu_grad(g, y)
+        lib = _lib.lib()
+        B, H, W, C = x.shape
+        N = L.cout
+        s = _lib.stream()
+        if L.db is not None:
+            _lib.check(lib.mpsr_bias_grad(_lib.ptr(g), B * H * W, N, _lib.ptr(L.db), s))
+        # the kernels read rows of N floats with 16-byte loads: pad a narrow output (the 3-channel xyz head) to 4
+        pad = (-N) % 4
+        g4 = F.pad(g, (0, pad)) if pad else g
+        N4 = N + pad
+        if pad:
+            dw4 = torch.zeros((N4, L.w.shape[1]), dtype=torch.float32, device=x.device)
+            w4 = F.pad(L.w, (0, 0, 0, pad))
+        else:
+            dw4, w4 = L.dw, L.w
+        _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
+                                             _lib.ptr(dw4), s))
+        if pad:
+            L.dw.add_(dw4[:N])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=x.device)
+            _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd), s))
+            dx = dn.conv2d(g4, wd, None, None, L.kh, L.kw, L.dilation, False)
+        return dx, (g if ctx.has_res else None), None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, padding):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, s, padding)
+        return dn.max_pool(x, k, s, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        k, s, padding = ctx.cfg
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().mpsr_max_pool_grad(_lib.ptr(x), _lib.ptr(dy.contiguous()), B, H, W, C, k, s,
+                                                 int(padding == "SAME"), _lib.ptr(dx), _lib.stream()))
+        return dx, None, None, None
+
+
+class ResizeBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, align_corners):
+        ctx.in_shape = tuple(x.shape)
+        ctx.cfg = (tuple(size), align_corners)
+        return dn.resize_bilinear(x, tuple(size), align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.in_shape
+        (oh, ow), ac = ctx.cfg
+        if (H, W) == (oh, ow):
+            return dy, None, None
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.lib().mpsr_resize_bilinear_grad(_lib.ptr(dy.contiguous()), B, H, W, C, oh, ow, int(ac),
+                                                        _lib.ptr(dx), _lib.stream()))
+        return dx, None, None
+
+
+_TOKEN = {}
+
+
+def _token(device):
+    if device not in _TOKEN:
+        _TOKEN[device] = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+    return _TOKEN[device]
+
+
+def conv2d(x, layer, residual=None):
+    return Conv2dFn.apply(x, residual, layer, _token(x.device))
+
+
+def max_pool(x, k, s, padding):
+    return MaxPoolFn.apply(x, k, s, padding)
+
+
+def resize_bilinear(x, size, align_corners):
+    return ResizeBilinearFn.apply(x, size, align_corners)

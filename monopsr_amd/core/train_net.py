@@ -1,0 +1,122 @@
+"""Trainable form of the instance path: the same layers as DeviceNet, sequenced in Python over
+the differentiable kernel wrappers of autograd_ops, with every parameter in ONE flat fp32 buffer and every
+gradient in ONE flat buffer of the same layout -- the buffer the data-parallel all-reduce
+(core/data_parallel.BucketedAllReduce) and the fused Adam kernel (mpsr_adam_step) run over.
+
+Parameterisation: inference-mode BatchNorm is folded into the convolutions (core/weights.fold_conv), so the
+trainable tensors are the folded weight and bias of each layer.  The trunks' BatchNorm is frozen in the reference
+too (faster_rcnn_resnet_v1_feature_extractor.py:63,238); training the folded weight instead of (w, gamma, beta)
+separately is a re-parameterisation of the same function, stated here because it is not the reference's variable set.
+"""
+import numpy as np
+import torch
+
+from monopsr_amd import _lib
+from monopsr_amd.core import autograd_ops as ops
+from monopsr_amd.core import weights as W
+
+
+def _im2col_root(img, kpad):
+    img = img.contiguous()
+    B, H, Wd, _ = img.shape
+    oh, ow = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
+    cols = torch.empty((B * oh * ow, 1, 1, kpad), dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().mpsr_im2col_root(_lib.ptr(img), B, H, Wd, _lib.ptr(cols), kpad, _lib.stream()))
+    return cols, oh, ow
+
+
+class TrainNet:
+    def __init__(self, weights, device="cuda", width_div=1, with_heads=True):
+        self.device = torch.device(device)
+        parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
+        fc_names = [n for n, _, _, _ in W.head_fc_specs()] if with_heads else []
+        blobs, recs, base = [], [], 0
+        for blob, records in parts:
+            for r in records:
+                recs.append(dict(r, w_off=r["w_off"] + base, b_off=(r["b_off"] + base) if r["b_off"] >= 0 else -1))
+            blobs.append(blob)
+            base += blob.size
+        self.fc_index = {}
+        for name in fc_names:
+            w = weights[name + "/weights"]  # (in, out)
+            kpad = (w.shape[0] + 3) // 4 * 4
+            w_ok = np.zeros((w.shape[1], kpad), np.float32)
+            w_ok[:, :w.shape[0]] = w.T
+            b = weights[name + "/biases"].astype(np.float32)
+            self.fc_index[name] = (len(recs), w.shape[0])
+            recs.append(dict(cin=kpad, cout=w.shape[1], kh=1, kw=1, dilation=1, relu=0, w_off=base,
+                             b_off=base + w_ok.size))
+            blobs += [w_ok.ravel(), b]
+            base += w_ok.size + b.size
+        flat = np.concatenate(blobs)
+        self.params = torch.from_numpy(flat).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.step_count = 0
+        self.layers = []
+        for r in recs:
+            n = r["cout"] * r["kh"] * r["kw"] * r["cin"]
+            wv = self.params[r["w_off"]:r["w_off"] + n].view(r["cout"], -1)
+            dwv = self.grads[r["w_off"]:r["w_off"] + n].view(r["cout"], -1)
+            bv = self.params[r["b_off"]:r["b_off"] + r["cout"]] if r["b_off"] >= 0 else None
+            dbv = self.grads[r["b_off"]:r["b_off"] + r["cout"]] if r["b_off"] >= 0 else None
+            self.layers.append(ops.LayerRef(wv, bv, dwv, dbv, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"],
+                                            bool(r["relu"])))
+        self.n_trunk = len(parts[0][1])
+        self.n_dec = len(parts[1][1])
+
+    # ------------------------------------------------------------------ forward pieces
+    def trunk(self, img):
+        L = self.layers
+        B = img.shape[0]
+        cols, oh, ow = _im2col_root(img, L[0].cin)
+        x = ops.conv2d(cols, L[0]).reshape(B, oh, ow, L[0].cout)
+        x = ops.max_pool(x, 3, 2, "SAME")
+        li = 1
+        for blk, units in enumerate((3, 4, 23)):
+            for u in range(units):
+                residual = x
+                if u == 0:
+                    residual = ops.conv2d(x, L[li])
+                    li += 1
+                t = ops.conv2d(x, L[li])
+                t = ops.conv2d(t, L[li + 1])
+                x = ops.conv2d(t, L[li + 2], residual=residual)
+                li += 3
+        return x
+
+    def squash_decoder(self, crop_feat, full_feat, map_size=(48, 48)):
+        L = self.layers[self.n_trunk:self.n_trunk + self.n_dec]
+        part = ops.conv2d(crop_feat, L[0])
+        sq = ops.conv2d(full_feat, L[1], residual=part)
+        feat_box = ops.max_pool(sq, 2, 2, "VALID")
+        y = ops.resize_bilinear(sq, (map_size[0] // 2, map_size[1] // 2), True)
+        y = ops.conv2d(ops.conv2d(y, L[2]), L[3])
+        y = ops.resize_bilinear(y, tuple(map_size), True)
+        feat_map = ops.conv2d(ops.conv2d(y, L[4]), L[5])
+        xyz = ops.conv2d(feat_map, L[6])
+        return feat_box, feat_map, xyz
+
+    def fully_connected(self, x, name, relu):
+        """Differentiable slim.fully_connected `name` (used by MonoPSROutputBuilder in training mode)."""
+        idx, fin = self.fc_index[name]
+        L = self.layers[idx]
+        L.relu = bool(relu)
+        if x.shape[1] != fin:
+            raise _lib.InvalidArgumentError("%s expects %d input features, got %d" % (name, fin, x.shape[1]))
+        if L.cin != fin:
+            x = torch.nn.functional.pad(x, (0, L.cin - fin))
+        B = x.shape[0]
+        return ops.conv2d(x.reshape(B, 1, 1, L.cin), L).reshape(B, -1)
+
+    # ------------------------------------------------------------------ optimisation
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def adam_step(self, lr=8e-5, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """tf.train.AdamOptimizer update (optimizer_builder.py:61-80; lr 8e-5 from monopsr_model_000.yaml:141-147)."""
+        self.step_count += 1
+        _lib.check(_lib.lib().mpsr_adam_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                             _lib.ptr(self.adam_v), self.params.numel(), lr, beta1, beta2, eps,
+                                             self.step_count, grad_scale, _lib.stream()))

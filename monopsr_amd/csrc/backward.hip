@@ -1,0 +1,376 @@
+// Backward-pass kernels of the instance path: weight gradient as an fp32-MFMA GEMM reduced
+// over pixels, weight re-layout for the data gradient (which then reuses the forward implicit-GEMM kernel),
+// bias gradient, ReLU / max-pool / bilinear-resize gradients and a fused Adam step over flat parameter buffers.
+// The reference gets all of these from TensorFlow's autodiff (trainer.py:71-81, optimizer_builder.py:61-80); there
+// is no reference source to cite beyond the forward call sites.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+//
+//   dW[n][tap*C + c] += sum_m dY[m][n] * X[pixel(m) + tap][c]
+//
+// GEMM with the output (N x C per tap) small and the reduction (pixels) long: a workgroup owns a 128 (n) x 128 (c)
+// tile of one tap and a contiguous slice of pixels; slices are combined with hardware fp32 atomics into the
+// pre-zeroed gradient.  Both operands are read row-wise (a pixel's N / C values are contiguous), staged in LDS as
+// [pixel][n] / [pixel][c] and fed to v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand (lane i reads column
+// i of pixel row k: consecutive lanes, consecutive banks).
+constexpr int WG_T = 128;  // tile edge (n and c)
+constexpr int WG_K = 32;   // pixels per step
+
+struct WgradParams {
+    const float *x;
+    const float *dy;
+    float *dw;
+    int M, H, W, C, N, KH, KW, dil;
+    int ntile_n, ntile_c, msteps_total, msteps_per_split, splits;
+    unsigned xbytes, dybytes;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) float At[WG_K * WG_T];  // [pixel][n]
+    __shared__ __attribute__((aligned(16))) float Bt[WG_K * WG_T];  // [pixel][c]
+    int t = blockIdx.x;
+    const int tn = t % p.ntile_n; t /= p.ntile_n;
+    const int tc = t % p.ntile_c; t /= p.ntile_c;
+    const int tap = t % (p.KH * p.KW);
+    const int si = t / (p.KH * p.KW);
+    const int n0 = tn * WG_T, c0 = tc * WG_T;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int dyo = (ky - (p.KH >> 1)) * p.dil, dxo = (kx - (p.KW >> 1)) * p.dil;
+    const int ms_begin = si * p.msteps_per_split;
+    const int ms_end = min(p.msteps_total, ms_begin + p.msteps_per_split);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 5, lcol = (tid & 31) * 4;  // 8 pixel rows per pass, 32 float4 per row
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, (int)p.dybytes, 0x00020000);
+    const bool nok = n0 + lcol < p.N, cok = c0 + lcol < p.C;
+    const int HW = p.H * p.W;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int ms) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = ms * WG_K + lrow + 8 * j;
+            const bool mok = m < p.M;
+            const unsigned offa = (mok && nok) ? ((unsigned)m * (unsigned)p.N + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa, 0, 0));
+            const int pix = mok ? m % HW : 0;
+            const int yy = pix / p.W + dyo, xx = pix % p.W + dxo;
+            const bool ok = mok && cok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const unsigned offb =
+                ok ? ((unsigned)(m + dyo * p.W + dxo) * (unsigned)p.C + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
+            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb, 0, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4 *>(&At[(lrow + 8 * j) * WG_T + lcol]) = ra[j];
+            *reinterpret_cast<float4 *>(&Bt[(lrow + 8 * j) * WG_T + lcol]) = rb[j];
+        }
+    };
+    const float *Aw = At + (lane >> 5) * 4 * WG_T + wm * 64 + (lane & 31);
+    const float *Bw = Bt + (lane >> 5) * 4 * WG_T + wn * 64 + (lane & 31);
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < WG_K / 8; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = (kb * 8 + s) * WG_T;
+                const float a0 = Aw[row], a1 = Aw[row + 32], b0 = Bw[row], b1 = Bw[row + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+    };
+
+    if (ms_begin >= ms_end) return;
+    load_tile(ms_begin);
+    store_tile();
+    __syncthreads();
+    for (int ms = ms_begin; ms < ms_end - 1; ++ms) {
+        load_tile(ms + 1);
+        compute_tile();
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+    compute_tile();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
+
+    const int Ktot = p.KH * p.KW * p.C;
+    const int col = lane & 31, rsub = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = c0 + wn * 64 + j * 32 + col;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + i * 32 + rsub + (e & 3) + 8 * (e >> 2);
+                if (n < p.N) unsafeAtomicAdd(&p.dw[(size_t)n * Ktot + (size_t)tap * p.C + c], acc[i][j][e]);
+            }
+    }
+}
+
+// wd[c][(T-1-t)*N + n] = w[n][t*C + c]: the data gradient of a stride-1 SAME convolution is the same convolution of
+// dY with the taps flipped and the channel roles swapped.
+__global__ __launch_bounds__(256) void dgrad_pack_kernel(const float *__restrict__ w, int N, int T, int C,
+                                                         float *__restrict__ wd, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        long long r = i / N;
+        const int tf = (int)(r % T);
+        const int c = (int)(r / T);
+        wd[i] = w[((size_t)n * T + (T - 1 - tf)) * C + c];
+    }
+}
+
+// db[n] += sum_m dy[m][n]; grid (ceil(N/256), row splits)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, long long M, int N,
+                                                        long long rows_per_block, float *__restrict__ db)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long m0 = (long long)blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    for (long long m = m0; m < m1; ++m) s += dy[m * N + n];
+    unsafeAtomicAdd(&db[n], s);
+}
+
+// dx = dy where y > 0 else 0 (y = the layer's post-activation output)
+__global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                        float *__restrict__ dx, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// max-pool gradient: each output cell routes its gradient to the first maximum of its window (row-major scan)
+__global__ __launch_bounds__(256) void max_pool_grad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                            int H, int W, int C, int OH, int OW, int k, int s,
+                                                            int pad_top, int pad_left, float *__restrict__ dx,
+                                                            long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const float *xb = x + (size_t)b * H * W * C;
+        float best = -__builtin_inff();
+        int by = -1, bx = -1;
+        for (int ky = 0; ky < k; ++ky) {
+            const int y = oy * s - pad_top + ky;
+            if (y < 0 || y >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = ox * s - pad_left + kx;
+                if (xx < 0 || xx >= W) continue;
+                const float v = xb[((size_t)y * W + xx) * C + c];
+                if (v > best) {
+                    best = v;
+                    by = y;
+                    bx = xx;
+                }
+            }
+        }
+        if (by >= 0) unsafeAtomicAdd(&dx[(((size_t)b * H + by) * W + bx) * C + c], dy[i]);
+    }
+}
+
+// bilinear-resize gradient (TF-1.8 kernel geometry): scatter each output gradient to its 4 source pixels
+__global__ __launch_bounds__(256) void resize_bilinear_grad_kernel(const float *__restrict__ dy, int H, int W, int C,
+                                                                   int OH, int OW, float hscale, float wscale,
+                                                                   float *__restrict__ dx, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const float sy = (float)oy * hscale, sx = (float)ox * wscale;
+        const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float yl = sy - (float)y0, xl = sx - (float)x0;
+        const float g = dy[i];
+        float *base = dx + (size_t)b * H * W * C + c;
+        unsafeAtomicAdd(base + ((size_t)y0 * W + x0) * C, g * (1.f - yl) * (1.f - xl));
+        unsafeAtomicAdd(base + ((size_t)y0 * W + x1) * C, g * (1.f - yl) * xl);
+        unsafeAtomicAdd(base + ((size_t)y1 * W + x0) * C, g * yl * (1.f - xl));
+        unsafeAtomicAdd(base + ((size_t)y1 * W + x1) * C, g * yl * xl);
+    }
+}
+
+// Adam (tf.train.AdamOptimizer form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)) over flat buffers
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, long long n,
+                                                   float lr_t, float b1, float b2, float eps, float grad_scale)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
+
+}  // namespace
+
+extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
+                                     int dilation, float *dw, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && (KH & 1) && (KW & 1) && dilation >= 1,
+                 "conv2d_wgrad: bad shape");
+    MPSR_REQUIRE(C % 4 == 0 && N % 4 == 0, "conv2d_wgrad: C=%d and N=%d must be multiples of 4", C, N);
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    const long long M = (long long)B * H * W;
+    MPSR_REQUIRE(M * C * 4 < 0xfffffff0LL && M * N * 4 < 0xfffffff0LL, "conv2d_wgrad: tensor exceeds 4 GiB");
+    WgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw;
+    p.M = (int)M; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation;
+    p.xbytes = (unsigned)(M * C * 4);
+    p.dybytes = (unsigned)(M * N * 4);
+    p.ntile_n = mpsr::ceil_div(N, WG_T);
+    p.ntile_c = mpsr::ceil_div(C, WG_T);
+    p.msteps_total = mpsr::ceil_div(p.M, WG_K);
+    const int tiles = p.ntile_n * p.ntile_c * KH * KW;
+    int splits = 1536 / (tiles > 0 ? tiles : 1);  // aim at ~6 workgroups per CU
+    if (splits < 1) splits = 1;
+    if (splits > p.msteps_total) splits = p.msteps_total;
+    p.msteps_per_split = mpsr::ceil_div(p.msteps_total, splits);
+    p.splits = mpsr::ceil_div(p.msteps_total, p.msteps_per_split);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(tiles * p.splits)), dim3(256), 0, mpsr::as_stream(stream), p);
+    MPSR_CHECK_LAUNCH("conv_wgrad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_conv2d_dgrad_pack(const float *w, int N, int KH, int KW, int C, float *wd, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(N > 0 && KH > 0 && KW > 0 && C > 0 && w && wd, "conv2d_dgrad_pack: bad argument");
+    const long long total = (long long)N * KH * KW * C;
+    hipLaunchKernelGGL(dgrad_pack_kernel, dim3(grid_for(total)), dim3(256), 0, mpsr::as_stream(stream), w, N, KH * KW, C,
+                       wd, total);
+    MPSR_CHECK_LAUNCH("dgrad_pack_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_bias_grad(const float *dy, long long M, int N, float *db, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(M >= 0 && N > 0, "bias_grad: bad shape");
+    if (M == 0) return MPSR_OK;
+    MPSR_REQUIRE(dy && db, "bias_grad: null pointer");
+    long long splits = (M + 511) / 512;
+    if (splits > 2048) splits = 2048;
+    const long long rows = (M + splits - 1) / splits;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(mpsr::ceil_div(N, 256), (unsigned)((M + rows - 1) / rows)), dim3(256), 0,
+                       mpsr::as_stream(stream), dy, M, N, rows, db);
+    MPSR_CHECK_LAUNCH("bias_grad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(total >= 0, "relu_grad: bad size");
+    if (total == 0) return MPSR_OK;
+    MPSR_REQUIRE(dy && y && dx, "relu_grad: null pointer");
+    hipLaunchKernelGGL(relu_grad_kernel, dim3(grid_for(total)), dim3(256), 0, mpsr::as_stream(stream), dy, y, dx, total);
+    MPSR_CHECK_LAUNCH("relu_grad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_max_pool_grad(const float *x, const float *dy, int B, int H, int W, int C, int k, int s_,
+                                  int pad_same, float *dx, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && k > 0 && s_ > 0, "max_pool_grad: bad shape");
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && dy && dx, "max_pool_grad: null pointer");
+    int OH, OW, pt = 0, pl = 0;
+    if (pad_same) {
+        OH = mpsr::ceil_div(H, s_);
+        OW = mpsr::ceil_div(W, s_);
+        const int th = (OH - 1) * s_ + k - H, tw = (OW - 1) * s_ + k - W;
+        pt = (th > 0 ? th : 0) / 2;
+        pl = (tw > 0 ? tw : 0) / 2;
+    } else {
+        OH = (H - k) / s_ + 1;
+        OW = (W - k) / s_ + 1;
+    }
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * H * W * C, s));
+    const long long total = (long long)B * OH * OW * C;
+    hipLaunchKernelGGL(max_pool_grad_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, dy, H, W, C, OH, OW, k, s_, pt,
+                       pl, dx, total);
+    MPSR_CHECK_LAUNCH("max_pool_grad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int OH, int OW, int align_corners,
+                                         float *dx, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "resize_bilinear_grad: bad shape");
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(dy && dx, "resize_bilinear_grad: null pointer");
+    const float hscale = (align_corners && OH > 1) ? (float)(H - 1) / (float)(OH - 1) : (float)H / (float)OH;
+    const float wscale = (align_corners && OW > 1) ? (float)(W - 1) / (float)(OW - 1) : (float)W / (float)OW;
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * H * W * C, s));
+    const long long total = (long long)B * OH * OW * C;
+    hipLaunchKernelGGL(resize_bilinear_grad_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, H, W, C, OH, OW, hscale,
+                       wscale, dx, total);
+    MPSR_CHECK_LAUNCH("resize_bilinear_grad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
+                              float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(n >= 0 && step >= 1, "adam_step: bad argument");
+    if (n == 0) return MPSR_OK;
+    MPSR_REQUIRE(param && grad && m && v, "adam_step: null pointer");
+    const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
+    const float lr_t = (float)(lr * sqrt(c2) / c1);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, mpsr::as_stream(stream), param, grad, m, v, n, lr_t,
+                       beta1, beta2, eps, grad_scale);
+    MPSR_CHECK_LAUNCH("adam_kernel");
+    return MPSR_OK;
+}

@@ -1,0 +1,240 @@
+"""Backward kernels of the instance path (wgrad GEMM, dgrad via the forward kernel, bias / ReLU / max-pool / resize
+gradients, Adam) against PyTorch-CPU float64 autograd of the same (BatchNorm-folded) formulation.
+
+Tolerance 1e-4 of the gradient tensor's scale (fp32 accumulation over up to 10^5 pixels; atomics reorder sums)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import net as onet
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _close(got, ref, tol, name):
+    got = got.detach().cpu().double().numpy()
+    ref = ref.detach().cpu().double().numpy()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(got - ref).max() / scale
+    assert err <= tol, "%s: max err / scale = %.3e" % (name, err)
+
+
+def _ref_conv(x, w_ok, b, res, kh, kw, dil, relu):
+    """folded layer in float64 on the CPU: w_ok (N, kh*kw*C)"""
+    N = w_ok.shape[0]
+    C = x.shape[-1]
+    w = w_ok.reshape(N, kh, kw, C).permute(0, 3, 1, 2)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, None, 1, ((kh - 1) * dil // 2, (kw - 1) * dil // 2), dil)
+    y = y.permute(0, 2, 3, 1)
+    if b is not None:
+        y = y + b
+    if res is not None:
+        y = y + res
+    return torch.relu(y) if relu else y
+
+
+CASES = [
+    # B, H, W, C, N, k, dil, bias, residual, relu
+    (2, 12, 12, 64, 32, 1, 1, True, False, True),
+    (3, 12, 12, 32, 128, 1, 1, True, True, True),
+    (2, 12, 12, 32, 32, 3, 1, True, False, True),
+    (2, 12, 12, 64, 64, 3, 4, True, False, True),
+    (2, 12, 12, 32, 48, 3, 2, False, False, False),
+    (1, 24, 24, 16, 3, 3, 1, True, False, False),   # xyz-like N = 3
+    (5, 9, 7, 36, 20, 3, 1, True, True, True),      # ragged
+    (37, 1, 1, 260, 100, 1, 1, True, False, True),  # FC
+    (2, 20, 20, 160, 136, 3, 1, True, False, True),  # more than one 128-wide tile in n and c
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_layer_gradients(case):
+    from monopsr_amd.core import autograd_ops as ops
+    B, H, Wd, C, N, k, dil, has_b, has_res, relu = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((N, k * k * C)) / np.sqrt(k * k * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if has_b else None
+    res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+    up = rng.standard_normal((B, H, Wd, N)).astype(np.float32)
+    # reference
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    wr = torch.from_numpy(w).double().requires_grad_(True)
+    br = torch.from_numpy(b).double().requires_grad_(True) if has_b else None
+    rr = torch.from_numpy(res).double().requires_grad_(True) if has_res else None
+    yr = _ref_conv(xr, wr, br, rr, k, k, dil, relu)
+    (yr * torch.from_numpy(up).double()).sum().backward()
+    # HIP
+    wt, dwt = _dev(w), torch.zeros((N, k * k * C), device="cuda")
+    bt, dbt = (_dev(b), torch.zeros((N,), device="cuda")) if has_b else (None, None)
+    layer = ops.LayerRef(wt, bt, dwt, dbt, C, N, k, k, dil, relu)
+    xt = _dev(x).requires_grad_(True)
+    rt = _dev(res).requires_grad_(True) if has_res else None
+    y = ops.conv2d(xt, layer, rt)
+    _close(y, yr, 2e-6, "forward")
+    (y * _dev(up)).sum().backward()
+    _close(xt.grad, xr.grad, 1e-5, "dx")
+    _close(dwt, wr.grad, 1e-4, "dw")
+    if has_b:
+        _close(dbt, br.grad, 1e-4, "db")
+    if has_res:
+        _close(rt.grad, rr.grad, 1e-6, "dresidual")
+
+
+@pytest.mark.parametrize("shape,k,s,pad", [((2, 24, 24, 16), 3, 2, "SAME"), ((2, 12, 12, 8), 2, 2, "VALID"),
+                                           ((1, 7, 9, 4), 3, 2, "SAME")])
+def test_max_pool_gradient(shape, k, s, pad):
+    from monopsr_amd.core import autograd_ops as ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    yr = onet.tf_max_pool(xr, k, s, pad)
+    up = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    (yr * torch.from_numpy(up).double()).sum().backward()
+    xt = _dev(x).requires_grad_(True)
+    y = ops.max_pool(xt, k, s, pad)
+    (y * _dev(up)).sum().backward()
+    _close(xt.grad, xr.grad, 1e-6, "max_pool dx")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 12, 12, 16), (24, 24)), ((1, 24, 24, 8), (48, 48)), ((2, 5, 7, 4), (9, 4))])
+def test_resize_bilinear_gradient(shape, out):
+    from monopsr_amd.core import autograd_ops as ops
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    yr = onet.tf_resize_bilinear(xr, out[0], out[1], True)
+    up = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    (yr * torch.from_numpy(up).double()).sum().backward()
+    xt = _dev(x).requires_grad_(True)
+    y = ops.resize_bilinear(xt, out, True)
+    (y * _dev(up)).sum().backward()
+    _close(xt.grad, xr.grad, 1e-5, "resize dx")
+
+
+def test_adam_step_matches_tf_formula():
+    from monopsr_amd import _lib
+    rng = np.random.default_rng(7)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pt, mt, vt = _dev(p), _dev(m), _dev(v)
+    lr, b1, b2, eps = 8e-5, 0.9, 0.999, 1e-8
+    pr, mr, vr = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        _lib.check(_lib.lib().mpsr_adam_step(pt.data_ptr(), _dev(g).data_ptr(), mt.data_ptr(), vt.data_ptr(), n, lr,
+                                             b1, b2, eps, step, 1.0, _lib.stream()))
+        mr = b1 * mr + (1 - b1) * g
+        vr = b2 * vr + (1 - b2) * g.astype(np.float64) ** 2
+        pr = pr - lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step) * mr / (np.sqrt(vr) + eps)
+    np.testing.assert_allclose(pt.cpu().numpy(), pr, rtol=1e-5, atol=1e-7)
+
+
+def _ref_network(params, layers, crops, full_feat, n_trunk):
+    """float64 CPU forward of trunk + decoder + xyz in the folded parameterisation, from the flat parameter vector."""
+    P = params.double()
+
+    def layer(i):
+        L = layers[i]
+        n = L.cout * L.kh * L.kw * L.cin
+        w = P[L._w_off:L._w_off + n].view(L.cout, -1)
+        b = P[L._b_off:L._b_off + L.cout] if L._b_off >= 0 else None
+        return L, w, b
+
+    def conv(x, i, res=None):
+        L, w, b = layer(i)
+        return _ref_conv(x, w, b, res, L.kh, L.kw, L.dilation, L.relu)
+
+    B = crops.shape[0]
+    xp = F.pad(crops.permute(0, 3, 1, 2), (3, 3, 3, 3))
+    cols = F.unfold(xp, 7, stride=2)  # (B, 3*49, L) ordered (c, ky, kx)
+    Lroot, w0, b0 = layer(0)
+    oh = (crops.shape[1] + 6 - 7) // 2 + 1
+    cols = cols.view(B, 3, 49, -1).permute(0, 3, 2, 1).reshape(B, -1, 147)  # -> (ky*7+kx)*3 + c
+    x = torch.relu(cols @ w0[:, :147].t() + b0).view(B, oh, oh, -1)
+    x = onet.tf_max_pool(x, 3, 2, "SAME")
+    li = 1
+    for units in (3, 4, 23):
+        for u in range(units):
+            res = x
+            if u == 0:
+                res = conv(x, li)
+                li += 1
+            t = conv(conv(x, li), li + 1)
+            x = conv(t, li + 2, res)
+            li += 3
+    d = n_trunk
+    sq = conv(full_feat, d + 1, conv(x, d))
+    y = onet.tf_resize_bilinear(sq, 24, 24, True)
+    y = conv(conv(y, d + 2), d + 3)
+    y = onet.tf_resize_bilinear(y, 48, 48, True)
+    fm = conv(conv(y, d + 4), d + 5)
+    return conv(fm, d + 6), onet.tf_max_pool(sq, 2, 2, "VALID")
+
+
+def test_network_training_gradients_end_to_end():
+    """Narrow (1/4-width) trunk + decoder + xyz head: loss = Chamfer(pred cloud, GT) + small L2 on the box
+    features; every parameter gradient of the flat buffer vs float64 CPU autograd; then one Adam step."""
+    from monopsr_amd.core import train_net
+    from monopsr_amd.core import weights as W
+    from monopsr_amd.tf_ops.nn_distance import tf_nndistance
+    B, div = 2, 4
+    weights = W.synthetic_weights(seed=51, width_div=div, heads=False)
+    net = train_net.TrainNet(weights, width_div=div, with_heads=False)
+    rng = np.random.default_rng(52)
+    crops = (rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)
+    full = np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0).astype(np.float32)
+    gt = rng.standard_normal((B, 300, 3)).astype(np.float32) * 30
+    # HIP
+    net.zero_grad()
+    feat = net.trunk(_dev(crops))
+    fb, fm, xyz = net.squash_decoder(feat, _dev(full))
+    pred = xyz.reshape(B, -1, 3)[:, :256]
+    d1, _, d2, _ = tf_nndistance.nn_distance(pred.contiguous(), _dev(gt))
+    loss = (d1.sum() + d2.sum()) / B + 1e-3 * (fb * fb).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    # reference
+    for L, r in zip(net.layers, W.pack_trunk(weights, W.CROP_SCOPE, div)[1] + W.pack_decoder(weights, div)[1]):
+        pass
+    base = 0
+    recs = []
+    for blob, records in (W.pack_trunk(weights, W.CROP_SCOPE, div), W.pack_decoder(weights, div)):
+        for r in records:
+            recs.append((r["w_off"] + base, (r["b_off"] + base) if r["b_off"] >= 0 else -1))
+        base += blob.size
+    for L, (wo, bo) in zip(net.layers, recs):
+        L._w_off, L._b_off = wo, bo
+    P = net.params.detach().cpu().double().requires_grad_(True)
+    xyz_r, fb_r = _ref_network(P, net.layers, torch.from_numpy(crops).double(), torch.from_numpy(full).double(),
+                               net.n_trunk)
+    _close(xyz, xyz_r, 1e-4, "xyz forward")
+    pr = xyz_r.reshape(B, -1, 3)[:, :256]
+    dist = ((pr[:, :, None, :] - torch.from_numpy(gt).double()[:, None, :, :]) ** 2).sum(-1)
+    loss_r = (dist.min(2).values.sum() + dist.min(1).values.sum()) / B + 1e-3 * (fb_r * fb_r).sum()
+    loss_r.backward()
+    np.testing.assert_allclose(float(loss), float(loss_r), rtol=1e-4)
+    g, gr = net.grads.cpu().double(), P.grad
+    # per-layer comparison (layers differ in gradient scale by orders of magnitude)
+    worst = 0.0
+    for L in net.layers:
+        n = L.cout * L.kh * L.kw * L.cin
+        a, b_ = g[L._w_off:L._w_off + n], gr[L._w_off:L._w_off + n]
+        if L.kh == 1 and L.cin == 160:  # root: compare the 147 real columns (padding columns get no gradient)
+            a, b_ = a.view(L.cout, 160)[:, :147], b_.view(L.cout, 160)[:, :147]
+        worst = max(worst, float((a - b_).abs().max() / (b_.abs().max() + 1e-30)))
+        if L._b_off >= 0:
+            a, b_ = g[L._b_off:L._b_off + L.cout], gr[L._b_off:L._b_off + L.cout]
+            worst = max(worst, float((a - b_).abs().max() / (b_.abs().max() + 1e-30)))
+    assert worst < 2e-3, "worst per-layer gradient error %.3e" % worst
+    before = net.params.clone()
+    net.adam_step(lr=1e-3)
+    assert float((net.params - before).abs().max()) > 0
