@@ -67,6 +67,9 @@ class Conv2dFn(torch.autograd.Function):
                                              _lib.ptr(dw4), s))
         if pad:
             L.dw.add_(dw4[:N])
+        ready = getattr(L, "on_grad_ready", None)
+        if ready is not None:
+            ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete
         dx = None
         if ctx.needs_input_grad[0]:
             wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=x.device)

@@ -44,10 +44,12 @@ class TrainNet:
             w_ok[:, :w.shape[0]] = w.T
             b = weights[name + "/biases"].astype(np.float32)
             self.fc_index[name] = (len(recs), w.shape[0])
+            wsz = (w_ok.size + 63) // 64 * 64  # keep every tensor 256-byte aligned (16-byte loads in the kernels)
+            bsz = (b.size + 63) // 64 * 64
             recs.append(dict(cin=kpad, cout=w.shape[1], kh=1, kw=1, dilation=1, relu=0, w_off=base,
-                             b_off=base + w_ok.size))
-            blobs += [w_ok.ravel(), b]
-            base += w_ok.size + b.size
+                             b_off=base + wsz))
+            blobs += [w_ok.ravel(), np.zeros(wsz - w_ok.size, np.float32), b, np.zeros(bsz - b.size, np.float32)]
+            base += wsz + bsz
         flat = np.concatenate(blobs)
         self.params = torch.from_numpy(flat).to(self.device)
         self.grads = torch.zeros_like(self.params)

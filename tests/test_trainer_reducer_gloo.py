@@ -1,0 +1,73 @@
+"""ReverseBucketReducer (core/trainer.py): bucket launch order and all-reduce result, world_size 2 over gloo."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from monopsr_amd.core.trainer import ReverseBucketReducer
+        flat = torch.zeros(1000)
+        spans = [(0, 300), (300, 450), (450, 700), (700, 1000)]  # four "layers"
+        red = ReverseBucketReducer(flat, spans, bucket_bytes=250 * 4)
+        assert len(red.buckets) == 4
+        order = []
+        orig = red._launch
+        red._launch = lambda bi: (order.append(bi), orig(bi))[1]
+        # backward visits layers last -> first; each writes its slice then reports
+        for li in (3, 2, 1, 0):
+            lo, hi = spans[li]
+            flat[lo:hi] = float(rank + 1) * (li + 1)
+            red.layer_ready(li)
+        red.finish(average=True)
+        want = torch.zeros(1000)
+        for li, (lo, hi) in enumerate(spans):
+            want[lo:hi] = (li + 1) * sum(range(1, world + 1)) / world
+        # bucket 3 = [750,1000) needs only layer 3; bucket 2 = [500,750) layers 2+3; buckets 1 and 0 both wait for
+        # layer 0 (span [0,300)) and go out together when it reports
+        ok = torch.allclose(flat, want) and order[:2] == [3, 2] and sorted(order[2:]) == [0, 1]
+        # second step reuses the reducer
+        flat.fill_(float(rank))
+        for li in (3, 2, 1, 0):
+            red.layer_ready(li)
+        red.finish(average=False)
+        ok = ok and torch.allclose(flat, torch.full((1000,), float(sum(range(world)))))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reverse_bucket_reducer_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert all(res.values()), res
+
+
+def test_reducer_single_process_is_a_noop():
+    from monopsr_amd.core.trainer import ReverseBucketReducer
+    flat = torch.arange(10, dtype=torch.float32)
+    red = ReverseBucketReducer(flat, [(0, 5), (5, 10)], bucket_bytes=16)
+    red.layer_ready(1)
+    red.layer_ready(0)
+    red.finish()
+    assert torch.equal(flat, torch.arange(10, dtype=torch.float32))

@@ -1,0 +1,77 @@
+"""Data-parallel TRAINING step of the instance path (secondary measurement; bench.py is the headline metric):
+forward + Chamfer / smooth-L1 losses + backward + gradient all-reduce (RCCL when launched with torchrun) + clip +
+Adam, synthetic inputs of BASELINE config 4 (256 crops per GPU, 1024-pt... here the full 2304-pt map vs GT map).
+
+    python tools/train_bench.py [--batch 256] [--steps 5]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_bench.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from monopsr_amd.core import config_utils  # noqa: E402
+from monopsr_amd.core import train_net, trainer  # noqa: E402
+from monopsr_amd.core import weights as W  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-clip", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = config_utils.default_config()
+    net = train_net.TrainNet(W.synthetic_weights(seed=0), device=dev)
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, clip_norm=0.0 if args.no_clip else 1.0)
+    inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
+    B = args.batch
+    sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
+                  cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"], mean_lwh=inp["mean_lwh"],
+                  prop_cen_z_offset=inp["z_off"])
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    gt = dict(xyz=torch.randn((B, 48, 48, 3), device=dev, generator=g) * 2,
+              mask=(torch.rand((B, 48, 48, 1), device=dev, generator=g) > 0.3).float(),
+              lwh=inp["mean_lwh"] + 0.1, centroids=torch.randn((B, 3), device=dev, generator=g) * 5)
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(float(tr.step(sample, gt)))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.step(sample, gt))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "instance-crops/sec (train: fwd+bwd+allreduce+Adam)",
+                          "value": round(B * world * args.steps / dt, 1), "unit": "crops/s", "n_gpus": world,
+                          "ms_per_step": round(1e3 * dt / args.steps, 2), "params": int(net.params.numel()),
+                          "grad_bytes": int(net.grads.numel() * 4),
+                          "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
