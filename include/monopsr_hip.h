@@ -129,6 +129,11 @@ int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, 
  * dx = mpsr_conv2d_nhwc_f32(dy, ..., w = wd, N := C, C := N) with the same KH, KW, dilation. */
 int mpsr_conv2d_dgrad_pack(const float *w, int N, int KH, int KW, int C, float *wd, mpsr_stream_t stream);
 
+/* Fused activation + bias gradient in one pass over dy (M,N): g = (y > 0 ? dy : 0) when y != NULL else dy;
+ * dx = g when dx != NULL (may alias dy); db[n] += sum_m g[m][n] when db != NULL (zeroed by the caller). */
+int mpsr_act_bias_grad(const float *dy, const float *y, float *dx, float *db, long long M, int N,
+                       mpsr_stream_t stream);
+
 /* db[n] += sum_m dy[m][n]; db zeroed by the caller. */
 int mpsr_bias_grad(const float *dy, long long M, int N, float *db, mpsr_stream_t stream);
 

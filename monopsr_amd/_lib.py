@@ -65,6 +65,7 @@ SIGNATURES = {
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
     "mpsr_conv2d_wgrad_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_act_bias_grad": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f]),
     "mpsr_bias_grad": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
     "mpsr_relu_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_f]),
     "mpsr_max_pool_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

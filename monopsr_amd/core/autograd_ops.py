@@ -46,14 +46,17 @@ class Conv2dFn(torch.autograd.Function):
         L = ctx.layer
         x, y = ctx.saved_tensors
         g = dy.contiguous()
-        if L.relu:
-            g = _relu_grad(g, y)
         lib = _lib.lib()
         B, H, W, C = x.shape
         N = L.cout
         s = _lib.stream()
-        if L.db is not None:
-            _lib.check(lib.mpsr_bias_grad(_lib.ptr(g), B * H * W, N, _lib.ptr(L.db), s))
+        if L.relu or L.db is not None:
+            # one pass: ReLU mask (when the layer has one) + bias gradient (when it has a bias)
+            gm = torch.empty_like(g) if L.relu else None
+            _lib.check(lib.mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y) if L.relu else None, _lib.ptr(gm),
+                                              _lib.ptr(L.db), B * H * W, N, s))
+            if L.relu:
+                g = gm
         # the kernels read rows of N floats with 16-byte loads: pad a narrow output (the 3-channel xyz head) to 4
         pad = (-N) % 4
         g4 = F.pad(g, (0, pad)) if pad else g

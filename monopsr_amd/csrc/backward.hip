@@ -153,7 +153,53 @@ __global__ __launch_bounds__(256) void dgrad_pack_kernel(const float *__restrict
     }
 }
 
-// db[n] += sum_m dy[m][n]; grid (ceil(N/256), row splits)
+// Fused activation + bias gradient: g = (y > 0 ? dy : 0) (or g = dy when y == nullptr), written to dx (may be
+// nullptr when only the column sums are wanted), and db[n] += sum_m g[m][n].  One pass over dy: a thread owns one
+// float4 column group and strides over rows; column sums are combined across the workgroup in LDS, then one fp32
+// atomic per column per workgroup.  N % 4 == 0, N <= 1024.
+__global__ __launch_bounds__(256) void act_bias_grad_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                            float *__restrict__ dx, float *__restrict__ db,
+                                                            long long M, int N, long long rows_per_block)
+{
+    __shared__ float4 part[256];
+    const int groups = N >> 2;            // float4 column groups per row
+    const int rstride = 256 / groups;     // rows covered per pass (>= 1 since N <= 1024)
+    const int tid = threadIdx.x;
+    const int cg = tid % groups, r0 = tid / groups;
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < rstride) {
+        for (long long m = m0 + r0; m < m1; m += rstride) {
+            const size_t o = (size_t)m * groups + cg;
+            float4 g = reinterpret_cast<const float4 *>(dy)[o];
+            if (y) {
+                const float4 a = reinterpret_cast<const float4 *>(y)[o];
+                g.x = a.x > 0.f ? g.x : 0.f;
+                g.y = a.y > 0.f ? g.y : 0.f;
+                g.z = a.z > 0.f ? g.z : 0.f;
+                g.w = a.w > 0.f ? g.w : 0.f;
+            }
+            if (dx) reinterpret_cast<float4 *>(dx)[o] = g;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        }
+    }
+    if (!db) return;
+    part[tid] = s;
+    __syncthreads();
+    if (tid < groups) {
+        float4 t = part[tid];
+        for (int r = 1; r < rstride; ++r) {
+            const float4 u = part[r * groups + tid];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        unsafeAtomicAdd(&db[4 * tid], t.x);
+        unsafeAtomicAdd(&db[4 * tid + 1], t.y);
+        unsafeAtomicAdd(&db[4 * tid + 2], t.z);
+        unsafeAtomicAdd(&db[4 * tid + 3], t.w);
+    }
+}
+
+// generic fallbacks (any N)
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, long long M, int N,
                                                         long long rows_per_block, float *__restrict__ db)
 {
@@ -165,7 +211,6 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
     unsafeAtomicAdd(&db[n], s);
 }
 
-// dx = dy where y > 0 else 0 (y = the layer's post-activation output)
 __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ dx, long long total)
 {
@@ -305,6 +350,42 @@ extern "C" int mpsr_bias_grad(const float *dy, long long M, int N, float *db, mp
     hipLaunchKernelGGL(bias_grad_kernel, dim3(mpsr::ceil_div(N, 256), (unsigned)((M + rows - 1) / rows)), dim3(256), 0,
                        mpsr::as_stream(stream), dy, M, N, rows, db);
     MPSR_CHECK_LAUNCH("bias_grad_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_act_bias_grad(const float *dy, const float *y, float *dx, float *db, long long M, int N,
+                                  mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(M >= 0 && N > 0, "act_bias_grad: bad shape");
+    if (M == 0) return MPSR_OK;
+    MPSR_REQUIRE(dy && (dx || db), "act_bias_grad: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    if (N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && ((uintptr_t)dy & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0) &&
+        (!dx || ((uintptr_t)dx & 15) == 0)) {
+        long long blocks = (M * N / 4 + 256 * 16 - 1) / (256 * 16);  // ~16 float4 per thread
+        if (blocks < 1) blocks = 1;
+        if (blocks > 4096) blocks = 4096;
+        const long long rows = (M + blocks - 1) / blocks;
+        hipLaunchKernelGGL(act_bias_grad_kernel, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, s, dy, y, dx, db,
+                           M, N, rows);
+        MPSR_CHECK_LAUNCH("act_bias_grad_kernel");
+        return MPSR_OK;
+    }
+    const float *g = dy;
+    if (y) {
+        MPSR_REQUIRE(dx, "act_bias_grad: dx required on the generic path when y is given");
+        hipLaunchKernelGGL(relu_grad_kernel, dim3(grid_for(M * N)), dim3(256), 0, s, dy, y, dx, M * N);
+        MPSR_CHECK_LAUNCH("relu_grad_kernel");
+        g = dx;
+    }
+    if (db) {
+        long long splits = (M + 511) / 512;
+        if (splits > 2048) splits = 2048;
+        const long long rows = (M + splits - 1) / splits;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(mpsr::ceil_div(N, 256), (unsigned)((M + rows - 1) / rows)), dim3(256), 0,
+                           s, g, M, N, rows, db);
+        MPSR_CHECK_LAUNCH("bias_grad_kernel");
+    }
     return MPSR_OK;
 }
 
