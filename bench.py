@@ -147,13 +147,14 @@ def cpu_baseline(weights, host, sample, npts):
     first `sample` instances of the same workload.  Reported baseline only."""
     from oracle import net as onet
     from oracle import ops as orc
-    if sample <= 0:  # size the sample for roughly 15 s of CPU work from a 2-instance probe
-        t0 = time.perf_counter()
+    if sample <= 0:  # size the sample for roughly 15 s of CPU work from a warm 8-instance probe of the trunk
+        sc = "FirstStageFeatureExtractor_crop/resnet_v1_101"
         with torch.no_grad():
-            onet.resnet101_block3(torch.from_numpy(host["crops"][:2]), weights,
-                                  "FirstStageFeatureExtractor_crop/resnet_v1_101")
-        per = (time.perf_counter() - t0) / 2 * 1.6  # trunk is ~64 % of the per-crop work
-        sample = int(max(4, min(host["crops"].shape[0], 15.0 / per)))
+            onet.resnet101_block3(torch.from_numpy(host["crops"][:2]), weights, sc)  # warm-up (thread pool, oneDNN)
+            t0 = time.perf_counter()
+            onet.resnet101_block3(torch.from_numpy(host["crops"][:8]), weights, sc)
+        per = (time.perf_counter() - t0) / 8 * 1.6  # trunk is ~64 % of the per-crop work
+        sample = int(max(8, min(host["crops"].shape[0], 15.0 / per)))
     s = slice(0, sample)
     t0 = time.perf_counter()
     with torch.no_grad():
