@@ -88,6 +88,9 @@ class DeviceNet:
         return conv2d(x.reshape(B, 1, 1, kpad), w_ok, bias, None, 1, 1, 1, relu, split_k=split).reshape(B, -1)
 
     # ------------------------------------------------------------------ trunk
+    MAX_CHUNK = 512  # instances per native call: keeps every activation of one call below the 4 GiB that the
+    #                  kernels' 32-bit buffer offsets address (largest: B x 48 x 48 x 256 fp32 = 2.4 MB per instance)
+
     def trunk(self, img, which="crop"):
         """img (B,H,W,3) -> block3 (B,H/4,W/4,C)."""
         part = self.crop_trunk if which == "crop" else self.full_trunk
@@ -95,6 +98,8 @@ class DeviceNet:
             raise _lib.MpsrError("DeviceNet was built without the full-image trunk")
         img = img.contiguous()
         B, H, Wd, _ = img.shape
+        if B > self.MAX_CHUNK:
+            return torch.cat([self.trunk(img[i:i + self.MAX_CHUNK], which) for i in range(0, B, self.MAX_CHUNK)], 0)
         oh, ow = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
         ph, pw = (oh + 1) // 2, (ow + 1) // 2
         cout = part.records[-1]["cout"]
@@ -110,6 +115,10 @@ class DeviceNet:
     def squash_decoder(self, crop_feat, full_feat, map_size=(48, 48), want_feat_map=True, want_xyz=True):
         crop_feat, full_feat = crop_feat.contiguous(), full_feat.contiguous()
         B, fh, fw, _ = crop_feat.shape
+        if B > self.MAX_CHUNK:
+            parts = [self.squash_decoder(crop_feat[i:i + self.MAX_CHUNK], full_feat[i:i + self.MAX_CHUNK], map_size,
+                                         want_feat_map, want_xyz) for i in range(0, B, self.MAX_CHUNK)]
+            return tuple(torch.cat([p[k] for p in parts], 0) if parts[0][k] is not None else None for k in range(3))
         mh, mw = map_size
         recs = self.decoder.records
         csq, c3 = recs[1]["cout"], recs[5]["cout"]

@@ -362,3 +362,28 @@ def test_evaluate_predictions_metrics():
                                rtol=1e-5)
     emd = orc.match_cost(p, g, orc.approx_match(p, g, "gpu"), "gpu")
     np.testing.assert_allclose(m[constants.METRIC_EMD].cpu().numpy(), (emd / nvalid)[:3], rtol=1e-3)
+
+
+def test_device_net_batch_chunking_is_bit_identical():
+    """Batches above DeviceNet.MAX_CHUNK run as several native calls; instances are independent and every output
+    element's K order is unchanged, so the result has the same bits."""
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    weights = W.synthetic_weights(seed=71, width_div=4)
+    net = dn.DeviceNet(weights, width_div=4)
+    rng = np.random.default_rng(72)
+    B = 5
+    crops = _dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32))
+    full = _dev(np.maximum(rng.standard_normal((B, 12, 12, 256)), 0).astype(np.float32))
+    f1 = net.trunk(crops)
+    a1 = net.squash_decoder(f1, full)
+    old = dn.DeviceNet.MAX_CHUNK
+    dn.DeviceNet.MAX_CHUNK = 2
+    try:
+        f2 = net.trunk(crops)
+        a2 = net.squash_decoder(f2, full)
+    finally:
+        dn.DeviceNet.MAX_CHUNK = old
+    assert torch.equal(f1, f2)
+    for x, y in zip(a1, a2):
+        assert torch.equal(x, y)
