@@ -9,15 +9,16 @@
 //     match[l][k] = sum_levels exp(level * |p2_l - p1_k|^2) * ratioL[level][k] * ratioR[level][l]
 // (same terms, same summation order as the reference's accumulation) so match is written exactly once:
 // b*n*m*4 bytes of HBM traffic instead of ~19x that, for 10 extra exponentials per pair.
-//   * sweeps: one 1024-thread workgroup per cloud; the opposite cloud is staged through LDS as float4
-//     (x, y, z, weight) tiles and read with wave-uniform ds_read_b128; each thread carries kPT own points;
+//   * sweeps: one launch per sweep, 512 own points per 256-thread workgroup; the opposite cloud is staged through
+//     LDS as float4 (x, y, z, weight) tiles and read with wave-uniform ds_read_b128; each thread carries kPT own
+//     points;
 //   * exp(x) is evaluated as exp2(x * log2 e) with log2 e folded into the level constant (v_exp_f32).
 #include "common.h"
 
 namespace {
 
 constexpr int kLevels = 10;
-constexpr int kSweepThreads = 1024;
+constexpr int kSweepThreads = 256;
 constexpr int kPT = 2;         // own points per thread in the sweeps
 constexpr int kTile = 2048;    // opposite-cloud points per LDS tile (32 KiB)
 constexpr float kLog2e = 1.4426950408889634f;
@@ -36,143 +37,96 @@ __device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, flo
     return dx * dx + dy * dy + dz * dz;
 }
 
-// Stage `cnt` points (xyz from `pts`, 4th lane from `wgt`) into the LDS tile.
+// Stage `cnt` points (xyz from `pts`, 4th lane from `wgt`, or the constant `wconst` when wgt == nullptr).
 __device__ __forceinline__ void stage_tile(float4 *tile, const float *__restrict__ pts, const float *__restrict__ wgt,
-                                           int first, int cnt)
+                                           float wconst, int first, int cnt)
 {
     for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
         const float *s = pts + (size_t)(first + p) * 3;
-        tile[p] = make_float4(s[0], s[1], s[2], wgt[first + p]);
+        tile[p] = make_float4(s[0], s[1], s[2], wgt ? wgt[first + p] : wconst);
     }
 }
 
 // State per cloud in `temp`: remL[n] remR[m] ratL[kLevels][n] ratR[kLevels][m].
-__global__ __launch_bounds__(kSweepThreads) void approx_match_sweeps_kernel(int n, int m,
-                                                                           const float *__restrict__ xyz1,
-                                                                           const float *__restrict__ xyz2,
-                                                                           float *__restrict__ temp)
+//
+// One launch per sweep (3 per level, 30 in all): every sweep is independent per OWN point (sweeps 1 and 3 per giver
+// k, sweep 2 per receiver l) and only needs the previous sweep finished, so the launch boundary is the only
+// synchronisation and a cloud spreads over ceil(points / 512) workgroups instead of one -- the reference's
+// 32-cloud evaluation batches fill the chip too.  grid = (ceil(own / (kSweepThreads * kPT)), b).
+//   SWEEP 1: ratL[k] = remL[k] / (1e-9 + sum_l e(k,l) * remR[l])
+//   SWEEP 2: s = remR[l] * sum_k e(k,l) * ratL[k];  ratR[l] = min(remR[l] / (s + 1e-9), 1) * remR[l];
+//            remR[l] = max(0, remR[l] - s)
+//   SWEEP 3: remL[k] = max(0, remL[k] - ratL[k] * sum_l e(k,l) * ratR[l])
+// At level 0 the capacities are the constants multiL / multiR (no initialisation pass).
+template <int SWEEP>
+__global__ __launch_bounds__(kSweepThreads) void approx_match_sweep_kernel(int n, int m,
+                                                                          const float *__restrict__ xyz1,
+                                                                          const float *__restrict__ xyz2,
+                                                                          float *__restrict__ temp, int lev)
 {
     __shared__ float4 tile[kTile];
-    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int cloud = blockIdx.y, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
     const float *p2 = xyz2 + (size_t)cloud * m * 3;
     float *st = temp + (size_t)cloud * ((size_t)(n + m) * (1 + kLevels));
     float *remL = st, *remR = st + n;
-    float *ratLall = st + n + m, *ratRall = ratLall + (size_t)kLevels * n;
+    float *ratL = st + n + m + (size_t)lev * n;
+    float *ratR = st + n + m + (size_t)kLevels * n + (size_t)lev * m;
     const float multiL = n >= m ? 1.f : (float)(m / n);
     const float multiR = n >= m ? (float)(n / m) : 1.f;
-    for (int k = tid; k < n; k += kSweepThreads) remL[k] = multiL;
-    for (int l = tid; l < m; l += kSweepThreads) remR[l] = multiR;
-    __syncthreads();
+    const bool first = lev == 0;
+    const float lv = level_log2e(lev);
+    constexpr bool kOwnIsL = SWEEP != 2;           // own points come from cloud 1 (givers) in sweeps 1 and 3
+    const int nown = kOwnIsL ? n : m, nother = kOwnIsL ? m : n;
+    const float *own = kOwnIsL ? p1 : p2, *other = kOwnIsL ? p2 : p1;
+    const float *wgt = SWEEP == 1 ? (first ? nullptr : remR) : (SWEEP == 2 ? ratL : ratR);
 
-    for (int lev = 0; lev < kLevels; ++lev) {
-        const float lv = level_log2e(lev);
-        float *ratL = ratLall + (size_t)lev * n;
-        float *ratR = ratRall + (size_t)lev * m;
-
-        // sweep 1: what each giver k could hand out, weighted by what receivers can still take
-        for (int k0 = 0; k0 < n; k0 += kSweepThreads * kPT) {
-            float x[kPT], y[kPT], z[kPT], s[kPT];
+    const int base = blockIdx.x * (kSweepThreads * kPT);
+    float x[kPT], y[kPT], z[kPT], s[kPT];
 #pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                const int k = k0 + u * kSweepThreads + tid;
-                const bool live = k < n;
-                x[u] = live ? p1[3 * k] : 0.f;
-                y[u] = live ? p1[3 * k + 1] : 0.f;
-                z[u] = live ? p1[3 * k + 2] : 0.f;
-                s[u] = 1e-9f;
-            }
-            for (int l0 = 0; l0 < m; l0 += kTile) {
-                const int cnt = min(kTile, m - l0);
-                __syncthreads();
-                stage_tile(tile, p2, remR, l0, cnt);
-                __syncthreads();
+    for (int u = 0; u < kPT; ++u) {
+        const int i = base + u * kSweepThreads + tid;
+        const bool live = i < nown;
+        x[u] = live ? own[3 * i] : 0.f;
+        y[u] = live ? own[3 * i + 1] : 0.f;
+        z[u] = live ? own[3 * i + 2] : 0.f;
+        s[u] = SWEEP == 1 ? 1e-9f : 0.f;
+    }
+    for (int o0 = 0; o0 < nother; o0 += kTile) {
+        const int cnt = min(kTile, nother - o0);
+        __syncthreads();
+        stage_tile(tile, other, wgt, multiR, o0, cnt);
+        __syncthreads();
 #pragma unroll 4
-                for (int l = 0; l < cnt; ++l) {
-                    const float4 t = tile[l];
-#pragma unroll
-                    for (int u = 0; u < kPT; ++u) s[u] += __builtin_amdgcn_exp2f(lv * sq3(t.x, t.y, t.z, x[u], y[u], z[u])) * t.w;
-                }
-            }
+        for (int o = 0; o < cnt; ++o) {
+            const float4 t = tile[o];
 #pragma unroll
             for (int u = 0; u < kPT; ++u) {
-                const int k = k0 + u * kSweepThreads + tid;
-                if (k < n) ratL[k] = remL[k] / s[u];
+                // distance evaluated as (other - own) for givers, (own - other) for receivers: the reference's
+                // operand order (x2 - x1), squares are identical either way
+                const float d2 = kOwnIsL ? sq3(t.x, t.y, t.z, x[u], y[u], z[u]) : sq3(x[u], y[u], z[u], t.x, t.y, t.z);
+                s[u] += __builtin_amdgcn_exp2f(lv * d2) * t.w;
             }
         }
-        __syncthreads();
-
-        // sweep 2: what each receiver l is offered; over-subscribed receivers scale down; receiver capacity update
-        for (int l0 = 0; l0 < m; l0 += kSweepThreads * kPT) {
-            float x[kPT], y[kPT], z[kPT], s[kPT];
+    }
 #pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                const int l = l0 + u * kSweepThreads + tid;
-                const bool live = l < m;
-                x[u] = live ? p2[3 * l] : 0.f;
-                y[u] = live ? p2[3 * l + 1] : 0.f;
-                z[u] = live ? p2[3 * l + 2] : 0.f;
-                s[u] = 0.f;
-            }
-            for (int k0 = 0; k0 < n; k0 += kTile) {
-                const int cnt = min(kTile, n - k0);
-                __syncthreads();
-                stage_tile(tile, p1, ratL, k0, cnt);
-                __syncthreads();
-#pragma unroll 4
-                for (int k = 0; k < cnt; ++k) {
-                    const float4 t = tile[k];
-#pragma unroll
-                    for (int u = 0; u < kPT; ++u) s[u] += __builtin_amdgcn_exp2f(lv * sq3(x[u], y[u], z[u], t.x, t.y, t.z)) * t.w;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                const int l = l0 + u * kSweepThreads + tid;
-                if (l < m) {
-                    const float rem = remR[l];
-                    const float offered = s[u] * rem;
-                    const float consumption = fminf(rem / (offered + 1e-9f), 1.0f);
-                    ratR[l] = consumption * rem;
-                    remR[l] = fmaxf(0.0f, rem - offered);
-                }
-            }
+    for (int u = 0; u < kPT; ++u) {
+        const int i = base + u * kSweepThreads + tid;
+        if (i >= nown) continue;
+        if (SWEEP == 1) {
+            ratL[i] = (first ? multiL : remL[i]) / s[u];
+        } else if (SWEEP == 2) {
+            const float rem = first ? multiR : remR[i];
+            const float offered = s[u] * rem;
+            const float consumption = fminf(rem / (offered + 1e-9f), 1.0f);
+            ratR[i] = consumption * rem;
+            remR[i] = fmaxf(0.0f, rem - offered);
+        } else {
+            // the reference multiplies every term by ratL[k] inside the sum; factoring it out changes the rounding
+            // of the sum by < 1 ulp per term and stays far inside the 1e-3 bar
+            const float given = s[u] * ratL[i];
+            remL[i] = fmaxf(0.0f, (first ? multiL : remL[i]) - given);
         }
-        __syncthreads();
-
-        // sweep 3: what each giver k actually hands out at this level; giver capacity update
-        for (int k0 = 0; k0 < n; k0 += kSweepThreads * kPT) {
-            float x[kPT], y[kPT], z[kPT], s[kPT], rl[kPT];
-#pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                const int k = k0 + u * kSweepThreads + tid;
-                const bool live = k < n;
-                x[u] = live ? p1[3 * k] : 0.f;
-                y[u] = live ? p1[3 * k + 1] : 0.f;
-                z[u] = live ? p1[3 * k + 2] : 0.f;
-                rl[u] = live ? ratL[k] : 0.f;
-                s[u] = 0.f;
-            }
-            for (int l0 = 0; l0 < m; l0 += kTile) {
-                const int cnt = min(kTile, m - l0);
-                __syncthreads();
-                stage_tile(tile, p2, ratR, l0, cnt);
-                __syncthreads();
-#pragma unroll 4
-                for (int l = 0; l < cnt; ++l) {
-                    const float4 t = tile[l];
-#pragma unroll
-                    for (int u = 0; u < kPT; ++u)
-                        s[u] += __builtin_amdgcn_exp2f(lv * sq3(t.x, t.y, t.z, x[u], y[u], z[u])) * rl[u] * t.w;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                const int k = k0 + u * kSweepThreads + tid;
-                if (k < n) remL[k] = fmaxf(0.0f, remL[k] - s[u]);
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -226,10 +180,13 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// cost[cloud] = sum_{l,k} |p2_l - p1_k| * match[l][k]; one workgroup per cloud streams its match slab once.
-__global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, const float *__restrict__ xyz1,
+// cost[cloud] = sum_{l,k} |p2_l - p1_k| * match[l][k]; the match slab is streamed once.  grid (b, slices): a
+// workgroup takes `rows` receiver rows of one cloud; with more than one slice per cloud the partial sums meet in an
+// fp32 atomic on the pre-zeroed output.
+__global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, int rows, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2,
-                                                          const float *__restrict__ match, float *__restrict__ out)
+                                                          const float *__restrict__ match, float *__restrict__ out,
+                                                          int atomic)
 {
     __shared__ float4 tile[kTile];
     __shared__ float part[16];
@@ -237,9 +194,10 @@ __global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, const fl
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
     const float *p2 = xyz2 + (size_t)cloud * m * 3;
     const float *mt = match + (size_t)cloud * n * m;
+    const int lbeg = blockIdx.y * rows, lend = min(m, lbeg + rows);
     float acc = 0.f;
-    for (int l0 = 0; l0 < m; l0 += kTile) {
-        const int cnt = min(kTile, m - l0);
+    for (int l0 = lbeg; l0 < lend; l0 += kTile) {
+        const int cnt = min(kTile, lend - l0);
         __syncthreads();
         for (int p = tid; p < cnt; p += 1024) {
             const float *s = p2 + (size_t)(l0 + p) * 3;
@@ -262,7 +220,10 @@ __global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, const fl
     if (tid < 64) {
         float v = tid < 16 ? part[tid] : 0.f;
         v = wave_sum(v);
-        if (tid == 0) out[cloud] = v;
+        if (tid == 0) {
+            if (atomic) atomicAdd(&out[cloud], v);
+            else out[cloud] = v;
+        }
     }
 }
 
@@ -368,8 +329,13 @@ extern "C" int mpsr_approx_match(int b, int n, int m, const float *xyz1, const f
     if (b == 0) return MPSR_OK;
     MPSR_REQUIRE(xyz1 && xyz2 && match && temp, "approx_match: null pointer");
     hipStream_t s = mpsr::as_stream(stream);
-    hipLaunchKernelGGL(approx_match_sweeps_kernel, dim3(b), dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp);
-    MPSR_CHECK_LAUNCH("approx_match_sweeps_kernel");
+    const dim3 gl(mpsr::ceil_div(n, kSweepThreads * kPT), b), gr(mpsr::ceil_div(m, kSweepThreads * kPT), b);
+    for (int lev = 0; lev < kLevels; ++lev) {
+        hipLaunchKernelGGL(approx_match_sweep_kernel<1>, gl, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
+        hipLaunchKernelGGL(approx_match_sweep_kernel<2>, gr, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
+        hipLaunchKernelGGL(approx_match_sweep_kernel<3>, gl, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
+    }
+    MPSR_CHECK_LAUNCH("approx_match_sweep_kernel");
     dim3 grid(mpsr::ceil_div(n, 256), mpsr::ceil_div(m, kEmitRows), b);
     MPSR_REQUIRE(grid.y <= 65535, "approx_match: m=%d too large", m);
     hipLaunchKernelGGL(approx_match_emit_kernel, grid, dim3(256), 0, s, n, m, xyz1, xyz2, temp, match);
@@ -383,8 +349,16 @@ extern "C" int mpsr_match_cost(int b, int n, int m, const float *xyz1, const flo
     if (int rc = check_emd_args("match_cost", b, n, m)) return rc;
     if (b == 0) return MPSR_OK;
     MPSR_REQUIRE(xyz1 && xyz2 && match && out, "match_cost: null pointer");
-    hipLaunchKernelGGL(match_cost_kernel, dim3(b), dim3(1024), 0, mpsr::as_stream(stream), n, m, xyz1, xyz2, match,
-                       out);
+    hipStream_t s = mpsr::as_stream(stream);
+    int slices = 1024 / b;  // aim at ~4 workgroups per CU
+    if (slices < 1) slices = 1;
+    if (slices > 32) slices = 32;
+    if (slices > m) slices = m;
+    const int rows = mpsr::ceil_div(m, slices);
+    slices = mpsr::ceil_div(m, rows);
+    if (slices > 1) MPSR_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * b, s));
+    hipLaunchKernelGGL(match_cost_kernel, dim3(b, slices), dim3(1024), 0, s, n, m, rows, xyz1, xyz2, match, out,
+                       slices > 1 ? 1 : 0);
     MPSR_CHECK_LAUNCH("match_cost_kernel");
     return MPSR_OK;
 }
