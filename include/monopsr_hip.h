@@ -154,6 +154,63 @@ int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int O
 int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream);
 
+/* ------------------------------------------------------------------------- per-box geometry and map losses
+ * SURVEY.md 8(f) rows 3-4.  Maps are (b, h, w, c) row-major; p = h*w points per instance. */
+
+/* instance_utils.py:567-602 tf_inst_xyz_map_local_to_global: xyz_global = T(centroid) R_y(view_ang) xyz_local.
+ * xyz_local/xyz_global (b,p,3); view_angs (b); centroids (b,3). */
+int mpsr_xyz_map_local_to_global(const float *xyz_local, const float *view_angs, const float *centroids,
+                                 float *xyz_global, int b, int p, mpsr_stream_t stream);
+
+/* Its gradient: grad_local (b,p,3) = R^T grad_global, grad_centroids (b,3) = sum over points; either may be NULL. */
+int mpsr_xyz_map_local_to_global_grad(const float *grad_global, const float *view_angs, float *grad_local,
+                                      float *grad_centroids, int b, int p, mpsr_stream_t stream);
+
+/* monopsr_output_builder.py:681-746 get_proj_err_maps_norm: (expected pixel-centre grid of the 2-D box - projection
+ * of xyz_global by cam_p) / box [w,h], * valid_mask, clipped to [-2,2] -> proj_err_maps (b,h,w,2) (may be NULL);
+ * proj_err_norm (b) = sum over the map / max(sum(valid_mask), 1).  boxes_2d (b,4) [y1,x1,y2,x2]; cam_p (12);
+ * valid_mask (b,h,w). */
+int mpsr_proj_err_norm(const float *xyz_global, const float *boxes_2d, const float *cam_p, const float *valid_mask,
+                       float *proj_err_maps, float *proj_err_norm, int b, int h, int w, mpsr_stream_t stream);
+
+/* d(sum_b grad_proj_err_norm[b] * proj_err_norm[b]) / d xyz_global -> grad_xyz_global (b,h,w,3), overwritten. */
+int mpsr_proj_err_norm_grad(const float *grad_proj_err_norm, const float *xyz_global, const float *boxes_2d,
+                            const float *cam_p, const float *valid_mask, float *grad_xyz_global, int b, int h, int w,
+                            mpsr_stream_t stream);
+
+/* instance_utils.py:605-680 tf_inst_depth_map_local_to_global: depth_global (b,h,w) = depth_local + cen_z[b]
+ * (+ the view-normalisation offset, linear along the ROW axis as the reference lays it out, when rotate_view).
+ * depth_local is read with a stride of depth_stride floats (3 to read the z channel of an xyz map in place). */
+int mpsr_depth_map_local_to_global(const float *depth_local, int depth_stride, const float *cen_z,
+                                   const float *boxes_2d, const float *view_angs, const float *cam_p,
+                                   float *depth_global, int b, int h, int w, int rotate_view, mpsr_stream_t stream);
+
+/* Gradient w.r.t. cen_z (b); the gradient w.r.t. depth_local is grad_global itself. */
+int mpsr_depth_map_local_to_global_grad(const float *grad_global, const float *boxes_2d, const float *view_angs,
+                                        const float *cam_p, float *grad_cen_z, int b, int h, int w, int rotate_view,
+                                        mpsr_stream_t stream);
+
+/* Per-instance sums behind WeightedNonZeroSmoothL1LocalizationLoss (losses_custom.py:93-132, tf.losses.huber_loss
+ * with Reduction.SUM_BY_NONZERO_WEIGHTS): pred/target (b,p,c), weights (b,p) broadcast over c.
+ * sums[b] = sum huber(pred-target)*w; counts[b] = c * #(w != 0).  loss = sum(sums)/sum(counts) (0 if none). */
+int mpsr_huber_loss_sums(const float *pred, const float *target, const float *weights, int b, int p, int c,
+                         float delta, float *sums, float *counts, mpsr_stream_t stream);
+
+/* grad (b,p,c) = scale[0] * w * clamp(pred - target, -delta, delta); scale is a DEVICE scalar (so the caller can
+ * derive it from sums/counts without a host sync). */
+int mpsr_huber_loss_grad(const float *pred, const float *target, const float *weights, const float *scale, int b,
+                         int p, int c, float delta, float *grad, mpsr_stream_t stream);
+
+/* monopsr_model.py:960-1071 format_predictions (test mode; lwh offset, alpha 'dc', view_ang est, centroids xyz)
+ * with instance_utils.py:988-1032 postprocess_cen_x and monopsr_output_builder.py:805-860 score_boxes, one thread
+ * per box in fp64: box_3d (b,9) = [x,y,z,l,w,h,ry,score,class-1], box_2d (b,7) = [y1,x1,y2,x2,alpha,score,class-1].
+ * lwh (b,3); view_angs (b); alpha_bins/alpha_regs (b,num_alpha_bins); centroids (b,3); boxes_2d (b,4);
+ * scores (b); class_idx (b) int32; cam_p (12). */
+int mpsr_format_boxes(const float *lwh, const float *view_angs, const float *alpha_bins, const float *alpha_regs,
+                      const float *centroids, const float *boxes_2d, const float *scores, const int *class_idx,
+                      const float *cam_p, int b, int num_alpha_bins, int img_h, int img_w, int centroid_middle,
+                      int post_process_cen_x, float max_depth, float *box_3d, float *box_2d, mpsr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ network */
 
 /* One packed convolution / FC layer inside a weight blob (offsets in floats from the blob base). */

@@ -72,6 +72,16 @@ SIGNATURES = {
     "mpsr_resize_bilinear_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, c_i, ctypes.c_float, c_f]),
+    "mpsr_xyz_map_local_to_global": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "mpsr_xyz_map_local_to_global_grad": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "mpsr_proj_err_norm": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "mpsr_proj_err_norm_grad": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "mpsr_depth_map_local_to_global": (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "mpsr_depth_map_local_to_global_grad": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "mpsr_huber_loss_sums": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f]),
+    "mpsr_huber_loss_grad": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f]),
+    "mpsr_format_boxes": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i,
+                                ctypes.c_float, c_f, c_f, c_f]),
     "mpsr_trunk_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
     "mpsr_decoder_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),

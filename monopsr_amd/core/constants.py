@@ -1,6 +1,12 @@
 """String keys of the instance path, same values as the reference's core/constants.py:35-77."""
 KEY_VALID_MASK_MAPS = 'valid_mask_maps'
 KEY_INST_XYZ_MAP_LOCAL = 'inst_xyz_map_local'
+KEY_INST_XYZ_MAP_GLOBAL = 'inst_xyz_map_global'
+KEY_INST_PROJ_ERR_MAP = 'inst_proj_err_map'
+KEY_INST_DEPTH_MAP_GLOBAL = 'inst_depth_map_global'
+KEY_INST_XYZ_MAP_GLOBAL_FROM_DEPTH = 'inst_xyz_map_global_from_depth'
+KEY_BOX_2D = 'box_2d'
+KEY_BOX_3D = 'box_3d'
 KEY_PROP_CEN_Z = 'prop_cen_z'
 KEY_VIEW_ANG = 'view_ang'
 KEY_CEN_X = 'cen_x'
@@ -25,3 +31,18 @@ FEATURES_REGRESSION_FC_OUT = 'features_regression_fc_out'
 
 METRIC_EMD = 'metric_emd'
 METRIC_CHAMFER = 'metric_chamfer'
+
+# sample-dict keys used by format_predictions / save_predictions (core/constants.py:2-32)
+SAMPLE_IMAGE_INPUT = 'sample_image_input'
+SAMPLE_NUM_OBJS = 'sample_num_objs'
+SAMPLE_LABEL_BOXES_2D = 'sample_label_boxes_2d'
+SAMPLE_LABEL_BOXES_3D = 'sample_label_boxes_3d'
+SAMPLE_VIEWING_ANGLES_3D = 'sample_viewing_angles_3d'
+SAMPLE_LABEL_CLASS_INDICES = 'sample_label_class_indices'
+SAMPLE_LABEL_SCORES = 'sample_label_scores'
+SAMPLE_CAM_P = 'sample_cam_p'
+SAMPLE_NAME = 'sample_name'
+
+OUT_DIR_BOX_2D = 'output_box_2d_dir'
+OUT_DIR_BOX_3D = 'output_box_3d_dir'
+OUT_DIR_XYZ_MAP_LOCAL = 'output_xyz_map_dir'

@@ -1,6 +1,79 @@
-"""Point-cloud losses of the reference (core/losses_custom.py:135-198), over the HIP ops."""
+"""The reference's custom losses (core/losses_custom.py), same class names and call convention, over the HIP ops:
+point-cloud losses (:135-198), the masked smooth-L1 the maps are trained with (:93-132), berHu (:45-90) and the
+sigmoid mask loss (:201-232)."""
+import torch
+import torch.nn.functional as F
+
+from monopsr_amd import _lib
+from monopsr_amd.core.losses import Loss
 from monopsr_amd.tf_ops.approxmatch import tf_approxmatch
 from monopsr_amd.tf_ops.nn_distance import tf_nndistance
+
+
+class _HuberNonZero(torch.autograd.Function):
+    """sum(huber(pred - target) * w) / #(broadcast w != 0) via mpsr_huber_loss_sums / mpsr_huber_loss_grad."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weights, delta):
+        b, c = pred.shape[0], pred.shape[-1]
+        p = pred[0].numel() // c if b else 0
+        pred, target = pred.contiguous().float(), target.contiguous().float()
+        weights = weights.contiguous().float()
+        sums = torch.empty((b,), dtype=torch.float32, device=pred.device)
+        counts = torch.empty((b,), dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.lib().mpsr_huber_loss_sums(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weights), b, p, c,
+                                                   float(delta), _lib.ptr(sums), _lib.ptr(counts), _lib.stream()))
+        n = counts.sum()
+        ctx.save_for_backward(pred, target, weights, n)
+        ctx.meta = (b, p, c, float(delta))
+        return torch.where(n > 0, sums.sum() / torch.clamp(n, min=1.0), torch.zeros_like(n))
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, weights, n = ctx.saved_tensors
+        b, p, c, delta = ctx.meta
+        scale = torch.where(n > 0, g.float() / torch.clamp(n, min=1.0), torch.zeros_like(n)).reshape(1).contiguous()
+        grad = torch.empty_like(pred)
+        _lib.check(_lib.lib().mpsr_huber_loss_grad(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weights),
+                                                   _lib.ptr(scale), b, p, c, delta, _lib.ptr(grad), _lib.stream()))
+        return grad, None, None, None
+
+
+class WeightedNonZeroSmoothL1LocalizationLoss(Loss):
+    """losses_custom.py:93-132: tf.losses.huber_loss with Reduction.SUM_BY_NONZERO_WEIGHTS -> a scalar.
+    weights must be prediction_tensor's shape with a last axis of 1 (a per-pixel / per-box mask)."""
+
+    def __init__(self, delta=1.0):
+        self._delta = delta
+
+    def _compute_loss(self, prediction_tensor, target_tensor, weights):
+        if tuple(weights.shape) != tuple(prediction_tensor.shape[:-1]) + (1,):
+            raise _lib.InvalidArgumentError("weights must have shape prediction.shape[:-1] + (1,), got %s for %s"
+                                            % (tuple(weights.shape), tuple(prediction_tensor.shape)))
+        if tuple(target_tensor.shape) != tuple(prediction_tensor.shape):
+            raise _lib.InvalidArgumentError("prediction and target shapes differ")
+        return _HuberNonZero.apply(prediction_tensor, target_tensor, weights, self._delta)
+
+
+class WeightedBerHu(Loss):
+    """losses_custom.py:45-90 (not selected by model 000's loss_config; small torch expression)."""
+
+    def _compute_loss(self, prediction_tensor, target_tensor, weights):
+        error = prediction_tensor - target_tensor
+        abs_error = error.abs()
+        l1_thresh = abs_error.max() / 5.0
+        per_pixel = torch.where(abs_error <= l1_thresh, abs_error, (error ** 2 + l1_thresh ** 2) / (2 * l1_thresh))
+        weights = weights.float()
+        num_valid = (weights != 0).sum().float()
+        total = (per_pixel * weights).sum()
+        return torch.where(num_valid > 0, total / torch.clamp(num_valid, min=1.0), torch.zeros_like(total))
+
+
+class SigmoidClassificationLoss(Loss):
+    """losses_custom.py:201-232: per-entry sigmoid cross entropy; the weights argument is ignored there too."""
+
+    def _compute_loss(self, prediction_tensor, target_tensor, class_indices=None, weights=None):
+        return F.binary_cross_entropy_with_logits(prediction_tensor, target_tensor, reduction='none')
 
 
 def _masked_points(prediction_tensor, target_tensor, weights):

@@ -4,12 +4,14 @@ Method names, arguments, output_dict keys and the order of operations are the re
 layer runs through the HIP fp32-MFMA GEMM (DeviceNet.fully_connected), the per-box scalar algebra (a few flops
 per box) is plain tensor arithmetic on the GPU.  The fused native fast path for the same graph is
 mpsr_heads_fwd (DeviceNet.heads_fwd); tests check that both agree.
-Only the output types of monopsr_model_000.yaml plus their 'est' variants are implemented; 'gt' variants and the
-global-map projection / box rescoring (:663-860) are out of scope.
+Only the output types of monopsr_model_000.yaml plus their 'est' variants are implemented ('gt' variants are
+not).  The global maps (:663-772) run through the geometry kernels (datasets/kitti/instance_utils.py); box
+rescoring (:805-860) is fused into mpsr_format_boxes (MonoPSRModel.format_predictions).
 """
 import torch
 
 from monopsr_amd.core import constants
+from monopsr_amd.datasets.kitti import instance_utils
 
 PROP_CEN_Y_NORM = 1.666754  # monopsr_output_builder.py:246
 CEN_Y_CLASS_OFFSET = {('Car', 'kitti'): 0.0648, ('Car', 'mscnn'): 0.0655, ('Pedestrian', 'kitti'): 0.0145,
@@ -237,3 +239,30 @@ class MonoPSROutputBuilder:
         self._output_dict.add_unique_to_dict({output_key: torch.cat([pred_cen_x, pred_cen_y, pred_cen_z], dim=1)})
         if self.is_train_or_val and gt_centroids is not None:
             self._gt_dict.add_unique_to_dict({output_key: gt_centroids})
+
+    # ------------------------------------------------------------------ global maps (:663-772)
+    def get_inst_xyz_map_global(self, pred_inst_xyz_maps_local, pred_view_angs, pred_centroids):
+        """Global point cloud map from the local xyz map (instance_utils.tf_inst_xyz_map_local_to_global)."""
+        return instance_utils.tf_inst_xyz_map_local_to_global(pred_inst_xyz_maps_local, self.map_roi_size,
+                                                              pred_view_angs, pred_centroids)
+
+    def get_proj_err_maps_norm(self, pred_inst_xyz_map_global, pred_boxes_2d, valid_mask_maps, debug=False):
+        """:681-746 -> (proj_err_norm (N,), proj_err_debug_dict).  The debug dict holds the normalised error map
+        only when `debug` (the reference's other debug entries are intermediate tensors of its TF graph)."""
+        proj_err_norm, maps = instance_utils.proj_err_maps_norm(pred_inst_xyz_map_global, pred_boxes_2d, self.cam_p,
+                                                                valid_mask_maps, want_maps=debug)
+        proj_err_debug_dict = {'pred_inst_xyz_map_global': pred_inst_xyz_map_global}
+        if debug:
+            proj_err_debug_dict['proj_err_map_norm'] = maps
+        return proj_err_norm, proj_err_debug_dict
+
+    def add_inst_depth_maps_global(self, pred_inst_depth_maps_local, gt_inst_depth_maps_global, rotate_view, box_2d):
+        """:748-772: local depth + predicted centroid depth (+ view-normalisation offset)."""
+        output_key = constants.KEY_INST_DEPTH_MAP_GLOBAL
+        pred_cen_z = self._output_dict[constants.KEY_CEN_Z]
+        inst_view_ang = self._output_dict[constants.KEY_VIEW_ANG]
+        pred = instance_utils.tf_inst_depth_map_local_to_global(
+            pred_inst_depth_maps_local, pred_cen_z, box_2d, inst_view_ang, self.map_roi_size, self.cam_p, rotate_view)
+        self._output_dict.add_unique_to_dict({output_key: pred})
+        if self.is_train_or_val:
+            self._gt_dict.add_unique_to_dict({output_key: gt_inst_depth_maps_global})

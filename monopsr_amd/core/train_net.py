@@ -69,7 +69,10 @@ class TrainNet:
         self.n_dec = len(parts[1][1])
 
     # ------------------------------------------------------------------ forward pieces
-    def trunk(self, img):
+    def trunk(self, img, scope='crop'):
+        if scope != 'crop':
+            raise _lib.InvalidArgumentError("TrainNet holds the crop trunk only (the full-image branch is fed as "
+                                            "its feature crop, SURVEY 8(a) a3)")
         L = self.layers
         B = img.shape[0]
         cols, oh, ow = _im2col_root(img, L[0].cin)

@@ -1,19 +1,17 @@
 """One data-parallel training step of the instance path: forward -> losses -> backward (gradients land in the flat
 buffer) -> bucketed RCCL all-reduce overlapped with the rest of backward -> per-variable norm clip -> fused Adam.
 
-What it mirrors of the reference's training setup (core/trainer.py:58-81, builders/optimizer_builder.py:61-112,
-configs/monopsr_model_000.yaml:100-152): Adam at lr 8e-5, per-variable clip_by_norm(1.0) as
-slim.learning.create_train_op(clip_gradient_norm=1.0) applies it, loss = weighted sum of per-output losses.
-What it does not: exponential lr decay schedule bookkeeping, the EMA shadow variables, TF summaries, checkpoints.
-Losses here: Chamfer on the local xyz map (losses_custom.ChamferDistance) and smooth-L1 on lwh / centroid outputs
-(the reference's default regression loss type for those outputs).
+What it mirrors of the reference's training setup (core/trainer.py:58-81, builders/optimizer_builder.py:24-122,
+configs/monopsr_model_000.yaml:100-152): model.build() in 'train' mode -> model.loss() (the configured weighted sum
+of per-output losses) -> Adam with the exponential-decay learning rate and the parameter moving average ->
+per-variable clip_by_norm(1.0) as slim.learning.create_train_op(clip_gradient_norm=1.0) applies it.
+Not mirrored: TF summaries and the checkpoint schedule.
 """
 import torch
 import torch.distributed as dist
 
-from monopsr_amd.core import constants
-from monopsr_amd.core import losses_custom
-from monopsr_amd.core.models.monopsr import monopsr_output_builder
+from monopsr_amd.builders import optimizer_builder
+from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
 
 
 class ReverseBucketReducer:
@@ -66,16 +64,61 @@ class ReverseBucketReducer:
         self.reset()
 
 
-def smooth_l1(pred, target, delta=1.0):
-    d = (pred - target).abs()
-    return torch.where(d < delta, 0.5 * d * d, delta * (d - 0.5 * delta)).sum()
+def synthetic_ground_truth(sample, seed=0, num_alpha_bins=12, map_size=(48, 48)):
+    """Seeded synthetic labels for a `sample` of MonoPSRModel.build (benchmarks and tests; there is no dataset
+    reader in this package): 3-D boxes near the proposal geometry, angle-bin labels through the reference's
+    encoder, unit-scale local maps, a 70 % valid mask and a global map at the box position."""
+    import numpy as np
+    from monopsr_amd.core import orientation_encoder
+    dev = sample['boxes_2d'].device
+    B = sample['boxes_2d'].shape[0]
+    rng = np.random.default_rng(seed)
+    view = sample['est_view_angs'].reshape(-1).cpu().numpy().astype(np.float64)
+    z = rng.uniform(8, 40, B)
+    lwh = sample['mean_lwh'].cpu().numpy() + rng.normal(0, 0.1, (B, 3))
+    boxes_3d = np.zeros((B, 7), np.float32)
+    boxes_3d[:, 0], boxes_3d[:, 1], boxes_3d[:, 2] = z * np.tan(view), rng.uniform(1.2, 2.0, B), z
+    boxes_3d[:, 3:6] = lwh
+    alphas = rng.uniform(-np.pi, np.pi, B)
+    boxes_3d[:, 6] = alphas + view
+    enc = [orientation_encoder.np_orientation_to_angle_bin(a, num_alpha_bins, 0.0) for a in alphas]
+    h, w = map_size
+    xyz_local = rng.standard_normal((B, h, w, 3)).astype(np.float32)
+    cen = np.stack([boxes_3d[:, 0], boxes_3d[:, 1] - boxes_3d[:, 5] / 2, boxes_3d[:, 2]], 1).astype(np.float32)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    gt = dict(boxes_3d=t(boxes_3d), gt_alpha_bins=t([e[0] for e in enc], torch.int64),
+              gt_alpha_regs=t(np.stack([e[1] for e in enc])), gt_alpha_valid_bins=t(np.stack([e[2] for e in enc])),
+              gt_view_angs=t(view), gt_inst_xyz_maps_local=t(xyz_local),
+              gt_inst_xyz_maps_global=t(xyz_local + cen[:, None, None, :]),
+              gt_valid_mask_maps=t((rng.uniform(size=(B, h, w, 1)) > 0.3).astype(np.float32)))
+    return gt
+
+
+class _ConstantLr:
+    optimizer_type = 'adam_optimizer'
+
+    def __init__(self, lr):
+        self.adam_optimizer = self
+        self.learning_rate_type, self.learning_rate = 'constant_learning_rate', lr
+        self.use_moving_average = False
 
 
 class InstanceTrainer:
-    def __init__(self, net, model_config, dataset_config, group=None, lr=8e-5, clip_norm=1.0,
+    """sample keys for step(): those of MonoPSRModel.build (rgb_image_crops, full_img_feature_crop, boxes_2d, cam_p,
+    est_view_angs, class_indices, mean_lwh, prop_cen_z_offset) plus the ground truth the reference feeds through
+    placeholders: boxes_3d (B,7), gt_alpha_bins (B), gt_alpha_regs (B,nb), gt_alpha_valid_bins (B,nb),
+    gt_view_angs (B), gt_inst_xyz_maps_local / gt_inst_xyz_maps_global (B,h,w,3), gt_valid_mask_maps (B,h,w,1)."""
+
+    def __init__(self, net, model_config, dataset_config, train_config=None, group=None, lr=None, clip_norm=1.0,
                  bucket_bytes=64 << 20, classes_name='Car'):
         self.net, self.model_config, self.dataset_config = net, model_config, dataset_config
-        self.lr, self.clip_norm, self.classes_name = lr, clip_norm, classes_name
+        self.clip_norm, self.classes_name = clip_norm, classes_name
+        self.model = MonoPSRModel(model_config, dataset_config, net, 'train', classes_name, fused_heads=False)
+        if lr is not None or train_config is None:
+            self.optimizer = optimizer_builder.build(_ConstantLr(8e-5 if lr is None else lr))
+        else:
+            self.optimizer = optimizer_builder.build(train_config.optimizer)
+        self.global_step = 0
         spans = []
         for L in net.layers:
             lo = L.w.data_ptr() - net.params.data_ptr()
@@ -84,49 +127,14 @@ class InstanceTrainer:
         self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group)
         for li, L in enumerate(net.layers):
             L.on_grad_ready = (lambda i=li: self.reducer.layer_ready(i))
-        self.chamfer = losses_custom.ChamferDistance()
 
     def forward(self, sample):
-        net = self.net
-        feat = net.trunk(sample['rgb_image_crops'])
-        feat_box, feat_map, xyz = net.squash_decoder(feat, sample['full_img_feature_crop'],
-                                                     tuple(self.model_config.map_roi_size))
-        features = {constants.FEATURES_FOR_MAP: feat_map, constants.FEATURES_FOR_BOX_3D: feat_box,
-                    '_' + constants.KEY_INST_XYZ_MAP_LOCAL: xyz}
-        B = feat_box.shape[0]
-        b = monopsr_output_builder.MonoPSROutputBuilder(
-            self.model_config.output_config, self.model_config, self.dataset_config, features, B,
-            self.model_config.map_roi_size, sample['cam_p'].reshape(3, 4), train_val_test='test', device_net=net)
-        out = b.get_output_dict()
-        view = sample['est_view_angs'].reshape(-1, 1)
-        shape = list(self.model_config.image_input_shape)
-        b.add_inst_xyz_maps_local(None)
-        b.add_proposal_fc_features(sample['boxes_2d'], view, sample['class_indices'], shape)
-        f = b.get_proposal_fc_features()
-        b.add_lwh_output(f, sample['mean_lwh'], None)
-        b.add_alpha_output(f, None, None)
-        b.add_view_ang_output(constants.KEY_VIEW_ANG, f, view, None)
-        pz = b.get_prop_cen_z(sample['boxes_2d'], sample['prop_cen_z_offset'])
-        py = b.get_prop_cen_y(sample['boxes_2d'], pz, self.classes_name)
-        b.add_regression_fc_features(sample['boxes_2d'], view, sample['class_indices'], shape,
-                                     out[constants.KEY_LWH + '_offs'], out[constants.KEY_ALPHA_BINS],
-                                     out[constants.KEY_ALPHA_REGS], py, pz,
-                                     self.dataset_config.obj_filter_config.depth_range[1])
-        r = b.get_regression_fc_features()
-        b.add_cen_y_output(constants.KEY_CEN_Y, r, py, None)
-        b.add_cen_z_output(constants.KEY_CEN_Z, r, pz, None)
-        b.add_cen_x_output(constants.KEY_CEN_X, out[constants.KEY_CEN_Z], out[constants.KEY_VIEW_ANG])
-        b.add_centroids_output(constants.KEY_CENTROIDS, out[constants.KEY_CEN_X], out[constants.KEY_CEN_Y],
-                               out[constants.KEY_CEN_Z], None)
-        return b.get_output()
+        out, _ = self.model.build(sample)
+        return out
 
-    def loss(self, out, gt):
-        """gt: 'xyz' (B,h,w,3), 'mask' (B,h,w,1), 'lwh' (B,3), 'centroids' (B,3)."""
-        B = out[constants.KEY_LWH].shape[0]
-        total = self.chamfer(out[constants.KEY_INST_XYZ_MAP_LOCAL], gt['xyz'], gt['mask'])
-        total = total + smooth_l1(out[constants.KEY_LWH], gt['lwh']) / B
-        total = total + 0.1 * smooth_l1(out[constants.KEY_CENTROIDS], gt['centroids']) / B
-        return total
+    def loss(self, out, sample):
+        """-> (losses_dict, total_loss) of monopsr_model.py:554-958 for the outputs just built."""
+        return self.model.loss(out, self.model.gt_dict, sample.get('gt_alpha_valid_bins'))
 
     def clip_per_variable(self):
         """tf.clip_by_norm(g, clip_norm) per variable (weights and biases separately), on the reduced gradients."""
@@ -139,13 +147,14 @@ class InstanceTrainer:
                 t.mul_(torch.clamp(self.clip_norm / (n + 1e-30), max=1.0))
         return g
 
-    def step(self, sample, gt):
+    def step(self, sample):
         self.net.zero_grad()
         out = self.forward(sample)
-        loss = self.loss(out, gt)
+        self.losses_dict, loss = self.loss(out, sample)
         loss.backward()
         self.reducer.finish(average=True)
         if self.clip_norm:
             self.clip_per_variable()
-        self.net.adam_step(lr=self.lr)
+        self.optimizer.apply_gradients(self.net, self.global_step)
+        self.global_step += 1
         return loss.detach()

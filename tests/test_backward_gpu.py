@@ -242,14 +242,14 @@ def test_network_training_gradients_end_to_end():
 
 def test_instance_trainer_step_reduces_loss():
     """Full training step on a 1/4-width copy: heads included (method-by-method output builder over differentiable
-    FC layers), Chamfer + smooth-L1 losses, per-variable clip, Adam; the loss must go down on a fixed batch and
-    every layer must have received a gradient."""
+    FC layers), the reference's configured loss set (monopsr_model.py:554-958), per-variable clip, Adam; the loss
+    must go down on a fixed batch and every layer must have received a gradient."""
     from monopsr_amd.core import config_utils, train_net, trainer
     from monopsr_amd.core import weights as W
     B, div = 4, 4
     cfg = config_utils.default_config()
     net = train_net.TrainNet(W.synthetic_weights(seed=61, width_div=div), width_div=div)
-    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, lr=1e-3)
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, lr=1e-4)
     rng = np.random.default_rng(62)
     y1, x1 = rng.uniform(0, 150, B), rng.uniform(0, 1000, B)
     boxes = np.stack([y1, x1, y1 + rng.uniform(20, 200, B), x1 + rng.uniform(20, 200, B)], 1).astype(np.float32)
@@ -262,16 +262,15 @@ def test_instance_trainer_step_reduces_loss():
                   class_indices=torch.ones((B, 1), dtype=torch.int32, device="cuda"),
                   mean_lwh=_dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
                   prop_cen_z_offset=torch.full((B,), 2.178, device="cuda"))
-    gt = dict(xyz=_dev(rng.standard_normal((B, 48, 48, 3)).astype(np.float32)),
-              mask=_dev((rng.uniform(size=(B, 48, 48, 1)) > 0.3).astype(np.float32)),
-              lwh=_dev(np.tile(np.array([[4.0, 1.7, 1.5]], np.float32), (B, 1))),
-              centroids=_dev(rng.standard_normal((B, 3)).astype(np.float32) * 5))
-    losses = [float(tr.step(sample, gt)) for _ in range(6)]
+    sample.update(trainer.synthetic_ground_truth(sample, seed=63))
+    losses = [float(tr.step(sample)) for _ in range(8)]
     assert np.isfinite(losses).all()
-    assert losses[-1] < losses[0], losses
+    assert min(losses[-3:]) < 0.9 * losses[0], losses
+    assert set(tr.losses_dict) == {"inst_xyz_map_local", "lwh_offs", "alpha_bins", "alpha_regs", "cen_z_offs",
+                                   "cen_y_offs", "proj_err", "inst_depth_map_global"}
     # one more backward without the optimizer: every layer's weight gradient is populated
     net.zero_grad()
-    tr.loss(tr.forward(sample), gt).backward()
+    tr.loss(tr.forward(sample), sample)[1].backward()
     tr.reducer.finish()
     empty = [i for i, L in enumerate(net.layers) if float(L.dw.abs().max()) == 0.0]
     assert not empty, empty

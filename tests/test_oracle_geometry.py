@@ -1,0 +1,212 @@
+"""Pins oracle/geometry.py and oracle/losses.py to the golden vectors the reference's own tests hold (re-expressed here;
+each test names the reference test it mirrors), and cross-checks the unpinned functions against closed forms."""
+import math
+
+import numpy as np
+
+from oracle import geometry as G
+from oracle import losses as L
+
+
+# ------------------------------------------------------------------- instance_utils_test.py / transform_utils_test.py
+
+def test_get_proj_uv_map_pixel_centres():
+    """instance_utils_test.py:12-25 -- the test's comment and expected values are the pixel-centre grid."""
+    uv = G.get_exp_proj_uv_map(np.asarray([0, 10, 10, 20], np.float32), (10, 10), use_pixel_centres=True)
+    np.testing.assert_allclose(uv[0, :, 0], np.linspace(10.5, 19.5, 10))
+    np.testing.assert_allclose(uv[:, 0, 1], np.linspace(0.5, 9.5, 10))
+
+
+def test_tf_get_proj_uv_map_equals_numpy_form():
+    """instance_utils_test.py:27-50."""
+    boxes = np.asarray([[0.0, 10.0, 10.0, 20.0], [5.0, 5.0, 10.0, 10.0], [0.0, 0.0, 100.0, 100.0]], np.float32)
+    want = [G.get_exp_proj_uv_map(b, (10, 10), use_pixel_centres=True) for b in boxes]
+    np.testing.assert_allclose(G.tf_get_exp_proj_uv_map(boxes, (10, 10)), want, rtol=1e-6)
+
+
+def test_map_local_to_global_equals_point_form():
+    """instance_utils_test.py:52-73."""
+    pts = np.random.default_rng(0).random((2304, 3)).astype(np.float32)
+    va, cen = np.float32(np.deg2rad(10.0)), np.asarray([2.5, 1.5, 15.0], np.float32)
+    want = G.inst_points_local_to_global(pts, va, cen)
+    got = G.inst_xyz_map_local_to_global(pts.reshape(1, 48, 48, 3), [[va]], cen.reshape(1, 3))
+    np.testing.assert_allclose(got.reshape(2304, 3), want, rtol=1e-6)
+    # closed form: x' = c x + s z + tx, z' = -s x + c z + tz
+    c, s = math.cos(va), math.sin(va)
+    np.testing.assert_allclose(want[:, 0], c * pts[:, 0] + s * pts[:, 2] + 2.5, rtol=1e-6)
+    np.testing.assert_allclose(want[:, 2], -s * pts[:, 0] + c * pts[:, 2] + 15.0, rtol=1e-6)
+
+
+def test_tr_mat_conventions():
+    """transform_utils_test.py:9-37 and :78-..: identity, translation column, R_y(90)."""
+    rot, tm = G.get_tr_mat_batch([0.0], [[2.0, 4.0, 6.0]], np.float64)
+    np.testing.assert_allclose(rot[0], np.eye(4))
+    exp = np.eye(4)
+    exp[0:3, 3] = [2.0, 4.0, 6.0]
+    np.testing.assert_allclose(tm[0], exp)
+    rot, _ = G.get_tr_mat_batch([np.deg2rad(90.0)], [[0, 0, 0]], np.float64)
+    np.testing.assert_allclose(rot[0, :3, :3], [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------ orientation_encoder_test.py
+
+def test_wrap_to_pi():
+    """orientation_encoder_test.py:9-20."""
+    deg = np.asarray([-360, -185, -175, -90, 0, 90, 175, 185, 360])
+    exp = np.deg2rad(np.asarray([0, 175, -175, -90, 0, 90, 175, -175, 0]))
+    np.testing.assert_allclose(G.wrap_to_pi(np.deg2rad(deg)), exp, atol=1e-12)
+
+
+def test_orientation_to_angle_bin_centres_and_residuals():
+    """orientation_encoder_test.py:22-90 (8 bins: centres give residual 0; +-1 degree gives +-1 degree)."""
+    centres = np.deg2rad([-180.0, -135.0, -90.0, -45.0, 0.0, 45.0, 90.0, 135.0, 180.0])
+    bins, res = [], []
+    for o in centres:
+        b, r, oh = G.orientation_to_angle_bin(o, 8)
+        bins.append(b)
+        res.append(r[np.argmax(oh)])
+    assert bins == [4, 5, 6, 7, 0, 1, 2, 3, 4]
+    np.testing.assert_allclose(res, 0, atol=1e-12)
+    angs = np.deg2rad([-181, -179, -136, -134, -91, -89, -46, -44, -1, 1, 44, 46, 89, 91, 134, 136, 179, 181])
+    bins, res = [], []
+    for o in angs:
+        b, r, oh = G.orientation_to_angle_bin(o, 8)
+        bins.append(b)
+        res.append(r[np.argmax(oh)])
+    assert bins == [4, 4, 5, 5, 6, 6, 7, 7, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+    np.testing.assert_allclose(res, np.deg2rad([-1.0, 1.0] * 9), atol=1e-9)
+
+
+def test_angle_bin_round_trip():
+    rng = np.random.default_rng(3)
+    for o in rng.uniform(-math.pi, math.pi, 200):
+        b, r, _ = G.orientation_to_angle_bin(o, 12)
+        back = G.angle_bin_to_orientation(b, r[b], 12)
+        assert abs(math.remainder(back - o, 2 * math.pi)) < 1e-9 and -math.pi - 1e-9 <= back <= math.pi + 1e-9
+
+
+# --------------------------------------------------------------------------- unpinned geometry: closed-form checks
+
+P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]])
+
+
+def test_projection_of_the_ideal_cloud_has_zero_error():
+    """A cloud built by back-projecting the expected pixel-centre grid at any depth projects back onto it."""
+    boxes = np.array([[100.0, 300.0, 180.0, 420.0], [150.0, 700.0, 260.0, 900.0]], np.float32)
+    exp_uv = G.tf_get_exp_proj_uv_map(boxes, (48, 48), np.float64)
+    z = np.random.default_rng(0).uniform(8, 30, (2, 48, 48))
+    # solve P [x y z 1]^T ~ (u, v): with P[2] = [0 0 1 t3]
+    w = z + P2[2, 3]
+    x = (exp_uv[..., 0] * w - P2[0, 2] * z - P2[0, 3]) / P2[0, 0]
+    y = (exp_uv[..., 1] * w - P2[1, 2] * z - P2[1, 3]) / P2[1, 1]
+    xyz = np.stack([x, y, z], -1)
+    mask = np.ones((2, 48, 48, 1))
+    norm, maps = G.proj_err_maps_norm(xyz, boxes, P2, mask, np.float64)
+    np.testing.assert_allclose(maps, 0, atol=1e-9)
+    np.testing.assert_allclose(norm, 0, atol=1e-9)
+    # a one-pixel shift in u is an error of -1/box_w per valid pixel (summed over both channels / valid pixels)
+    xyz[..., 0] += w / P2[0, 0]
+    norm, _ = G.proj_err_maps_norm(xyz, boxes, P2, mask, np.float64)
+    np.testing.assert_allclose(norm, -1.0 / (boxes[:, 3] - boxes[:, 1]).astype(np.float64), rtol=1e-9)
+    # clipping and the empty mask
+    xyz[..., 0] += 1e4
+    norm, maps = G.proj_err_maps_norm(xyz, boxes, P2, mask, np.float64)
+    assert maps.min() == -2.0
+    norm, _ = G.proj_err_maps_norm(xyz, boxes, P2, np.zeros_like(mask), np.float64)
+    np.testing.assert_array_equal(norm, 0)
+
+
+def test_depth_map_global_offsets():
+    boxes = np.array([[100.0, 300.0, 180.0, 420.0], [150.0, 700.0, 260.0, 900.0]], np.float32)
+    d = np.random.default_rng(1).standard_normal((2, 48, 48, 1)).astype(np.float32)
+    z = np.array([[12.0], [30.0]], np.float32)
+    va = np.array([[-0.3], [0.2]], np.float32)
+    plain = G.inst_depth_map_local_to_global(d, z, boxes, va, P2, rotate_view=False)
+    np.testing.assert_allclose(plain, d + z.reshape(2, 1, 1, 1))
+    rot = G.inst_depth_map_local_to_global(d, z, boxes, va, P2, rotate_view=True, dtype=np.float64)
+    off = rot - (d + z.reshape(2, 1, 1, 1))
+    assert np.ptp(off, axis=2).max() < 1e-5            # constant along columns, varies along rows (the reference's layout)
+    # closed form of an edge offset: -z tan(va) tan(theta - va), linear in z
+    x1 = boxes[:, 1] + (boxes[:, 3] - boxes[:, 1]) / 48 / 2
+    th = np.arctan2((x1 - P2[0, 2]) / P2[0, 0], 1.0)
+    np.testing.assert_allclose(off[:, 0, 0, 0], -z[:, 0] * np.tan(va[:, 0]) * np.tan(th - va[:, 0]), rtol=1e-5)
+    # a box seen straight on (va = 0) gets no offset
+    rot0 = G.inst_depth_map_local_to_global(d, z, boxes, np.zeros((2, 1), np.float32), P2, rotate_view=True)
+    np.testing.assert_allclose(rot0, plain, atol=1e-6)
+
+
+def test_box_corners_and_projection():
+    c = G.compute_box_3d_corners([1.0, 2.0, 10.0, 4.0, 2.0, 1.5, 0.0])
+    np.testing.assert_allclose(c[:, 0], [3.0, 2.0, 11.0])
+    np.testing.assert_allclose(c[:, 6], [-1.0, 0.5, 9.0])
+    c90 = G.compute_box_3d_corners([0.0, 0.0, 10.0, 4.0, 2.0, 1.5, np.pi / 2])
+    np.testing.assert_allclose(c90[:, 0], [1.0, 0.0, 8.0], atol=1e-12)   # +x of the box points to -z at ry = 90 deg
+    box = G.project_to_image_space([0.0, 1.5, 20.0, 4.0, 1.6, 1.5, 0.3], P2, (1242, 375))
+    assert box is not None and 0 <= box[0] < box[2] <= 1242 and 0 <= box[1] < box[3] <= 375
+    assert G.project_to_image_space([0.0, 1.5, 2.0, 4.0, 1.6, 1.5, 0.0], P2, (1242, 375)) is None   # > 80 % of the image
+    assert G.project_to_image_space([200.0, 1.5, 20.0, 4.0, 1.6, 1.5, 0.0], P2, (1242, 375)) is None  # off-image
+
+
+def test_postprocess_cen_x_is_a_fixed_point_for_a_consistent_box():
+    """If the 2-D box IS the projection of the 3-D box, the post-processed x equals the x the projection implies."""
+    b3 = np.array([2.0, 1.6, 18.0, 3.9, 1.6, 1.5, 0.4])
+    uv = G.project_pc_to_image(G.compute_box_3d_corners(b3), P2)
+    b2 = np.array([uv[1].min(), uv[0].min(), uv[1].max(), uv[0].max()])
+    x = G.postprocess_cen_x(b2, b3, P2)
+    cen_u = G.project_pc_to_image(b3[:3].reshape(3, 1), P2)[0, 0]
+    np.testing.assert_allclose(x, (cen_u - P2[0, 2]) * b3[2] / P2[0, 0], rtol=1e-12)
+    s = G.score_boxes((375, 1242), [b2], [b3], [0.8], P2)
+    np.testing.assert_allclose(s, 0.95 * 0.8 + 0.05 * ((1 - 18.0 / 45) + 1.0) / 2, rtol=1e-9)
+
+
+def test_format_predictions_layout():
+    rng = np.random.default_rng(5)
+    n = 4
+    boxes = np.array([[150.0, 500.0, 220.0, 620.0]] * n) + rng.uniform(-5, 5, (n, 4))
+    lwh = np.tile([3.9, 1.6, 1.5], (n, 1))
+    cen = np.tile([-1.0, 1.0, 20.0], (n, 1)) + rng.uniform(-0.2, 0.2, (n, 3))
+    bins, regs = rng.standard_normal((n, 12)), rng.uniform(-0.2, 0.2, (n, 12))
+    view = np.arctan2(cen[:, 0], cen[:, 2]).reshape(n, 1)
+    b3, b2 = G.format_predictions(lwh, view, bins, regs, cen, boxes, np.full(n, 0.9), np.ones((n, 1)), P2, (375, 1242))
+    assert b3.shape == (n, 9) and b2.shape == (n, 7)
+    np.testing.assert_allclose(b3[:, 1], cen[:, 1] + 0.75)              # 'middle' centroid -> bottom face
+    np.testing.assert_allclose(b3[:, 6] - view[:, 0], b2[:, 4])         # ry = alpha + viewing angle
+    np.testing.assert_array_equal(b3[:, 8], 0)
+    np.testing.assert_array_equal(b2[:, :4], boxes)
+
+
+# ------------------------------------------------------------------------------ object_detection/core/losses_test.py
+
+def test_weighted_smooth_l1_known_answer():
+    """losses_test.py:87-107 -> 7.695."""
+    pred = np.array([[[2.5, 0, .4, 0], [0, 0, 0, 0], [0, 2.5, 0, .4]], [[3.5, 0, 0, 0], [0, .4, 0, .9], [0, 0, 1.5, 0]]])
+    w = np.array([[2, 1, 1], [0, 3, 0]], np.float64)
+    np.testing.assert_allclose(L.weighted_smooth_l1(pred, np.zeros_like(pred), w).sum(), 7.695, rtol=1e-6)
+
+
+def test_weighted_softmax_known_answers():
+    """losses_test.py:490-544."""
+    pred = np.array([[[-100, 100, -100], [100, -100, -100], [0, 0, -100], [-100, -100, 100]],
+                     [[-100, 0, 0], [-100, 100, -100], [-100, 100, -100], [100, -100, -100]]], np.float64)
+    tgt = np.array([[[0, 1, 0], [1, 0, 0], [1, 0, 0], [0, 0, 1]], [[0, 0, 1], [0, 1, 0], [0, 1, 0], [1, 0, 0]]])
+    w = np.array([[1, 1, .5, 1], [1, 1, 1, 0]])
+    got = L.weighted_softmax(pred, tgt, w)
+    np.testing.assert_allclose(got.sum(), -1.5 * math.log(.5), rtol=1e-6)
+    np.testing.assert_allclose(got, [[0, 0, -0.5 * math.log(.5), 0], [-math.log(.5), 0, 0, 0]], atol=1e-6)
+
+
+def test_nonzero_smooth_l1_and_berhu_definitions():
+    rng = np.random.default_rng(7)
+    p, t = rng.standard_normal((2, 6, 6, 3)) * 2, rng.standard_normal((2, 6, 6, 3))
+    m = (rng.random((2, 6, 6, 1)) > 0.4).astype(np.float64)
+    e = np.abs(p - t)
+    per = np.where(e <= 1, 0.5 * e * e, e - 0.5)
+    np.testing.assert_allclose(L.weighted_nonzero_smooth_l1(p, t, m), (per * m).sum() / (3 * m.sum()), rtol=1e-12)
+    assert L.weighted_nonzero_smooth_l1(p, t, np.zeros_like(m)) == 0.0
+    th = e.max() / 5
+    per = np.where(e <= th, e, (e * e + th * th) / (2 * th))
+    mm = np.broadcast_to(m, p.shape)
+    np.testing.assert_allclose(L.weighted_berhu(p, t, mm), (per * mm).sum() / np.count_nonzero(mm), rtol=1e-12)
+    x, z = rng.standard_normal(50) * 5, rng.random(50)
+    s = 1 / (1 + np.exp(-x))
+    np.testing.assert_allclose(L.sigmoid_ce(x, z), -(z * np.log(s) + (1 - z) * np.log(1 - s)), rtol=1e-9)

@@ -40,25 +40,23 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cfg = config_utils.default_config()
     net = train_net.TrainNet(W.synthetic_weights(seed=0), device=dev)
-    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, clip_norm=0.0 if args.no_clip else 1.0)
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
+                                clip_norm=0.0 if args.no_clip else 1.0)
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
     B = args.batch
     sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
                   cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"], mean_lwh=inp["mean_lwh"],
                   prop_cen_z_offset=inp["z_off"])
-    g = torch.Generator(device=dev).manual_seed(7 + rank)
-    gt = dict(xyz=torch.randn((B, 48, 48, 3), device=dev, generator=g) * 2,
-              mask=(torch.rand((B, 48, 48, 1), device=dev, generator=g) > 0.3).float(),
-              lwh=inp["mean_lwh"] + 0.1, centroids=torch.randn((B, 3), device=dev, generator=g) * 5)
+    sample.update(trainer.synthetic_ground_truth(sample, seed=7 + rank))
     losses = []
     for _ in range(args.warmup):
-        losses.append(float(tr.step(sample, gt)))
+        losses.append(float(tr.step(sample)))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(tr.step(sample, gt))
+        losses.append(tr.step(sample))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
