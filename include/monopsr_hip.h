@@ -36,6 +36,10 @@ enum {
 const char *mpsr_last_error(void);
 /* ABI version, bumped on any signature change. */
 int mpsr_abi_version(void);
+/* CRC-32C (Castagnoli) of n bytes of HOST memory, continuing from `crc` (0 to start).  The checksum TensorFlow's
+ * checkpoint files carry (tensor_bundle block trailers and tensor payloads); used by core/tf_checkpoint.py, which
+ * replaces the tf.train.Saver restore of core/checkpoint_utils.py:64-117. */
+uint32_t mpsr_crc32c(uint32_t crc, const void *data, size_t n);
 
 /* ------------------------------------------------------------------------------------------------ Chamfer */
 

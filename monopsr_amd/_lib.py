@@ -51,6 +51,7 @@ class HeadOutputs(ctypes.Structure):
 SIGNATURES = {
     "mpsr_last_error": (ctypes.c_char_p, []),
     "mpsr_abi_version": (c_i, []),
+    "mpsr_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, c_sz]),
     "mpsr_nn_distance_fwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_approx_match_temp_floats": (c_sz, [c_i, c_i, c_i]),

@@ -1,9 +1,9 @@
 """Weight import for the instance path, honouring the reference's variable names
 (core/checkpoint_utils.py:64-117 and MonoPSRModel.get_variable_restore_map, monopsr_model.py:1230-1266).
 
-A TensorFlow checkpoint itself cannot be read here (TensorFlow is not installed), so the exchange format is a flat
-name -> array mapping (an .npz written by `tf.train.load_checkpoint(...).get_tensor(name)` on any machine that has
-TensorFlow, or a dict).  What this module reproduces is the reference's NAME LOGIC:
+Checkpoints come in as a flat name -> array mapping: read straight from a TensorFlow checkpoint
+(`load_checkpoint(prefix)` -> core/tf_checkpoint.py, no TensorFlow needed), from an .npz, or a dict.  What this
+module reproduces is the reference's NAME LOGIC:
 
   * Object-Detection-API checkpoints hold ONE trunk under `FirstStageFeatureExtractor/resnet_v1_101/...`; the
     reference restores it into BOTH of its trunks by rewriting `FirstStageFeatureExtractor_crop/` and
@@ -62,6 +62,30 @@ def restore_monopsr_weights(weights, checkpoint, strict_shapes=True):
             weights[name] = arr
             restored.append(name)
     return restored
+
+
+def load_checkpoint(path):
+    """name -> array from a TensorFlow V2 checkpoint (prefix, .index file or directory with a `checkpoint` state
+    file) or an .npz."""
+    if str(path).endswith(".npz"):
+        return load_npz(path)
+    from monopsr_amd.core import tf_checkpoint
+    return tf_checkpoint.read_checkpoint(path)
+
+
+def save_checkpoint(prefix, weights, global_step=None):
+    """Write `weights` (plus `global_step`) as a TensorFlow V2 checkpoint `<prefix>[-<global_step, 8 digits>]`, the
+    naming tf.train.Saver(pad_step_number=True) uses (core/trainer.py:86, :190-193), and update the directory's
+    `checkpoint` state file.  Returns the prefix written."""
+    import os
+    from monopsr_amd.core import tf_checkpoint
+    tensors = dict(weights)
+    if global_step is not None:
+        tensors["global_step"] = np.asarray(global_step, dtype=np.int64)
+        prefix = "%s-%08d" % (prefix, int(global_step))
+    tf_checkpoint.write_checkpoint(prefix, tensors)
+    tf_checkpoint.write_checkpoint_state(os.path.dirname(prefix) or ".", os.path.basename(prefix))
+    return prefix
 
 
 def load_npz(path):
