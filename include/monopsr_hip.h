@@ -125,9 +125,11 @@ int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols, int kpad,
 
 /* dW[n][(ky*KW+kx)*C + c] += sum over pixels of dy[pixel][n] * x[pixel + tap][c] (same geometry as
  * mpsr_conv2d_nhwc_f32).  x (B,H,W,C), dy (B,H,W,N), dw (N, KH*KW*C) must be zeroed by the caller (partial sums
- * from pixel slices are combined with fp32 atomics).  C % 4 == 0, N % 4 == 0. */
+ * from pixel slices are combined with fp32 atomics).  C % 4 == 0, N % 4 == 0.
+ * db (N) or NULL: the bias gradient db[n] += sum over pixels of dy[pixel][n] rides along (column sums of the dy
+ * tiles the kernel stages anyway; also pre-zeroed by the caller). */
 int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
-                          int dilation, float *dw, mpsr_stream_t stream);
+                          int dilation, float *dw, float *db, mpsr_stream_t stream);
 
 /* Weight re-layout for the data gradient: wd[c][((KH*KW-1-t)*N) + n] = w[n][t*C + c].  Then
  * dx = mpsr_conv2d_nhwc_f32(dy, ..., w = wd, N := C, C := N) with the same KH, KW, dilation. */

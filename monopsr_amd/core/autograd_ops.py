@@ -50,24 +50,27 @@ class Conv2dFn(torch.autograd.Function):
         B, H, W, C = x.shape
         N = L.cout
         s = _lib.stream()
-        if L.relu or L.db is not None:
-            # one pass: ReLU mask (when the layer has one) + bias gradient (when it has a bias)
-            gm = torch.empty_like(g) if L.relu else None
-            _lib.check(lib.mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y) if L.relu else None, _lib.ptr(gm),
-                                              _lib.ptr(L.db), B * H * W, N, s))
-            if L.relu:
-                g = gm
+        if L.relu:
+            # ReLU mask in one streaming pass; the bias gradient rides in the weight-gradient kernel below
+            gm = torch.empty_like(g)
+            _lib.check(lib.mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), None, B * H * W, N, s))
+            g = gm
         # the kernels read rows of N floats with 16-byte loads: pad a narrow output (the 3-channel xyz head) to 4
         pad = (-N) % 4
         g4 = F.pad(g, (0, pad)) if pad else g
         N4 = N + pad
+        db4 = L.db
         if pad:
             dw4 = torch.zeros((N4, L.w.shape[1]), dtype=torch.float32, device=x.device)
             w4 = F.pad(L.w, (0, 0, 0, pad))
+            if L.db is not None:
+                db4 = torch.zeros((N4,), dtype=torch.float32, device=x.device)
         else:
             dw4, w4 = L.dw, L.w
         _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
-                                             _lib.ptr(dw4), s))
+                                             _lib.ptr(dw4), _lib.ptr(db4), s))
+        if pad and L.db is not None:
+            L.db.add_(db4[:N])
         if pad:
             L.dw.add_(dw4[:N])
         ready = getattr(L, "on_grad_ready", None)

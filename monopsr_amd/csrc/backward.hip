@@ -27,6 +27,7 @@ struct WgradParams {
     const float *x;
     const float *dy;
     float *dw;
+    float *db;  // optional bias gradient: db[n] += sum over pixels of dy[pixel][n]
     int M, H, W, C, N, KH, KW, dil;
     int ntile_n, ntile_c, msteps_total, msteps_per_split, splits;
     unsigned xbytes, dybytes;
@@ -91,7 +92,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     };
     const float *Aw = At + (lane >> 5) * 4 * WG_T + wm * 64 + (lane & 31);
     const float *Bw = Bt + (lane >> 5) * 4 * WG_T + wn * 64 + (lane & 31);
+    // bias gradient = column sums of the dy tile, taken by the workgroups of tap 0 / channel tile 0 (they see every
+    // pixel of their slice exactly once): thread t < 128 owns column n0 + t
+    const bool do_db = p.db != nullptr && tap == 0 && tc == 0 && tid < WG_T;
+    float colsum = 0.f;
     auto compute_tile = [&]() {
+        if (do_db) {
+#pragma unroll
+            for (int k = 0; k < WG_K; ++k) colsum += At[k * WG_T + tid];
+        }
 #pragma unroll
         for (int kb = 0; kb < WG_K / 8; ++kb)
 #pragma unroll
@@ -122,6 +131,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
 
+    if (do_db && n0 + tid < p.N) unsafeAtomicAdd(&p.db[n0 + tid], colsum);
     const int Ktot = p.KH * p.KW * p.C;
     const int col = lane & 31, rsub = (lane >> 5) * 4;
 #pragma unroll
@@ -301,7 +311,7 @@ inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144
 }  // namespace
 
 extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
-                                     int dilation, float *dw, mpsr_stream_t stream)
+                                     int dilation, float *dw, float *db, mpsr_stream_t stream)
 {
     MPSR_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && (KH & 1) && (KW & 1) && dilation >= 1,
                  "conv2d_wgrad: bad shape");
@@ -311,7 +321,7 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     const long long M = (long long)B * H * W;
     MPSR_REQUIRE(M * C * 4 < 0xfffffff0LL && M * N * 4 < 0xfffffff0LL, "conv2d_wgrad: tensor exceeds 4 GiB");
     WgradParams p;
-    p.x = x; p.dy = dy; p.dw = dw;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.M = (int)M; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation;
     p.xbytes = (unsigned)(M * C * 4);
     p.dybytes = (unsigned)(M * N * 4);
