@@ -160,6 +160,15 @@ int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int O
 int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream);
 
+/* tf.clip_by_norm applied to every variable of a flat gradient buffer separately, as
+ * slim.learning.create_train_op(clip_gradient_norm=1.0) does (core/trainer.py:78-81): g *= clip / max(||g||, clip).
+ * The caller describes the variables once as a chunk table (device arrays): chunk i covers
+ * grads[chunk_begin[i] .. +chunk_len[i]) and belongs to variable chunk_seg[i] in [0, n_segments).
+ * sumsq: n_segments floats of scratch (holds each variable's squared norm on return). */
+int mpsr_clip_by_norm_segments(float *grads, const int *chunk_seg, const long long *chunk_begin,
+                               const int *chunk_len, int n_chunks, float *sumsq, int n_segments, float clip_norm,
+                               mpsr_stream_t stream);
+
 /* ------------------------------------------------------------------------- per-box geometry and map losses
  * SURVEY.md 8(f) rows 3-4.  Maps are (b, h, w, c) row-major; p = h*w points per instance. */
 

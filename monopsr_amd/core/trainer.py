@@ -10,6 +10,7 @@ Not mirrored: TF summaries and the checkpoint schedule.
 import torch
 import torch.distributed as dist
 
+from monopsr_amd import _lib
 from monopsr_amd.builders import optimizer_builder
 from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
 
@@ -119,6 +120,7 @@ class InstanceTrainer:
         else:
             self.optimizer = optimizer_builder.build(train_config.optimizer)
         self.global_step = 0
+        self._clip = None
         spans = []
         for L in net.layers:
             lo = L.w.data_ptr() - net.params.data_ptr()
@@ -136,16 +138,36 @@ class InstanceTrainer:
         """-> (losses_dict, total_loss) of monopsr_model.py:554-958 for the outputs just built."""
         return self.model.loss(out, self.model.gt_dict, sample.get('gt_alpha_valid_bins'))
 
-    def clip_per_variable(self):
-        """tf.clip_by_norm(g, clip_norm) per variable (weights and biases separately), on the reduced gradients."""
-        g = self.net.grads
+    def _clip_table(self, chunk=16384):
+        """Chunk table of mpsr_clip_by_norm_segments: every weight / bias gradient is one variable."""
+        base = self.net.grads.data_ptr()
+        seg, begin, length = [], [], []
+        nseg = 0
         for L in self.net.layers:
             for t in (L.dw, L.db):
                 if t is None:
                     continue
-                n = torch.linalg.vector_norm(t)
-                t.mul_(torch.clamp(self.clip_norm / (n + 1e-30), max=1.0))
-        return g
+                lo, n = (t.data_ptr() - base) // 4, t.numel()
+                for o in range(0, n, chunk):
+                    seg.append(nseg)
+                    begin.append(lo + o)
+                    length.append(min(chunk, n - o))
+                nseg += 1
+        dev = self.net.grads.device
+        return (torch.tensor(seg, dtype=torch.int32, device=dev), torch.tensor(begin, dtype=torch.int64, device=dev),
+                torch.tensor(length, dtype=torch.int32, device=dev),
+                torch.empty((nseg,), dtype=torch.float32, device=dev))
+
+    def clip_per_variable(self):
+        """tf.clip_by_norm(g, clip_norm) per variable (weights and biases separately), on the reduced gradients:
+        two launches over the flat buffer."""
+        if self._clip is None:
+            self._clip = self._clip_table()
+        seg, begin, length, sumsq = self._clip
+        _lib.check(_lib.lib().mpsr_clip_by_norm_segments(
+            _lib.ptr(self.net.grads), _lib.ptr(seg), _lib.ptr(begin), _lib.ptr(length), seg.numel(), _lib.ptr(sumsq),
+            sumsq.numel(), float(self.clip_norm), _lib.stream()))
+        return self.net.grads
 
     def step(self, sample):
         self.net.zero_grad()

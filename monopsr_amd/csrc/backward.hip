@@ -29,24 +29,48 @@ struct WgradParams {
     float *dw;
     float *db;  // optional bias gradient: db[n] += sum over pixels of dy[pixel][n]
     int M, H, W, C, N, KH, KW, dil;
-    int ntile_n, ntile_c, msteps_total, msteps_per_split, splits;
+    int ntile_n, ntile_c, splits;
+    // pixel slices per tap (proportional to the tap's valid pixels) and the cumulative workgroup count; used when
+    // the kernel has at most MAX_TAPS taps, otherwise every tap gets `splits` slices
+    int per_tap, tap_splits[9], tap_end[9];
     unsigned xbytes, dybytes;
 };
+constexpr int MAX_TAPS = 9;
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(16))) float At[WG_K * WG_T];  // [pixel][n]
     __shared__ __attribute__((aligned(16))) float Bt[WG_K * WG_T];  // [pixel][c]
     int t = blockIdx.x;
+    int tap, si, nsplit;
+    if (p.per_tap) {
+        tap = 0;
+        while (t >= p.tap_end[tap]) ++tap;
+        if (tap > 0) t -= p.tap_end[tap - 1];
+        nsplit = p.tap_splits[tap];
+    } else {
+        tap = t % (p.KH * p.KW);
+        t /= p.KH * p.KW;
+        nsplit = p.splits;
+    }
     const int tn = t % p.ntile_n; t /= p.ntile_n;
     const int tc = t % p.ntile_c; t /= p.ntile_c;
-    const int tap = t % (p.KH * p.KW);
-    const int si = t / (p.KH * p.KW);
+    si = t;
     const int n0 = tn * WG_T, c0 = tc * WG_T;
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const int dyo = (ky - (p.KH >> 1)) * p.dil, dxo = (kx - (p.KW >> 1)) * p.dil;
-    const int ms_begin = si * p.msteps_per_split;
-    const int ms_end = min(p.msteps_total, ms_begin + p.msteps_per_split);
+    // Only pixels whose shifted partner (y + dyo, x + dxo) lies inside the image contribute to this tap: enumerate
+    // that sub-rectangle of every image instead of all pixels (a 3x3 tap at dilation 4 on a 12x12 map touches 44-67 %
+    // of them), and split ITS steps over the tap's `nsplit` pixel slices.
+    const int ylo = max(0, -dyo), xlo = max(0, -dxo);
+    const int hv = p.H - max(0, dyo) - ylo, wv = p.W - max(0, dxo) - xlo;
+    if (hv <= 0 || wv <= 0) return;
+    const int HWv = hv * wv;
+    const int Mv = (p.M / (p.H * p.W)) * HWv;
+    const int msteps_tap = (Mv + WG_K - 1) / WG_K;
+    const int per_split = (msteps_tap + nsplit - 1) / nsplit;
+    const int ms_begin = si * per_split;
+    const int ms_end = min(msteps_tap, ms_begin + per_split);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -71,15 +95,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     auto load_tile = [&](int ms) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = ms * WG_K + lrow + 8 * j;
-            const bool mok = m < p.M;
+            const int mv = ms * WG_K + lrow + 8 * j;  // index into the tap's valid pixels
+            const bool mok = mv < Mv;
+            const int img = mv / HWv, r = mv - img * HWv;
+            const int ry = r / wv;
+            const int m = img * HW + (ylo + ry) * p.W + xlo + (r - ry * wv);  // the pixel itself
             const unsigned offa = (mok && nok) ? ((unsigned)m * (unsigned)p.N + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
             ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa, 0, 0));
-            const int pix = mok ? m % HW : 0;
-            const int yy = pix / p.W + dyo, xx = pix % p.W + dxo;
-            const bool ok = mok && cok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            const unsigned offb =
-                ok ? ((unsigned)(m + dyo * p.W + dxo) * (unsigned)p.C + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
+            const unsigned offb = (mok && cok)
+                ? ((unsigned)(m + dyo * p.W + dxo) * (unsigned)p.C + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
             rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb, 0, 0));
         }
     };
@@ -92,9 +116,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     };
     const float *Aw = At + (lane >> 5) * 4 * WG_T + wm * 64 + (lane & 31);
     const float *Bw = Bt + (lane >> 5) * 4 * WG_T + wn * 64 + (lane & 31);
-    // bias gradient = column sums of the dy tile, taken by the workgroups of tap 0 / channel tile 0 (they see every
-    // pixel of their slice exactly once): thread t < 128 owns column n0 + t
-    const bool do_db = p.db != nullptr && tap == 0 && tc == 0 && tid < WG_T;
+    // bias gradient = column sums of the dy tile, taken by the workgroups of the CENTRE tap / channel tile 0 (they see
+    // every pixel exactly once): thread t < 128 owns column n0 + t
+    const bool do_db = p.db != nullptr && tap == (p.KH * p.KW) / 2 && tc == 0 && tid < WG_T;
     float colsum = 0.f;
     auto compute_tile = [&]() {
         if (do_db) {
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             }
     };
 
-    if (ms_begin >= ms_end) return;
+    if (ms_begin >= ms_end) return;  // uniform over the workgroup
     load_tile(ms_begin);
     store_tile();
     __syncthreads();
@@ -264,7 +288,68 @@ __global__ __launch_bounds__(256) void max_pool_grad_kernel(const float *__restr
     }
 }
 
-// bilinear-resize gradient (TF-1.8 kernel geometry): scatter each output gradient to its 4 source pixels
+// bilinear-resize gradient (TF-1.8 kernel geometry) in GATHER form: a thread owns one float4 of dx and sums the output
+// gradients that read it.  Along each axis output o reads inputs i0 = floor(o*scale) (weight 1-l) and
+// i1 = min(i0+1, I-1) (weight l); the candidates for input i are the o with o*scale in (i-1, i+1), found by scanning
+// a slightly wider window and re-evaluating the forward's own float expressions (so the weights match it exactly).
+// No atomics: deterministic, and dx needs no pre-zeroing.
+constexpr int RG_MAX = 12;  // candidates kept per axis; the host falls back to the scatter kernel beyond that
+
+__device__ __forceinline__ int resize_axis_taps(int i, int I, int O, float scale, int *os, float *ws)
+{
+    const float inv = 1.0f / scale;
+    int lo = (int)floorf((float)(i - 1) * inv) - 1, hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    lo = max(lo, 0);
+    hi = min(hi, O - 1);
+    int n = 0;
+    for (int o = lo; o <= hi; ++o) {
+        const float sp = (float)o * scale;
+        const int i0 = (int)floorf(sp);
+        const int i1 = min(i0 + 1, I - 1);
+        const float l = sp - (float)i0;
+        const float w = (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+        if (w != 0.f && n < RG_MAX) {
+            os[n] = o;
+            ws[n] = w;
+            ++n;
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_grad_gather_kernel(const float *__restrict__ dy, int H, int W,
+                                                                          int C4, int OH, int OW, float hscale,
+                                                                          float wscale, float *__restrict__ dx,
+                                                                          long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        int oys[RG_MAX], oxs[RG_MAX];
+        float wys[RG_MAX], wxs[RG_MAX];
+        const int ny = resize_axis_taps(iy, H, OH, hscale, oys, wys);
+        const int nx = resize_axis_taps(ix, W, OW, wscale, oxs, wxs);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 *src = reinterpret_cast<const float4 *>(dy) + (size_t)b * OH * OW * C4 + c;
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e) {
+                const float4 g = src[((size_t)oys[a] * OW + oxs[e]) * C4];
+                const float w = wys[a] * wxs[e];
+                acc.x += w * g.x;
+                acc.y += w * g.y;
+                acc.z += w * g.z;
+                acc.w += w * g.w;
+            }
+        reinterpret_cast<float4 *>(dx)[i] = acc;
+    }
+}
+
+// scatter form (any C, any scale): each output gradient is added to its 4 source pixels; dx pre-zeroed
 __global__ __launch_bounds__(256) void resize_bilinear_grad_kernel(const float *__restrict__ dy, int H, int W, int C,
                                                                    int OH, int OW, float hscale, float wscale,
                                                                    float *__restrict__ dx, long long total)
@@ -327,14 +412,36 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     p.dybytes = (unsigned)(M * N * 4);
     p.ntile_n = mpsr::ceil_div(N, WG_T);
     p.ntile_c = mpsr::ceil_div(C, WG_T);
-    p.msteps_total = mpsr::ceil_div(p.M, WG_K);
-    const int tiles = p.ntile_n * p.ntile_c * KH * KW;
-    int splits = 1536 / (tiles > 0 ? tiles : 1);  // aim at ~6 workgroups per CU
-    if (splits < 1) splits = 1;
-    if (splits > p.msteps_total) splits = p.msteps_total;
-    p.msteps_per_split = mpsr::ceil_div(p.msteps_total, splits);
-    p.splits = mpsr::ceil_div(p.msteps_total, p.msteps_per_split);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(tiles * p.splits)), dim3(256), 0, mpsr::as_stream(stream), p);
+    const int taps = KH * KW;
+    const int tiles = p.ntile_n * p.ntile_c;
+    const int msteps_total = mpsr::ceil_div(p.M, WG_K);
+    int slices = 1536 / (tiles * taps > 0 ? tiles * taps : 1);  // aim at ~6 workgroups per CU
+    if (slices < 1) slices = 1;
+    if (slices > msteps_total) slices = msteps_total;
+    p.splits = slices;
+    p.per_tap = taps <= MAX_TAPS;
+    long long blocks = (long long)tiles * taps * slices;
+    if (p.per_tap) {
+        // share taps * slices pixel slices among the taps in proportion to their valid pixels
+        long long valid[MAX_TAPS], sum = 0;
+        for (int t = 0; t < taps; ++t) {
+            const int dyo = (t / KW - (KH >> 1)) * dilation, dxo = (t % KW - (KW >> 1)) * dilation;
+            const long long hv = H - (dyo < 0 ? -dyo : dyo), wv = W - (dxo < 0 ? -dxo : dxo);
+            valid[t] = hv > 0 && wv > 0 ? hv * wv : 0;
+            sum += valid[t];
+        }
+        blocks = 0;
+        for (int t = 0; t < taps; ++t) {
+            long long st = sum > 0 ? (valid[t] * taps * slices + sum / 2) / sum : 0;
+            const long long steps = (valid[t] * B + WG_K - 1) / WG_K;
+            if (st > steps) st = steps;
+            if (st < 1) st = 1;  // an empty tap exits at once
+            p.tap_splits[t] = (int)st;
+            blocks += st * tiles;
+            p.tap_end[t] = (int)blocks;
+        }
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, mpsr::as_stream(stream), p);
     MPSR_CHECK_LAUNCH("conv_wgrad_kernel");
     return MPSR_OK;
 }
@@ -444,6 +551,15 @@ extern "C" int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, i
     const float hscale = (align_corners && OH > 1) ? (float)(H - 1) / (float)(OH - 1) : (float)H / (float)OH;
     const float wscale = (align_corners && OW > 1) ? (float)(W - 1) / (float)(OW - 1) : (float)W / (float)OW;
     hipStream_t s = mpsr::as_stream(stream);
+    // gather form when rows are float4-addressable and at most RG_MAX outputs read one input along an axis
+    const bool few = 2.0f / hscale + 4.0f <= (float)RG_MAX && 2.0f / wscale + 4.0f <= (float)RG_MAX;
+    if (few && C % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+        const long long n4 = (long long)B * H * W * (C / 4);
+        hipLaunchKernelGGL(resize_bilinear_grad_gather_kernel, dim3(grid_for(n4)), dim3(256), 0, s, dy, H, W, C / 4, OH,
+                           OW, hscale, wscale, dx, n4);
+        MPSR_CHECK_LAUNCH("resize_bilinear_grad_gather_kernel");
+        return MPSR_OK;
+    }
     MPSR_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * H * W * C, s));
     const long long total = (long long)B * OH * OW * C;
     hipLaunchKernelGGL(resize_bilinear_grad_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, H, W, C, OH, OW, hscale,

@@ -103,7 +103,8 @@ def test_max_pool_gradient(shape, k, s, pad):
     _close(xt.grad, xr.grad, 1e-6, "max_pool dx")
 
 
-@pytest.mark.parametrize("shape,out", [((2, 12, 12, 16), (24, 24)), ((1, 24, 24, 8), (48, 48)), ((2, 5, 7, 4), (9, 4))])
+@pytest.mark.parametrize("shape,out", [((2, 12, 12, 16), (24, 24)), ((1, 24, 24, 8), (48, 48)), ((2, 5, 7, 4), (9, 4)),
+                                       ((1, 3, 3, 3), (40, 40)), ((1, 2, 2, 4), (40, 40)), ((1, 1, 1, 4), (5, 5))])
 def test_resize_bilinear_gradient(shape, out):
     from monopsr_amd.core import autograd_ops as ops
     rng = np.random.default_rng(6)
@@ -274,3 +275,34 @@ def test_instance_trainer_step_reduces_loss():
     tr.reducer.finish()
     empty = [i for i, L in enumerate(net.layers) if float(L.dw.abs().max()) == 0.0]
     assert not empty, empty
+
+
+def test_clip_by_norm_segments_matches_per_tensor_clip():
+    """mpsr_clip_by_norm_segments over the trainer's chunk table == tf.clip_by_norm tensor by tensor."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    cfg = config_utils.default_config()
+    net = train_net.TrainNet(W.synthetic_weights(seed=91, width_div=4), width_div=4)
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, clip_norm=1.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    net.grads.copy_(torch.randn(net.grads.shape, device="cuda", generator=g) * 0.02)
+    net.layers[3].dw.mul_(1e-3)                      # a variable below the threshold stays untouched
+    before = net.grads.clone()
+    want = before.clone()
+    base = net.grads.data_ptr()
+    n_clipped = 0
+    for L in net.layers:
+        for t in (L.dw, L.db):
+            if t is None:
+                continue
+            lo = (t.data_ptr() - base) // 4
+            seg = want[lo:lo + t.numel()]
+            norm = torch.linalg.vector_norm(seg.double())
+            if norm > 1.0:
+                seg.mul_((1.0 / norm).float())
+                n_clipped += 1
+    tr.clip_per_variable()
+    assert n_clipped > 10
+    assert float((net.grads - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+    lo = (net.layers[3].dw.data_ptr() - base) // 4
+    assert torch.equal(net.grads[lo:lo + net.layers[3].dw.numel()], before[lo:lo + net.layers[3].dw.numel()])
