@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmonopsr_hip.so")
+# MPSR_LIB_PATH: development knob for A/B-ing two builds of the library inside one GPU session
+LIB_PATH = os.environ.get("MPSR_LIB_PATH") or os.path.join(_HERE, "libmonopsr_hip.so")
 ABI_VERSION = 2
 
 _lib = None
