@@ -31,6 +31,8 @@ __device__ __forceinline__ float level_log2e(int lev)
     return -exp2f(2.f * (float)j) * kLog2e;
 }
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 __device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, float by, float bz)
 {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
@@ -82,7 +84,11 @@ __global__ __launch_bounds__(kSweepThreads) void approx_match_sweep_kernel(int n
     const float *wgt = SWEEP == 1 ? (first ? nullptr : remR) : (SWEEP == 2 ? ratL : ratR);
 
     const int base = blockIdx.x * (kSweepThreads * kPT);
-    float x[kPT], y[kPT], z[kPT], s[kPT];
+    // the two own points of a thread live in the halves of 2-wide vectors: the distance / weighting arithmetic then
+    // compiles to packed fp32 instructions (v_pk_add/mul/fma_f32: two points per VALU slot); only the two exp2 stay
+    // scalar (quarter-rate transcendental unit)
+    static_assert(kPT == 2, "packed sweep arithmetic pairs two own points per thread");
+    f32x2 x, y, z, sv;
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
         const int i = base + u * kSweepThreads + tid;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kSweepThreads) void approx_match_sweep_kernel(int n
         x[u] = live ? own[3 * i] : 0.f;
         y[u] = live ? own[3 * i + 1] : 0.f;
         z[u] = live ? own[3 * i + 2] : 0.f;
-        s[u] = SWEEP == 1 ? 1e-9f : 0.f;
+        sv[u] = SWEEP == 1 ? 1e-9f : 0.f;
     }
     for (int o0 = 0; o0 < nother; o0 += kTile) {
         const int cnt = min(kTile, nother - o0);
@@ -100,15 +106,19 @@ __global__ __launch_bounds__(kSweepThreads) void approx_match_sweep_kernel(int n
 #pragma unroll 4
         for (int o = 0; o < cnt; ++o) {
             const float4 t = tile[o];
-#pragma unroll
-            for (int u = 0; u < kPT; ++u) {
-                // distance evaluated as (other - own) for givers, (own - other) for receivers: the reference's
-                // operand order (x2 - x1), squares are identical either way
-                const float d2 = kOwnIsL ? sq3(t.x, t.y, t.z, x[u], y[u], z[u]) : sq3(x[u], y[u], z[u], t.x, t.y, t.z);
-                s[u] += __builtin_amdgcn_exp2f(lv * d2) * t.w;
-            }
+            // distance evaluated as (other - own) for givers, (own - other) for receivers: the reference's operand
+            // order (x2 - x1); squares are identical either way
+            const f32x2 dx = kOwnIsL ? t.x - x : x - t.x, dy = kOwnIsL ? t.y - y : y - t.y,
+                        dz = kOwnIsL ? t.z - z : z - t.z;
+            const f32x2 d2 = dx * dx + dy * dy + dz * dz;
+            const f32x2 a = lv * d2;
+            f32x2 e;
+            e[0] = __builtin_amdgcn_exp2f(a[0]);
+            e[1] = __builtin_amdgcn_exp2f(a[1]);
+            sv += e * t.w;
         }
     }
+    float s[kPT] = {sv[0], sv[1]};
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
         const int i = base + u * kSweepThreads + tid;
