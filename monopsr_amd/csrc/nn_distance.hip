@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kQPT = 2;      // query points per thread
+constexpr int kQPT = 4;      // query points per thread (one LDS broadcast read feeds kQPT distance evaluations)
 constexpr int kTile = 1024;  // searched points per LDS tile (16 KiB as float4)
 constexpr int kChunk = 8;    // points per min-tracking chunk
 
@@ -33,6 +33,8 @@ __device__ __forceinline__ float sqdist(float rx, float ry, float rz, float qx, 
     const float dz = rz - qz;
     return (dx * dx + dy * dy) + dz * dz;
 }
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 __global__ __launch_bounds__(kThreads) void nn_search_kernel(int n, const float *__restrict__ xyz1, int m,
                                                              const float *__restrict__ xyz2,
@@ -80,15 +82,35 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(int n, const float 
             tile[p] = v;
         }
         __syncthreads();
-        for (int k0 = 0; k0 < cntp; k0 += kChunk) {
-            float cm[kQPT];
+        // the thread's two queries sit in the halves of 2-wide vectors: subtract / square / add issue as packed fp32
+        // (v_pk_add_f32 / v_pk_mul_f32 are IEEE-exact and nothing is contracted, so every distance keeps the bits of
+        // the scalar expression (dx*dx + dy*dy) + dz*dz); only the running minimum stays per component
+        static_assert(kQPT % 2 == 0, "packed search arithmetic pairs the queries of a thread");
+        f32x2 vqx[kQPT / 2], vqy[kQPT / 2], vqz[kQPT / 2];
 #pragma unroll
-            for (int u = 0; u < kQPT; ++u) cm[u] = __builtin_inff();
+        for (int v = 0; v < kQPT / 2; ++v) {
+            vqx[v] = f32x2{qx[2 * v], qx[2 * v + 1]};
+            vqy[v] = f32x2{qy[2 * v], qy[2 * v + 1]};
+            vqz[v] = f32x2{qz[2 * v], qz[2 * v + 1]};
+        }
+        for (int k0 = 0; k0 < cntp; k0 += kChunk) {
+            f32x2 cmv[kQPT / 2];
+#pragma unroll
+            for (int v = 0; v < kQPT / 2; ++v) cmv[v] = f32x2{__builtin_inff(), __builtin_inff()};
 #pragma unroll
             for (int s = 0; s < kChunk; ++s) {
                 const float4 rp = tile[k0 + s];
 #pragma unroll
-                for (int u = 0; u < kQPT; ++u) cm[u] = fminf(cm[u], sqdist(rp.x, rp.y, rp.z, qx[u], qy[u], qz[u]));
+                for (int v = 0; v < kQPT / 2; ++v) {
+                    const f32x2 dx = rp.x - vqx[v], dy = rp.y - vqy[v], dz = rp.z - vqz[v];
+                    cmv[v] = __builtin_elementwise_min(cmv[v], (dx * dx + dy * dy) + dz * dz);
+                }
+            }
+            float cm[kQPT];
+#pragma unroll
+            for (int v = 0; v < kQPT / 2; ++v) {
+                cm[2 * v] = cmv[v][0];
+                cm[2 * v + 1] = cmv[v][1];
             }
 #pragma unroll
             for (int u = 0; u < kQPT; ++u) {
