@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_CROP = 2 * 6196658176  # trunk + squash + decoder + xyz + heads, MACs x 2
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (v_mfma_f32_32x32x16_bf16)
 P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791],
                [0.0, 0.0, 1.0, 0.002745884]], np.float32)  # a KITTI P2 (values of training/calib/000000.txt)
 
@@ -186,6 +187,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="split each GPU's batch into this many instance shards on separate HIP streams")
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
+                    help="contraction arithmetic of the timed run: fp32 (default, the headline) or the opt-in "
+                         "split-bfloat16 mode (include/monopsr_hip.h MPSR_MATH_BF16X3)")
+    ap.add_argument("--no-fast-mode", action="store_true",
+                    help="skip the extra bf16x3_mode measurement appended to a default fp32 run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,8 +208,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     n_gpus = world
 
+    from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
+    _lib.set_conv_math(args.math)
     weights = W.synthetic_weights(seed=0)
     net = dn.DeviceNet(weights, device=device)
     inp, host = make_inputs(args.batch, args.points, rank, device)
@@ -246,7 +254,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.math == "fp32" else "bf16x3 (split-bfloat16 products, f32 accumulate, f32 tensors)",
         "data": "synthetic",
         "config": {"workload": "BASELINE cfg3: batch=%d/GPU synthetic 48x48 crops -> ResNet-101 trunk(block3, os4) + "
                                "squash/map-decoder/xyz + heads fwd, + %d-pt nn_distance Chamfer fwd/bwd" %
@@ -282,11 +290,40 @@ def main():
                 break
             except Exception:
                 pass
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM)",
-                              "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_F32_MFMA_TFLOPS if args.math == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        kname = "conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM)" if args.math == "fp32" else \
+            "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
+        result["roofline"] = {"bound": "mfma", "kernel": kname,
+                              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                              "frac": round(achieved / peak, 4), "traffic": traffic if args.math == "fp32" else None,
                               "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
                               "flops_per_launch": round(flops / launches)}
+    if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
+        # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
+        # on the same inputs (NOT the headline: `value` above is fp32)
+        ref = None
+        if isinstance(step, Step):
+            xyz32, out32 = step.forward_net()
+            ref = (xyz32.clone(), out32["centroids"].clone())
+        _lib.set_conv_math("bf16x3")
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = max(3, min(10, args.steps))
+        for _ in range(k):
+            one_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fast = {"value": round(args.batch * k / dt, 2), "unit": "crops/s", "ms_per_step": round(1e3 * dt / k, 3),
+                "arithmetic": "hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 tensors"}
+        if ref is not None:
+            xyz, out = step.forward_net()
+            rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+            fast["max_rel_drift_vs_fp32"] = {"inst_xyz_map_local": float("%.3g" % rel(xyz, ref[0])),
+                                             "centroids": float("%.3g" % rel(out["centroids"], ref[1]))}
+        _lib.set_conv_math("fp32")
+        result["bf16x3_mode"] = fast
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
         result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
 

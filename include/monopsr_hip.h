@@ -114,6 +114,17 @@ int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float
                          const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                          int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream);
 
+/* Arithmetic of every contraction mpsr_conv2d_nhwc_f32 and the network entry points run (process-wide setting).
+ *   MPSR_MATH_FP32   (default) exact fp32 products on v_mfma_f32_32x32x2_f32: what every parity and benchmark
+ *                    number of this library refers to unless it says otherwise.
+ *   MPSR_MATH_BF16X3 opt-in fast mode: operands split into hi + lo bfloat16 halves on the fly, each product evaluated
+ *                    as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative
+ *                    error per product; inputs, outputs and weights stay fp32 in memory).
+ * The reference has no such switch (TF-1.8 convolutions are fp32); the path's drift budget is 1e-3 (BASELINE.json). */
+enum { MPSR_MATH_FP32 = 0, MPSR_MATH_BF16X3 = 1 };
+int mpsr_set_conv_math(int mode);
+int mpsr_get_conv_math(void);
+
 /* Explicit im2col for the ResNet root: explicit zero pad 3 + 7x7 stride-2 VALID (resnet_utils.py:115-122 via
  * resnet_v1.py:234).  x (B,H,W,3) -> cols (B*OH*OW, kpad) with OH=(H+6-7)/2+1; column (ky*7+kx)*3+c, columns
  * 147..kpad-1 zero.  kpad % 32 == 0, kpad >= 147. */

@@ -52,6 +52,8 @@ class HeadOutputs(ctypes.Structure):
 SIGNATURES = {
     "mpsr_last_error": (ctypes.c_char_p, []),
     "mpsr_abi_version": (c_i, []),
+    "mpsr_set_conv_math": (c_i, [c_i]),
+    "mpsr_get_conv_math": (c_i, []),
     "mpsr_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, c_sz]),
     "mpsr_nn_distance_fwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -120,6 +122,20 @@ def lib():
             raise MpsrError("libmonopsr_hip.so ABI %d != expected %d; rebuild" % (got, ABI_VERSION))
         _lib = handle
     return _lib
+
+
+MATH_MODES = {"fp32": 0, "bf16x3": 1}
+
+
+def set_conv_math(mode):
+    """Process-wide arithmetic of the convolution / FC contractions: "fp32" (default, exact) or "bf16x3" (opt-in:
+    split-bfloat16 products with fp32 accumulation, see include/monopsr_hip.h).  Returns the previous mode."""
+    names = {v: k for k, v in MATH_MODES.items()}
+    prev = names[lib().mpsr_get_conv_math()]
+    if mode not in MATH_MODES:
+        raise InvalidArgumentError("unknown conv math mode %r (choose from %s)" % (mode, sorted(MATH_MODES)))
+    check(lib().mpsr_set_conv_math(MATH_MODES[mode]))
+    return prev
 
 
 def check(status):

@@ -34,6 +34,17 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// Arithmetic of the contraction.  MATH_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products.
+// MATH_BF16X3 (opt-in, mpsr_set_conv_math): every fp32 operand is split into hi + lo bfloat16 halves when its tile is
+// written to LDS (hi = rne(x), lo = rne(x - hi): 16 mantissa bits together) and each product is evaluated as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 3 matrix instructions at 16x the fp32
+// MFMA rate.  Per-product relative error <= ~2^-16; measured end-to-end drift of the whole network 1e-5..4e-5
+// (DESIGN.md 4.1), against the path's 1e-3 budget.  Same tiles, loads, LDS footprint and epilogue as the fp32 path.
+constexpr int MATH_FP32 = 0, MATH_BF16X3 = 1;
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats per LDS row
@@ -62,7 +73,7 @@ struct ConvParams {
     PixelClass cls[MAX_CLS];
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -173,13 +184,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
             }
         }
     };
+    // bf16x3: a row keeps its 144-byte stride: [32 hi bf16 | 32 lo bf16 | 16 B pad]
+    auto store_split = [&](float *row, const float4 &v4) {
+        const f32x4 v = {v4.x, v4.y, v4.z, v4.w};
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+        __bf16 *r = reinterpret_cast<__bf16 *>(row);
+        *reinterpret_cast<bf16x4 *>(r + lcol) = hi;
+        *reinterpret_cast<bf16x4 *>(r + BK + lcol) = lo;
+    };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < AV; ++j)
-            *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDS_STRIDE + lcol]) = ra[j];
+        for (int j = 0; j < AV; ++j) {
+            if constexpr (MATH == MATH_BF16X3) store_split(&As[(lrow + 32 * j) * LDS_STRIDE], ra[j]);
+            else *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDS_STRIDE + lcol]) = ra[j];
+        }
 #pragma unroll
-        for (int j = 0; j < BV; ++j)
-            *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDS_STRIDE + lcol]) = rb[j];
+        for (int j = 0; j < BV; ++j) {
+            if constexpr (MATH == MATH_BF16X3) store_split(&Bs[(lrow + 32 * j) * LDS_STRIDE], rb[j]);
+            else *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDS_STRIDE + lcol]) = rb[j];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -195,6 +219,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     const float *Bw = Bs + (wn * TN * 32) * LDS_STRIDE + frag;
 
     auto compute_tile = [&]() {
+        if constexpr (MATH == MATH_BF16X3) {
+            // lane (i = l & 31, g = l >> 5) supplies k = 16*slice + 8*g .. +7 of row i for both operands (the same
+            // k assignment on the A and the B side is all the dot product needs)
+            const __bf16 *Ah = reinterpret_cast<const __bf16 *>(As + (wm * TM * 32 + (lane & 31)) * LDS_STRIDE) +
+                               (lane >> 5) * 8;
+            const __bf16 *Bh = reinterpret_cast<const __bf16 *>(Bs + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE) +
+                               (lane >> 5) * 8;
+#pragma unroll
+            for (int sl = 0; sl < BK / 16; ++sl) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDS_STRIDE * 2 + sl * 16);
+                    al[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDS_STRIDE * 2 + BK + sl * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDS_STRIDE * 2 + sl * 16);
+                    bl[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDS_STRIDE * 2 + BK + sl * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             float4 a[TM], b[TN];
@@ -372,14 +427,14 @@ void build_classes(ConvParams &p, int B, int BM, bool use_classes)
     for (int i = 0; i < p.ncls; ++i) p.mtiles_xcd += mpsr::ceil_div(p.cls[i].tiles, 8);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
 int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
 {
     build_classes(p, B, BM, use_classes);
     p.ntiles = mpsr::ceil_div(p.N, BN);
     const long long blocks = 8LL * p.mtiles_xcd * p.ntiles * p.splits;
     if (blocks > 0x7fffffffLL) return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv2d: grid too large");
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     MPSR_CHECK_LAUNCH("conv_igemm_kernel");
     return MPSR_OK;
 }
@@ -388,6 +443,7 @@ int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
 // classes -1 = heuristic, 0 = never, 1 = whenever the geometry allows
 int g_tile_override = -1;
 int g_class_override = -1;
+int g_math = MATH_FP32;  // mpsr_set_conv_math
 
 }  // namespace
 
@@ -449,13 +505,28 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         else if (p.M < 131072) sel = 3;
         else sel = 0;
     }
-    switch (sel) {
-        case 0: rc = launch<128, 128, 2, 2>(p, B, use_classes, stream); break;
-        case 1: rc = launch<128, 64, 2, 2>(p, B, use_classes, stream); break;
-        case 2: rc = launch<64, 128, 2, 2>(p, B, use_classes, stream); break;
-        case 3: rc = launch<64, 64, 2, 2>(p, B, use_classes, stream); break;
-        case 5: rc = launch<96, 128, 1, 4>(p, B, use_classes, stream); break;
-        default: rc = launch<128, 32, 4, 1>(p, B, use_classes, stream); break;
+    if (g_math == MATH_BF16X3) {
+        // 3 bf16 matrix instructions replace 8 fp32 ones at 1/16 of the cycles each, so LDS and the operand split
+        // feed the matrix pipes: larger wave tiles (fewer fragment reads per instruction) win -- 128x128 on the big
+        // decoder maps, 128x64 on the 12x12 trunk layers (tools/conv_layer_bench.py --math bf16x3)
+        if (g_tile_override < 0) sel = N <= 32 ? 4 : ((N <= 64 || p.M < 131072) ? 1 : 0);
+        switch (sel) {
+            case 0: rc = launch<128, 128, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
+            case 1: rc = launch<128, 64, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
+            case 2: rc = launch<64, 128, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
+            case 3: rc = launch<64, 64, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
+            case 5: rc = launch<96, 128, 1, 4, MATH_BF16X3>(p, B, use_classes, stream); break;
+            default: rc = launch<128, 32, 4, 1, MATH_BF16X3>(p, B, use_classes, stream); break;
+        }
+    } else {
+        switch (sel) {
+            case 0: rc = launch<128, 128, 2, 2>(p, B, use_classes, stream); break;
+            case 1: rc = launch<128, 64, 2, 2>(p, B, use_classes, stream); break;
+            case 2: rc = launch<64, 128, 2, 2>(p, B, use_classes, stream); break;
+            case 3: rc = launch<64, 64, 2, 2>(p, B, use_classes, stream); break;
+            case 5: rc = launch<96, 128, 1, 4>(p, B, use_classes, stream); break;
+            default: rc = launch<128, 32, 4, 1>(p, B, use_classes, stream); break;
+        }
     }
     if (rc) return rc;
     if (p.splits > 1) {
@@ -474,6 +545,14 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 // and for the tests that sweep every instantiation.  Process-wide, not thread-safe.
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
 extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
+
+extern "C" int mpsr_set_conv_math(int mode)
+{
+    MPSR_REQUIRE(mode == MATH_FP32 || mode == MATH_BF16X3, "set_conv_math: unknown mode %d", mode);
+    g_math = mode;
+    return MPSR_OK;
+}
+extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
 extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
                                     const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,

@@ -387,3 +387,62 @@ def test_device_net_batch_chunking_is_bit_identical():
     assert torch.equal(f1, f2)
     for x, y in zip(a1, a2):
         assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------- opt-in bf16x3 contraction mode
+
+@pytest.fixture
+def bf16x3():
+    from monopsr_amd import _lib
+    prev = _lib.set_conv_math("bf16x3")
+    yield
+    _lib.set_conv_math(prev)
+    _lib.lib().mpsr_debug_set_conv_tile(-1)
+    _lib.lib().mpsr_debug_set_conv_classes(-1)
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_bf16x3_vs_fp64(case, tile, bf16x3):
+    """Split-bfloat16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate): every tile instantiation within 4e-5 of
+    the float64 convolution (the fp32 path: 2e-6)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    B, H, Wd, C, N, k, rate, has_bias, has_res, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((k, k, C, N)) / np.sqrt(k * k * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+    ref = _conv_ref(x, w, bias, res, rate, relu)
+    w_ok, _ = W.fold_conv(w)
+    _lib.lib().mpsr_debug_set_conv_tile(tile)
+    _lib.lib().mpsr_debug_set_conv_classes(1 if rate > 1 else -1)
+    got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, k, k, rate,
+                    relu)
+    _close(got, ref, 4e-5, "bf16x3 conv %s tile %d" % (case, tile))
+
+
+def test_network_drift_in_bf16x3_mode(bf16x3):
+    """Whole instance path (full-width trunk, decoder, heads) in bf16x3 mode vs the fp32 CPU restatement: within
+    2e-4 of tensor scale (measured 1e-5..4e-5), a fifth of the path's 1e-3 budget; fp32 mode: 1e-5."""
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    B = 4
+    weights = W.synthetic_weights(seed=0)
+    sample, (crops, boxes, cam_p, view, cls, mean_lwh, z_off) = _sample(B, 5)
+    full_feat = np.maximum(np.random.default_rng(6).standard_normal((B, 12, 12, 1024)), 0).astype(np.float32)
+    ref = onet.instance_path(crops, full_feat, boxes, cam_p, view, cls, mean_lwh, z_off, weights)
+    net = dn.DeviceNet(weights)
+    feat = net.trunk(_dev(crops))
+    fb, fm, xyz = net.squash_decoder(feat, _dev(full_feat))
+    out = net.heads_fwd(fb, _dev(boxes), _dev(cam_p), _dev(view), _dev(cls), _dev(mean_lwh), _dev(z_off))
+    worst = 0.0
+    for got, key in ((feat, "crop_feat"), (xyz, "inst_xyz_map_local"), (out["centroids"], "centroids"),
+                     (out["lwh"], "lwh"), (out["alpha_bins"], "alpha_bins")):
+        want = ref[key].numpy()
+        err = np.abs(got.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30)
+        assert err < 2e-4, "%s drift %.3e" % (key, err)
+        worst = max(worst, err)
+    assert worst > 1e-7   # the mode really was active (fp32 mode sits at ~3e-6 on block3 but ~1e-7 on lwh)

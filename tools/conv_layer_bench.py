@@ -41,11 +41,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--tiles", default="-1,0,3,5")
     ap.add_argument("--classes", type=int, default=-1)
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--shape", action="append", default=[],
                     help="extra shape H,W,C,N,k,dil,res (repeatable); replaces the built-in list")
     args = ap.parse_args()
+    _lib.set_conv_math(args.math)
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
     lib.mpsr_debug_set_conv_classes(args.classes)
