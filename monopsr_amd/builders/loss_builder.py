@@ -1,43 +1,42 @@
-"""Loss selection by config, mirroring the reference's builders/loss_builder.py:8-85."""
+"""Loss selection by config: same entry points as the reference's builders/loss_builder.py:8-85
+(get_loss_type_and_weight, build_loss, add_loss_tensor), driven by a registry instead of an if-chain."""
 import torch
 
 from monopsr_amd.core import losses, losses_custom
 
+# loss type string (model_config.loss_config entries, yaml:102-117) -> constructor
+_REGISTRY = {
+    'smooth_l1': losses.WeightedSmoothL1LocalizationLoss,
+    'smooth_l1_nonzero': losses_custom.WeightedNonZeroSmoothL1LocalizationLoss,
+    'softmax': losses.WeightedSoftmaxClassificationLoss,
+    'softmax_temp': lambda: losses.WeightedSoftmaxClassificationLoss(0.5),
+    'sigmoid_ce': losses_custom.SigmoidClassificationLoss,
+    'berHu': losses_custom.WeightedBerHu,
+    'chamfer_dist': losses_custom.ChamferDistance,
+    'emd': losses_custom.EarthMoversDistance,
+}
+_NOT_BUILT = {'focal': 'the sigmoid focal loss is selectable in the reference but used by no MonoPSR config'}
+
 
 def get_loss_type_and_weight(loss_config, output_rep):
-    if not hasattr(loss_config, output_rep):
+    """-> (type string, weight) of `output_rep`'s entry, e.g. ['smooth_l1', 0.1]."""
+    entry = getattr(loss_config, output_rep, None)
+    if entry is None:
         raise ValueError('Loss not configured for output_rep:', output_rep)
-    this_loss_config = getattr(loss_config, output_rep)
-    return this_loss_config[0], this_loss_config[1]
+    return entry[0], entry[1]
 
 
 def build_loss(loss_type):
-    if loss_type == 'berHu':
-        return losses_custom.WeightedBerHu()
-    elif loss_type == 'chamfer_dist':
-        return losses_custom.ChamferDistance()
-    elif loss_type == 'emd':
-        return losses_custom.EarthMoversDistance()
-    elif loss_type == 'smooth_l1':
-        return losses.WeightedSmoothL1LocalizationLoss()
-    elif loss_type == 'smooth_l1_nonzero':
-        return losses_custom.WeightedNonZeroSmoothL1LocalizationLoss()
-    elif loss_type == 'softmax':
-        return losses.WeightedSoftmaxClassificationLoss()
-    elif loss_type == 'softmax_temp':
-        return losses.WeightedSoftmaxClassificationLoss(0.5)
-    elif loss_type == 'sigmoid_ce':
-        return losses_custom.SigmoidClassificationLoss()
-    elif loss_type == 'focal':
-        raise ValueError('focal loss is not selected by any MonoPSR config and is not built here', loss_type)
-    else:
+    if loss_type in _NOT_BUILT:
+        raise ValueError('Loss type not built: ' + _NOT_BUILT[loss_type], loss_type)
+    if loss_type not in _REGISTRY:
         raise ValueError('Invalid loss type', loss_type)
+    return _REGISTRY[loss_type]()
 
 
 def add_loss_tensor(loss_config, output_type, pred_tensor, gt_tensor, mask):
-    """loss_builder.py:59-85: the configured loss of `output_type`, times its configured weight."""
+    """The configured loss of `output_type` between prediction and ground truth under `mask`, times its weight."""
     loss_type, loss_weight = get_loss_type_and_weight(loss_config, output_type)
     if loss_type is None:
         return torch.zeros_like(pred_tensor)
-    loss_obj = build_loss(loss_type)
-    return loss_obj(pred_tensor, gt_tensor, weights=mask) * loss_weight
+    return build_loss(loss_type)(pred_tensor, gt_tensor, weights=mask) * loss_weight

@@ -1,22 +1,31 @@
-"""Mean subtraction + bilinear resize of the input image, mirroring core/img_preprocessor.py:12-35."""
+"""Input-image preprocessing of the instance path: per-channel mean subtraction followed by a bilinear resize with
+tf.image.resize_images semantics (align_corners=False).  Same class / method / argument names as the reference's
+core/img_preprocessor.py:4-35; the resize runs through mpsr_resize_bilinear."""
 import torch
 
 from monopsr_amd.core import device_net as dn
 
+# per-channel RGB means by dataset statistics name (values of img_preprocessor.py:7,10)
+CHANNEL_MEANS = {
+    'kitti': (92.8403, 97.7996, 93.5843),
+    'imagenet': (123.68, 116.78, 103.94),
+}
+
 
 class ImgPreprocessor:
-    _KITTI_CHANNEL_MEANS = [92.8403, 97.7996, 93.5843]
-    _IMAGENET_CHANNEL_MEANS = [123.68, 116.78, 103.94]
+
+    def __init__(self):
+        self._means_on_device = {}
+
+    def _means(self, mean_sub_type, device):
+        key = (mean_sub_type, str(device))
+        if key not in self._means_on_device:
+            if mean_sub_type not in CHANNEL_MEANS:
+                raise ValueError('Invalid mean subtraction type {}'.format(mean_sub_type))
+            self._means_on_device[key] = torch.tensor(CHANNEL_MEANS[mean_sub_type], dtype=torch.float32, device=device)
+        return self._means_on_device[key]
 
     def preprocess_input(self, tensor_in, output_size, mean_sub_type):
-        """tensor_in (batch, H, W, 3) on the GPU -> float32 (batch, output_size) mean-subtracted, resized with
-        tf.image.resize_images semantics (bilinear, align_corners=False)."""
-        image = tensor_in.to(torch.float32)
-        if mean_sub_type == 'kitti':
-            channel_means = self._KITTI_CHANNEL_MEANS
-        elif mean_sub_type == 'imagenet':
-            channel_means = self._IMAGENET_CHANNEL_MEANS
-        else:
-            raise ValueError('Invalid mean subtraction type {}'.format(mean_sub_type))
-        image_centered = image - torch.tensor(channel_means, dtype=torch.float32, device=image.device)
-        return dn.resize_bilinear(image_centered, tuple(output_size), align_corners=False)
+        """(batch, H, W, 3) image tensor on the GPU (any numeric dtype) -> float32 (batch, *output_size, 3)."""
+        centred = tensor_in.to(torch.float32) - self._means(mean_sub_type, tensor_in.device)
+        return dn.resize_bilinear(centred, tuple(output_size), align_corners=False)
