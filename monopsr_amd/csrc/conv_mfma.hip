@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     const int ppi = pc.h * pc.w;               // class pixels per image
     const int ntx = pc.kx1 - pc.kx0 + 1;
     const int ksteps_cls = (pc.ky1 - pc.ky0 + 1) * ntx * p.cblocks;
-    const int ks_begin = si * p.ksteps_per_split;
-    const int ks_end = min(ksteps_cls, ks_begin + p.ksteps_per_split);
+    // split-K: every class shares ITS K steps among the p.splits slices (an empty slice writes a zero partial)
+    const int ks_per = p.splits > 1 ? (ksteps_cls + p.splits - 1) / p.splits : ksteps_cls;
+    const int ks_begin = si * ks_per;
+    const int ks_end = min(ksteps_cls, ks_begin + ks_per);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -269,18 +271,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         }
     };
 
-    // K loop (the host guarantees ks_begin < ks_end); last tile peeled so the body has no conditional
-    load_tile();
-    store_tile();
-    __syncthreads();
-    for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+    // K loop; last tile peeled so the body has no conditional.  ks_begin >= ks_end only for an empty split-K slice
+    // (block-uniform).
+    if (ks_begin < ks_end) {
         load_tile();
-        compute_tile();
-        __syncthreads();
         store_tile();
         __syncthreads();
+        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+            load_tile();
+            compute_tile();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        compute_tile();
     }
-    compute_tile();
 
     // The 16-pass fp32 MFMA needs 18 wait states before its result is read.  hipcc (ROCm 7.2) was seen to place
     // the first v_accvgpr_read too early on a loop-exit edge (wrong last accumulator element); the wait is made
@@ -452,6 +457,29 @@ namespace mpsr {
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s);  // image_ops.hip
 
+// split_k == 0 ("auto"): a launch whose 64x64 tiles would leave most of the 256 CUs with one workgroup or none
+// (32 proposal crops: M = 4608; the 40x152 full-image map: M = 6080) is cut along K so that ~3 workgroups per CU
+// exist, each keeping at least 4 K steps; bounded by the scratch the caller provides.  kAutoSplitFloats covers every
+// case the rule can produce: (768 + tiles) * 64 * 64 floats with tiles < 768.
+// Measured at 32 crops (tools/conv_layer_bench.py --batch 32 --split 0): 768 workgroups / >= 4 K steps per slice is
+// the sweet spot (conv time 5.02 -> 4.47 ms); asking for 1536+ workgroups loses again to partial-sum traffic.
+size_t conv_auto_split_floats() { return (size_t)1536 * 64 * 64; }
+
+constexpr int g_auto_split_target = 768;  // workgroups wanted per launch
+constexpr int g_auto_split_min_ksteps = 4;
+
+int auto_split_k(int M, int N, int ksteps, const float *ws, size_t ws_floats)
+{
+    if (!ws) return 1;
+    const long long tiles = (long long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (tiles >= g_auto_split_target || N <= 32) return 1;
+    long long s = (g_auto_split_target + tiles - 1) / tiles;
+    if (s > 8) s = 8;
+    if (s > ksteps / g_auto_split_min_ksteps) s = ksteps / g_auto_split_min_ksteps;
+    while (s > 1 && (size_t)s * M * N > ws_floats) --s;
+    return s < 1 ? 1 : (int)s;
+}
+
 // Shared by the network-level entry points (network.hip).
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
@@ -481,6 +509,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     p.wbytes = (unsigned)((long long)N * KH * KW * C * 4);
     p.cblocks = ceil_div(C, BK);
     p.ksteps_total = KH * KW * p.cblocks;
+    if (split_k == 0) split_k = auto_split_k(p.M, N, p.ksteps_total, ws, ws_floats);  // fill an under-filled launch
     if (split_k < 1) split_k = 1;
     if (split_k > p.ksteps_total) split_k = p.ksteps_total;
     p.ksteps_per_split = ceil_div(p.ksteps_total, split_k);
@@ -490,11 +519,10 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
             return fail(MPSR_ERR_WORKSPACE, "conv2d: split_k=%d needs %zu workspace floats, got %zu", p.splits,
                         (size_t)p.splits * p.M * N, ws_floats);
     }
-    // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little), never
-    // together with split-K (the split assumes every tile has the same K extent)
-    bool use_classes = p.splits == 1 && KH == 3 && KW == 3 && dilation > 1;
+    // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little)
+    bool use_classes = KH == 3 && KW == 3 && dilation > 1;
     if (g_class_override == 0) use_classes = false;
-    if (g_class_override == 1) use_classes = p.splits == 1 && KH == 3 && KW == 3;
+    if (g_class_override == 1) use_classes = KH == 3 && KW == 3;
     int rc;
     int sel = g_tile_override;
     if (sel < 0) {

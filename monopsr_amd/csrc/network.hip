@@ -10,6 +10,7 @@ namespace mpsr {
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
            hipStream_t stream);
+size_t conv_auto_split_floats();
 }
 
 namespace {
@@ -67,7 +68,9 @@ extern "C" size_t mpsr_trunk_workspace_bytes(int B, int H, int W)
     const TrunkDims d = trunk_dims(H, W);
     const size_t Mr = (size_t)B * d.OH * d.OW, Mp = (size_t)B * d.PH * d.PW;
     // cols, root, pooled, 3 x (Mp x 1024) ping/pong/shortcut, 2 x (Mp x 256) bottleneck temporaries
-    return fbytes(Mr * 160) + fbytes(Mr * 64) + fbytes(Mp * 64) + 3 * fbytes(Mp * 1024) + 2 * fbytes(Mp * 256);
+    // + the split-K scratch small batches use to fill the chip (conv_mfma.hip auto_split_k)
+    return fbytes(Mr * 160) + fbytes(Mr * 64) + fbytes(Mp * 64) + 3 * fbytes(Mp * 1024) + 2 * fbytes(Mp * 256) +
+           fbytes(mpsr::conv_auto_split_floats());
 }
 
 extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
@@ -96,6 +99,8 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
     float *pooled = ar.floats(Mp * root.cout);
     float *ping = ar.floats(Mp * cmax), *pong = ar.floats(Mp * cmax), *scut = ar.floats(Mp * cmax);
     float *t1 = ar.floats(Mp * bmax), *t2 = ar.floats(Mp * bmax);
+    const size_t skn = mpsr::conv_auto_split_floats();
+    float *sk = ar.floats(skn);
     if (!ar.ok)
         return mpsr::fail(MPSR_ERR_WORKSPACE, "trunk_fwd: workspace %zu bytes too small (see mpsr_trunk_workspace_bytes)",
                           workspace_bytes);
@@ -115,7 +120,7 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
             if (u == 0) {  // projection shortcut: 1x1, BN folded, no activation
                 const mpsr_layer &S = layers[li++];
                 MPSR_REQUIRE(S.kh == 1 && S.cin == cur_c && !S.relu, "trunk_fwd: record %d is not a shortcut", li - 1);
-                if ((rc = run_layer(blob, S, cur, B, d.PH, d.PW, nullptr, scut, 1, nullptr, 0, s))) return rc;
+                if ((rc = run_layer(blob, S, cur, B, d.PH, d.PW, nullptr, scut, 0, sk, skn, s))) return rc;
                 residual = scut;
             }
             const mpsr_layer &c1 = layers[li], &c2 = layers[li + 1], &c3 = layers[li + 2];
@@ -124,9 +129,9 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
                              c3.cin == c2.cout && (u == 0 || c3.cout == cur_c),
                          "trunk_fwd: records %d..%d do not form a bottleneck unit", li - 3, li - 1);
             float *dst = last ? out : (cur == ping ? pong : ping);
-            if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 1, nullptr, 0, s))) return rc;
-            if ((rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 1, nullptr, 0, s))) return rc;
-            if ((rc = run_layer(blob, c3, t2, B, d.PH, d.PW, residual, dst, 1, nullptr, 0, s))) return rc;
+            if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 0, sk, skn, s))) return rc;
+            if ((rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 0, sk, skn, s))) return rc;
+            if ((rc = run_layer(blob, c3, t2, B, d.PH, d.PW, residual, dst, 0, sk, skn, s))) return rc;
             cur = dst;
             cur_c = c3.cout;
         }

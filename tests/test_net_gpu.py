@@ -446,3 +446,36 @@ def test_network_drift_in_bf16x3_mode(bf16x3):
         assert err < 2e-4, "%s drift %.3e" % (key, err)
         worst = max(worst, err)
     assert worst > 1e-7   # the mode really was active (fp32 mode sits at ~3e-6 on block3 but ~1e-7 on lwh)
+
+
+@pytest.mark.parametrize("split", [0, 2, 3, 5])
+@pytest.mark.parametrize("case", [
+    (2, 12, 12, 256, 256, 3, 4, True, False, True),    # block3 conv2: border classes + split-K together
+    (1, 12, 12, 128, 128, 3, 2, True, False, True),
+    (2, 12, 12, 1024, 256, 1, 1, True, False, True),   # block3 conv1 at a small batch
+    (2, 12, 12, 256, 1024, 1, 1, True, True, True),    # conv3 + residual
+    (1, 9, 11, 36, 40, 3, 2, False, True, False),      # ragged everything
+    (1, 5, 5, 64, 64, 3, 4, True, False, False),       # dilation close to the map size: single-class fallback
+])
+def test_conv2d_split_k_with_classes_and_auto(case, split):
+    """split_k > 1 on convolutions (slices per pixel class, empty slices write zero partials) and split_k = 0 (auto:
+    the library fills an under-filled launch) give the same result as the unsplit kernel up to summation order."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    B, H, Wd, C, N, k, rate, has_bias, has_res, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((k, k, C, N)) / np.sqrt(k * k * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+    ref = _conv_ref(x, w, bias, res, rate, relu)
+    w_ok, _ = W.fold_conv(w)
+    for classes in (-1, 0, 1):
+        _lib.lib().mpsr_debug_set_conv_classes(classes)
+        try:
+            got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, k, k,
+                            rate, relu, split_k=split)
+        finally:
+            _lib.lib().mpsr_debug_set_conv_classes(-1)
+        _close(got, ref, 2e-6, "split %d classes %d %s" % (split, classes, case))

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--tiles", default="-1,0,3,5")
     ap.add_argument("--classes", type=int, default=-1)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"])
+    ap.add_argument("--split", type=int, default=1, help="split_k passed to the library (0 = automatic)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--shape", action="append", default=[],
@@ -69,6 +70,8 @@ def main():
         bias = torch.randn((N,), device=dev)
         r = torch.randn((B, H, W, N), device=dev) if res else None
         y = torch.empty((B, H, W, N), device=dev)
+        nws = (8 if args.split == 0 else (args.split if args.split > 1 else 0)) * B * H * W * N
+        ws = torch.empty((nws,), device=dev) if nws else None
         flop = 2.0 * B * H * W * C * k * k * N
         cells = []
         for t in tiles:
@@ -79,8 +82,8 @@ def main():
 
             def run():
                 _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
-                                                    r.data_ptr() if res else None, y.data_ptr(), N, k, k, dil, 1, 1,
-                                                    None, 0, _lib.stream()))
+                                                    r.data_ptr() if res else None, y.data_ptr(), N, k, k, dil, 1,
+                                                    args.split, ws.data_ptr() if nws else None, nws, _lib.stream()))
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
