@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     const int hv = p.H - max(0, dyo) - ylo, wv = p.W - max(0, dxo) - xlo;
     if (hv <= 0 || wv <= 0) return;
     const int HWv = hv * wv;
+    const float inv_HWv = 1.0f / (float)HWv, inv_wv = 1.0f / (float)wv;
     const int Mv = (p.M / (p.H * p.W)) * HWv;
     const int msteps_tap = (Mv + WG_K - 1) / WG_K;
     const int per_split = (msteps_tap + nsplit - 1) / nsplit;
@@ -97,8 +98,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         for (int j = 0; j < 4; ++j) {
             const int mv = ms * WG_K + lrow + 8 * j;  // index into the tap's valid pixels
             const bool mok = mv < Mv;
-            const int img = mv / HWv, r = mv - img * HWv;
-            const int ry = r / wv;
+            // two divisions per load, four loads per K step: float reciprocal + one-step fix-up instead of the
+            // ~40-instruction integer division sequence (operands < 2^24; the fix-up absorbs the rounding)
+            int img = (int)((float)mv * inv_HWv);
+            img -= (img * HWv > mv);
+            img += ((img + 1) * HWv <= mv);
+            const int r = mv - img * HWv;
+            int ry = (int)((float)r * inv_wv);
+            ry -= (ry * wv > r);
+            ry += ((ry + 1) * wv <= r);
             const int m = img * HW + (ylo + ry) * p.W + xlo + (r - ry * wv);  // the pixel itself
             const unsigned offa = (mok && nok) ? ((unsigned)m * (unsigned)p.N + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
             ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa, 0, 0));
@@ -391,6 +399,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+int g_wgrad_target = 768;  // one round of the 3 workgroups per CU the kernel's registers allow (measured best)
+
 inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
 
 }  // namespace
@@ -415,7 +425,7 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     const int taps = KH * KW;
     const int tiles = p.ntile_n * p.ntile_c;
     const int msteps_total = mpsr::ceil_div(p.M, WG_K);
-    int slices = 1536 / (tiles * taps > 0 ? tiles * taps : 1);  // aim at ~6 workgroups per CU
+    int slices = g_wgrad_target / (tiles * taps > 0 ? tiles * taps : 1);  // aim at one round of resident workgroups
     if (slices < 1) slices = 1;
     if (slices > msteps_total) slices = msteps_total;
     p.splits = slices;
@@ -581,3 +591,5 @@ extern "C" int mpsr_adam_step(float *param, const float *grad, float *m, float *
     MPSR_CHECK_LAUNCH("adam_kernel");
     return MPSR_OK;
 }
+
+extern "C" void mpsr_debug_set_wgrad_target(int workgroups) { g_wgrad_target = workgroups; }
