@@ -301,29 +301,33 @@ def main():
     if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
         # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
         # on the same inputs (NOT the headline: `value` above is fp32)
-        ref = None
-        if isinstance(step, Step):
-            xyz32, out32 = step.forward_net()
-            ref = (xyz32.clone(), out32["centroids"].clone())
-        _lib.set_conv_math("bf16x3")
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        k = max(3, min(10, args.steps))
-        for _ in range(k):
-            one_step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        fast = {"value": round(args.batch * k / dt, 2), "unit": "crops/s", "ms_per_step": round(1e3 * dt / k, 3),
-                "arithmetic": "hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 tensors"}
-        if ref is not None:
-            xyz, out = step.forward_net()
-            rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-            fast["max_rel_drift_vs_fp32"] = {"inst_xyz_map_local": float("%.3g" % rel(xyz, ref[0])),
-                                             "centroids": float("%.3g" % rel(out["centroids"], ref[1]))}
-        _lib.set_conv_math("fp32")
-        result["bf16x3_mode"] = fast
+        try:
+            ref = None
+            if isinstance(step, Step):
+                xyz32, out32 = step.forward_net()
+                ref = (xyz32.clone(), out32["centroids"].clone())
+            _lib.set_conv_math("bf16x3")
+            for _ in range(2):
+                one_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = max(3, min(10, args.steps))
+            for _ in range(k):
+                one_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            fast = {"value": round(args.batch * k / dt, 2), "unit": "crops/s", "ms_per_step": round(1e3 * dt / k, 3),
+                    "arithmetic": "hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 tensors"}
+            if ref is not None:
+                xyz, out = step.forward_net()
+                rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+                fast["max_rel_drift_vs_fp32"] = {"inst_xyz_map_local": float("%.3g" % rel(xyz, ref[0])),
+                                                 "centroids": float("%.3g" % rel(out["centroids"], ref[1]))}
+            result["bf16x3_mode"] = fast
+        except Exception as e:  # the side measurement must never cost the headline line
+            result["bf16x3_mode"] = {"error": repr(e)}
+        finally:
+            _lib.set_conv_math("fp32")
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
         result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
 
