@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the timed run: fp32 (default, the headline) or the opt-in "
                          "split-bfloat16 mode (include/monopsr_hip.h MPSR_MATH_BF16X3)")
+    ap.add_argument("--no-allreduce-probe", action="store_true",
+                    help="N > 1: skip the extra region that repeats the step with the gradient-sized all-reduce")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3_mode measurement appended to a default fp32 run")
     args = ap.parse_args()
@@ -202,7 +204,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MPSR_BENCH_FORCE_DIST"):  # the env knob exercises the N > 1 code on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -264,6 +266,41 @@ def main():
                    "sharding": "instances/%d, no data-path collective" % n_gpus +
                                (" + all-reduce(401 MB synthetic grad buffer)" if args.allreduce_grads else "")},
     }
+
+    if dist is not None and not args.allreduce_grads and not args.no_allreduce_probe:
+        # BASELINE config 4 adds "data-parallel RCCL all-reduce" to the sharded step.  The metric path itself has no
+        # exchange (value above); this extra region repeats the step with an all-reduce of a buffer the size of the
+        # model's fp32 gradient (100,204,832 floats, synthetic contents -- the forward path produces no parameter
+        # gradient; the real one is exercised by tools/train_bench.py), launched asynchronously so RCCL overlaps the
+        # step's kernels as a trainer's bucketed reduce overlaps backward.
+        try:
+            gbuf = torch.zeros((100204832,), dtype=torch.float32, device=device)
+
+            def ar_step():
+                work = dist.all_reduce(gbuf, async_op=True)
+                out = step()
+                work.wait()
+                return out
+            for _ in range(2):
+                ar_step()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k2 = max(3, min(10, args.steps))
+            for _ in range(k2):
+                ar_step()
+            torch.cuda.synchronize()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+            result["with_grad_allreduce"] = {
+                "value": round(args.batch * n_gpus * k2 / el2, 2), "unit": "crops/s",
+                "ms_per_step": round(1e3 * el2 / k2, 3), "allreduce_bytes": int(gbuf.numel() * 4),
+                "note": "same step + async RCCL all-reduce(sum) of a gradient-sized synthetic fp32 buffer per step"}
+            del gbuf
+        except Exception as e:
+            result["with_grad_allreduce"] = {"error": repr(e)}
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel alone: every conv/FC launch of one step, timed with events on the launch stream
