@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
+                    help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -39,6 +41,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cfg = config_utils.default_config()
+    from monopsr_amd import _lib
+    _lib.set_conv_math(args.math)
     net = train_net.TrainNet(W.synthetic_weights(seed=0), device=dev)
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
