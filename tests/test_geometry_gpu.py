@@ -282,3 +282,37 @@ def test_trainer_schedule_and_moving_average():
     tr.optimizer.apply_gradients(net, 1)
     want = p1 * 0.9999 + net.params * 0.0001
     assert float((tr.optimizer.averaged_params(net) - want).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------ argument validation
+
+def test_geometry_entry_points_reject_bad_arguments():
+    """Shape / pointer errors come back as MPSR_ERR_INVALID_ARG (raised as InvalidArgumentError), empty batches are
+    no-ops -- the behaviour the reference gets from OP_REQUIRES in its op shells."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import losses_custom
+    from monopsr_amd.datasets.kitti import instance_utils as iu
+    lib = _lib.lib()
+    x = torch.zeros((2, 4, 4, 3), device="cuda")
+    s = _lib.stream()
+    assert lib.mpsr_xyz_map_local_to_global(None, None, None, None, 0, 16, s) == 0          # b == 0: nothing to do
+    assert lib.mpsr_xyz_map_local_to_global(None, None, None, None, 2, 16, s) == 1          # null pointers
+    assert b"null pointer" in lib.mpsr_last_error()
+    assert lib.mpsr_proj_err_norm(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 2, 0, 4,
+                                  s) == 1                                                   # h == 0
+    assert lib.mpsr_depth_map_local_to_global(x.data_ptr(), 3, x.data_ptr(), None, None, None, x.data_ptr(), 2, 4, 4,
+                                              1, s) == 1                                    # rotate_view needs boxes
+    assert lib.mpsr_huber_loss_sums(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 16, 3, 0.0, x.data_ptr(),
+                                    x.data_ptr(), s) == 1                                   # delta must be > 0
+    assert lib.mpsr_format_boxes(*([x.data_ptr()] * 9), 2, 0, 375, 1242, 1, 1, 45.0, x.data_ptr(), x.data_ptr(), s) == 1
+    assert lib.mpsr_set_conv_math(7) == 1 and lib.mpsr_get_conv_math() == 0
+    assert lib.mpsr_clip_by_norm_segments(x.data_ptr(), None, None, None, 3, x.data_ptr(), 2, 1.0, s) == 1
+    with pytest.raises(_lib.InvalidArgumentError):
+        iu.tf_inst_xyz_map_local_to_global(x[..., :2], (4, 4), torch.zeros((2, 1), device="cuda"),
+                                           torch.zeros((2, 3), device="cuda"))
+    with pytest.raises(_lib.InvalidArgumentError):
+        iu.tf_inst_depth_map_local_to_global(x[..., :1], torch.zeros((2, 1), device="cuda"), rotate_view=True)
+    with pytest.raises(_lib.InvalidArgumentError):
+        losses_custom.WeightedNonZeroSmoothL1LocalizationLoss()(x, x, weights=torch.ones((2, 4, 4), device="cuda"))
+    with pytest.raises(_lib.MpsrError):
+        iu.tf_inst_xyz_map_local_to_global(x.cpu(), (4, 4), torch.zeros((2, 1)), torch.zeros((2, 3)))   # no CPU path
