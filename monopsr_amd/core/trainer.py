@@ -180,3 +180,45 @@ class InstanceTrainer:
         self.optimizer.apply_gradients(self.net, self.global_step)
         self.global_step += 1
         return loss.detach()
+
+    # ------------------------------------------------------------------ checkpoint / resume (core/trainer.py:85,149-185)
+    def save(self, checkpoint_dir, name='monopsr'):
+        """Write the training state as a TensorFlow-format checkpoint `<dir>/<name>-<global_step, 8 digits>` (the
+        naming of the reference's Saver(pad_step_number=True)) and update the directory's `checkpoint` state file.
+        The variables are this trainer's FLAT buffers (BatchNorm already folded into the weights), so the file
+        resumes this trainer; it is not interchangeable with a checkpoint of the reference's TF variables."""
+        import os
+        import numpy as np
+        from monopsr_amd.core import tf_checkpoint
+        net, opt = self.net, self.optimizer
+        tensors = {
+            'global_step': np.asarray(self.global_step, np.int64),
+            'monopsr_amd/flat_params': net.params.cpu().numpy(),
+            'monopsr_amd/flat_params/Adam': net.adam_m.cpu().numpy(),
+            'monopsr_amd/flat_params/Adam_1': net.adam_v.cpu().numpy(),
+            'monopsr_amd/adam_step': np.asarray(net.step_count, np.int64),
+        }
+        if opt.shadow is not None:
+            tensors['monopsr_amd/flat_params/ExponentialMovingAverage'] = opt.shadow.cpu().numpy()
+        prefix = os.path.join(checkpoint_dir, '%s-%08d' % (name, self.global_step))
+        tf_checkpoint.write_checkpoint(prefix, tensors)
+        tf_checkpoint.write_checkpoint_state(checkpoint_dir, os.path.basename(prefix))
+        return prefix
+
+    def restore(self, path):
+        """Resume from `save`'s output (a prefix, or a directory holding a `checkpoint` state file)."""
+        from monopsr_amd.core import tf_checkpoint
+        t = tf_checkpoint.read_checkpoint(path)
+        net = self.net
+        if t['monopsr_amd/flat_params'].shape != tuple(net.params.shape):
+            raise ValueError('checkpoint holds %d parameters, this net %d' % (t['monopsr_amd/flat_params'].size,
+                                                                          net.params.numel()))
+        dev = net.params.device
+        net.params.copy_(torch.from_numpy(t['monopsr_amd/flat_params']).to(dev))
+        net.adam_m.copy_(torch.from_numpy(t['monopsr_amd/flat_params/Adam']).to(dev))
+        net.adam_v.copy_(torch.from_numpy(t['monopsr_amd/flat_params/Adam_1']).to(dev))
+        net.step_count = int(t['monopsr_amd/adam_step'])
+        self.global_step = int(t['global_step'])
+        ema = t.get('monopsr_amd/flat_params/ExponentialMovingAverage')
+        self.optimizer.shadow = None if ema is None else torch.from_numpy(ema).to(dev)
+        return self.global_step

@@ -79,3 +79,44 @@ def test_train_mode_requires_builder_path():
     with pytest.raises(ValueError):
         model.build_outputs({}, dict(boxes_2d=torch.zeros(1, 4), cam_p=torch.zeros(3, 4),
                                      est_view_angs=torch.zeros(1)))
+
+
+def test_trainer_save_restore_resumes(tmp_path):
+    """3 steps, save, 2 more == restore into a fresh trainer + 2 more (parameters, Adam slots, moving average)."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    cfg = config_utils.default_config()
+    B, div = 3, 8
+
+    def make():
+        net = train_net.TrainNet(W.synthetic_weights(seed=101, width_div=div), width_div=div)
+        return net, trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
+    rng = np.random.default_rng(102)
+    y1, x1 = rng.uniform(100, 200, B), rng.uniform(100, 900, B)
+    boxes = np.stack([y1, x1, y1 + rng.uniform(40, 120, B), x1 + rng.uniform(60, 200, B)], 1).astype(np.float32)
+    sample = dict(rgb_image_crops=_dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
+                  full_img_feature_crop=_dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0)
+                                             .astype(np.float32)),
+                  boxes_2d=_dev(boxes),
+                  cam_p=_dev(np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.003]], np.float32)),
+                  est_view_angs=_dev(rng.uniform(-0.5, 0.5, B).astype(np.float32)),
+                  class_indices=torch.ones((B, 1), dtype=torch.int32, device="cuda"),
+                  mean_lwh=_dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                  prop_cen_z_offset=torch.full((B,), 2.178, device="cuda"))
+    sample.update(trainer.synthetic_ground_truth(sample, seed=103))
+    net_a, tr_a = make()
+    for _ in range(3):
+        tr_a.step(sample)
+    prefix = tr_a.save(str(tmp_path))
+    assert prefix.endswith("monopsr-00000003") and os.path.exists(prefix + ".index")
+    for _ in range(2):
+        tr_a.step(sample)
+    net_b, tr_b = make()
+    assert tr_b.restore(str(tmp_path)) == 3
+    for _ in range(2):
+        tr_b.step(sample)
+    # weight-gradient slices are combined with atomics, so two runs agree to rounding, not bitwise
+    scale = float(net_a.params.abs().max())
+    assert float((net_a.params - net_b.params).abs().max()) < 1e-5 * scale
+    assert float((tr_a.optimizer.shadow - tr_b.optimizer.shadow).abs().max()) < 1e-5 * scale
+    assert tr_a.global_step == tr_b.global_step == 5 and net_a.step_count == net_b.step_count
