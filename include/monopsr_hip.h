@@ -171,6 +171,12 @@ int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int O
 int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream);
 
+/* Gradient of mpsr_crop_and_resize w.r.t. the image (TensorFlow's CropAndResizeGradImage, reached through autodiff
+ * from net_builder.py:54-59 when the full-image trunk trains).  grad_out (nb,ch,cw,C) -> grad_image (nimg,H,W,C),
+ * zeroed inside and accumulated with fp32 atomics; samples that were extrapolated contribute nothing. */
+int mpsr_crop_and_resize_grad(const float *grad_out, int nimg, int H, int W, int C, const float *boxes,
+                              const int *box_ind, int nb, int ch, int cw, float *grad_image, mpsr_stream_t stream);
+
 /* tf.clip_by_norm applied to every variable of a flat gradient buffer separately, as
  * slim.learning.create_train_op(clip_gradient_norm=1.0) does (core/trainer.py:78-81): g *= clip / max(||g||, clip).
  * The caller describes the variables once as a chunk table (device arrays): chunk i covers

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mpsr_resize_bilinear_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, c_i, ctypes.c_float, c_f]),
+    "mpsr_crop_and_resize_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_clip_by_norm_segments": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_i, ctypes.c_float, c_f]),
     "mpsr_xyz_map_local_to_global": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "mpsr_xyz_map_local_to_global_grad": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),

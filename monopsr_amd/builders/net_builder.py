@@ -40,8 +40,12 @@ def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_
         full_img_encoder_out = net.trunk(full_img, 'full')
         # Crop and resize, then max pool the feature map from the full image (net_builder.py:54-60)
         half = (model.map_roi_size[0] // 2, model.map_roi_size[1] // 2)
-        full_img_feature_large_crop = dn.crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
-        full_img_feature_crop = dn.max_pool(full_img_feature_large_crop, 2, 2, "VALID")
+        # a trainable net brings differentiable versions of the two operators (the crop's image gradient feeds the
+        # full-image trunk's backward pass)
+        crop_and_resize = getattr(net, 'crop_and_resize', dn.crop_and_resize)
+        max_pool = getattr(net, 'max_pool', dn.max_pool)
+        full_img_feature_large_crop = crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
+        full_img_feature_crop = max_pool(full_img_feature_large_crop, 2, 2, "VALID")
 
     # concat + 1x1 squash + pool + map decoder in one native call; the xyz-map head (a 3x3 conv on the map
     # features, monopsr_output_builder.py:95-104) rides along and is handed to the output builder

@@ -122,6 +122,29 @@ class ResizeBilinearFn(torch.autograd.Function):
         return dx, None, None
 
 
+class CropAndResizeFn(torch.autograd.Function):
+    """tf.image.crop_and_resize, differentiable w.r.t. the image (boxes are inputs of the graph)."""
+
+    @staticmethod
+    def forward(ctx, image, boxes, box_ind, crop_size, extrapolation_value):
+        image = image.contiguous()
+        boxes = boxes.to(torch.float32).contiguous()
+        box_ind = box_ind.contiguous().int() if box_ind is not None else None
+        ctx.save_for_backward(boxes, box_ind)
+        ctx.cfg = (tuple(image.shape), tuple(crop_size))
+        return dn.crop_and_resize(image, boxes, box_ind, tuple(crop_size), extrapolation_value)
+
+    @staticmethod
+    def backward(ctx, dy):
+        boxes, box_ind = ctx.saved_tensors
+        (nimg, H, W, C), (ch, cw) = ctx.cfg
+        dimg = torch.empty((nimg, H, W, C), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.lib().mpsr_crop_and_resize_grad(_lib.ptr(dy.contiguous()), nimg, H, W, C, _lib.ptr(boxes),
+                                                        _lib.ptr(box_ind), boxes.shape[0], ch, cw, _lib.ptr(dimg),
+                                                        _lib.stream()))
+        return dimg, None, None, None, None
+
+
 _TOKEN = {}
 
 
@@ -141,3 +164,7 @@ def max_pool(x, k, s, padding):
 
 def resize_bilinear(x, size, align_corners):
     return ResizeBilinearFn.apply(x, size, align_corners)
+
+
+def crop_and_resize(image, boxes, box_ind, crop_size, extrapolation_value=0.0):
+    return CropAndResizeFn.apply(image, boxes, box_ind, crop_size, extrapolation_value)

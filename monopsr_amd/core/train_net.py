@@ -26,7 +26,10 @@ def _im2col_root(img, kpad):
 
 
 class TrainNet:
-    def __init__(self, weights, device="cuda", width_div=1, with_heads=True):
+    def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False):
+        """full_trunk: also hold (and train) the full-image ResNet-101 (`weights` must then carry both scopes); its
+        layers follow the heads in the flat buffer, so the flat gradient is the reference's whole 100 M-parameter
+        set (401 MB at full width)."""
         self.device = torch.device(device)
         parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
         fc_names = [n for n, _, _, _ in W.head_fc_specs()] if with_heads else []
@@ -50,6 +53,14 @@ class TrainNet:
                              b_off=base + wsz))
             blobs += [w_ok.ravel(), np.zeros(wsz - w_ok.size, np.float32), b, np.zeros(bsz - b.size, np.float32)]
             base += wsz + bsz
+        self.full_base = None
+        if full_trunk:
+            blob, records = W.pack_trunk(weights, W.FULL_SCOPE, width_div)
+            self.full_base = len(recs)
+            for r in records:
+                recs.append(dict(r, w_off=r["w_off"] + base, b_off=(r["b_off"] + base) if r["b_off"] >= 0 else -1))
+            blobs.append(blob)
+            base += blob.size
         flat = np.concatenate(blobs)
         self.params = torch.from_numpy(flat).to(self.device)
         self.grads = torch.zeros_like(self.params)
@@ -70,10 +81,13 @@ class TrainNet:
 
     # ------------------------------------------------------------------ forward pieces
     def trunk(self, img, scope='crop'):
-        if scope != 'crop':
-            raise _lib.InvalidArgumentError("TrainNet holds the crop trunk only (the full-image branch is fed as "
-                                            "its feature crop, SURVEY 8(a) a3)")
-        L = self.layers
+        if scope == 'crop':
+            L = self.layers
+        elif scope == 'full' and self.full_base is not None:
+            L = self.layers[self.full_base:]
+        else:
+            raise _lib.InvalidArgumentError("TrainNet was built without the %r trunk (full_trunk=True adds the "
+                                            "full-image one)" % scope)
         B = img.shape[0]
         cols, oh, ow = _im2col_root(img, L[0].cin)
         x = ops.conv2d(cols, L[0]).reshape(B, oh, ow, L[0].cout)
@@ -102,6 +116,13 @@ class TrainNet:
         feat_map = ops.conv2d(ops.conv2d(y, L[4]), L[5])
         xyz = ops.conv2d(feat_map, L[6])
         return feat_box, feat_map, xyz
+
+    # differentiable image operators the feature builder uses between the trunks (net_builder.py:54-60)
+    def crop_and_resize(self, image, boxes, box_ind, crop_size, extrapolation_value=0.0):
+        return ops.crop_and_resize(image, boxes, box_ind, crop_size, extrapolation_value)
+
+    def max_pool(self, x, k, s, padding="VALID"):
+        return ops.max_pool(x, k, s, padding)
 
     def fully_connected(self, x, name, relu):
         """Differentiable slim.fully_connected `name` (used by MonoPSROutputBuilder in training mode)."""

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--full-image", action="store_true",
+                    help="train BOTH trunks from a raw 375x1242 image + `--batch` boxes (the reference's step shape at "
+                         "--batch 32) instead of the crop trunk over a precomputed full-image feature crop")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
     args = ap.parse_args()
@@ -43,7 +46,8 @@ def main():
     cfg = config_utils.default_config()
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
-    net = train_net.TrainNet(W.synthetic_weights(seed=0), device=dev)
+    scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
+    net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image)
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
@@ -51,6 +55,11 @@ def main():
     sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
                   cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"], mean_lwh=inp["mean_lwh"],
                   prop_cen_z_offset=inp["z_off"])
+    if args.full_image:
+        del sample["rgb_image_crops"], sample["full_img_feature_crop"]
+        g = torch.Generator(device=dev).manual_seed(11 + rank)
+        sample["rgb_image"] = torch.randint(0, 256, (375, 1242, 3), device=dev, generator=g).float()
+        sample["boxes_2d_norm"] = sample["boxes_2d"] / torch.tensor([375.0, 1242.0, 375.0, 1242.0], device=dev)
     sample.update(trainer.synthetic_ground_truth(sample, seed=7 + rank))
     losses = []
     for _ in range(args.warmup):
