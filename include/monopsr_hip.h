@@ -177,6 +177,25 @@ int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long lon
 int mpsr_crop_and_resize_grad(const float *grad_out, int nimg, int H, int W, int C, const float *boxes,
                               const int *box_ind, int nb, int ch, int cw, float *grad_image, mpsr_stream_t stream);
 
+/* Training-mode batch normalisation of the map decoder (net_builder.py:76-87: slim.batch_norm with is_training,
+ * statistics over (N,H,W) per channel, no scale, epsilon 1e-3, then ReLU).  z is the (M, C) convolution output,
+ * M = N*H*W, C % 4 == 0, C <= 1024.  Statistics are accumulated in fp64 around the first row for conditioning:
+ *   sum[c] = sum_m (z[m][c] - z[0][c]),  sumsq_shifted[c] = sum_m (z[m][c] - z[0][c])^2
+ * so mean = z[0] + sum/M and the (biased) variance = sumsq_shifted/M - (sum/M)^2. */
+int mpsr_batch_norm_stats(const float *z, long long M, int C, double *sum, double *sumsq_shifted,
+                          mpsr_stream_t stream);
+/* y = act((z - mean) * inv_std + beta); relu 0/1; mean, inv_std, beta (C). */
+int mpsr_batch_norm_apply(const float *z, long long M, int C, const float *mean, const float *inv_std,
+                          const float *beta, int relu, float *y, mpsr_stream_t stream);
+/* Backward, pass 1: with g = dy * (y > 0) (g = dy when y == NULL) and zhat = (z - mean) * inv_std:
+ * sum_g[c] = sum_m g (= the beta gradient), sum_gz[c] = sum_m g * zhat; fp64, zeroed inside. */
+int mpsr_batch_norm_grad_sums(const float *dy, const float *y, const float *z, long long M, int C, const float *mean,
+                              const float *inv_std, double *sum_g, double *sum_gz, mpsr_stream_t stream);
+/* Backward, pass 2: dz = inv_std * (g - mean_g - zhat * mean_gz), mean_g = sum_g / M, mean_gz = sum_gz / M. */
+int mpsr_batch_norm_grad(const float *dy, const float *y, const float *z, long long M, int C, const float *mean,
+                         const float *inv_std, const float *mean_g, const float *mean_gz, float *dz,
+                         mpsr_stream_t stream);
+
 /* tf.clip_by_norm applied to every variable of a flat gradient buffer separately, as
  * slim.learning.create_train_op(clip_gradient_norm=1.0) does (core/trainer.py:78-81): g *= clip / max(||g||, clip).
  * The caller describes the variables once as a chunk table (device arrays): chunk i covers

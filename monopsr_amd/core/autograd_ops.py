@@ -18,6 +18,16 @@ class LayerRef:
     def __init__(self, w, b, dw, db, cin, cout, kh, kw, dilation, relu):
         self.w, self.b, self.dw, self.db = w, b, dw, db
         self.cin, self.cout, self.kh, self.kw, self.dilation, self.relu = cin, cout, kh, kw, dilation, relu
+        # batch_norm: None, or a BatchNormState -- the convolution then runs without bias / activation and `b` / `db`
+        # are the BatchNorm beta and its gradient (still this layer's second variable for clipping and all-reduce)
+        self.batch_norm = None
+
+
+class BatchNormState:
+    """Moving statistics of one training-mode BatchNorm (slim.batch_norm defaults: decay 0.999, no scale)."""
+
+    def __init__(self, moving_mean, moving_variance, eps=1e-3, decay=0.999):
+        self.moving_mean, self.moving_variance, self.eps, self.decay = moving_mean, moving_variance, eps, decay
 
 
 def _relu_grad(dy, y):
@@ -35,10 +45,12 @@ class Conv2dFn(torch.autograd.Function):
         # x nor residual needs a gradient (first layer), so that backward still deposits dW / db
         x = x.contiguous()
         res = residual.contiguous() if residual is not None else None
-        y = dn.conv2d(x, layer.w, layer.b, res, layer.kh, layer.kw, layer.dilation, layer.relu)
+        bn = layer.batch_norm is not None
+        y = dn.conv2d(x, layer.w, None if bn else layer.b, res, layer.kh, layer.kw, layer.dilation,
+                      layer.relu and not bn)
         ctx.layer = layer
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if layer.relu else None)
+        ctx.save_for_backward(x, y if (layer.relu and not bn) else None)
         return y
 
     @staticmethod
@@ -50,7 +62,8 @@ class Conv2dFn(torch.autograd.Function):
         B, H, W, C = x.shape
         N = L.cout
         s = _lib.stream()
-        if L.relu:
+        bn = L.batch_norm is not None
+        if L.relu and not bn:
             # ReLU mask in one streaming pass; the bias gradient rides in the weight-gradient kernel below
             gm = torch.empty_like(g)
             _lib.check(lib.mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), None, B * H * W, N, s))
@@ -59,17 +72,17 @@ class Conv2dFn(torch.autograd.Function):
         pad = (-N) % 4
         g4 = F.pad(g, (0, pad)) if pad else g
         N4 = N + pad
-        db4 = L.db
+        db4 = None if bn else L.db  # with BatchNorm, db is the beta gradient and BatchNormReluFn deposits it
         if pad:
             dw4 = torch.zeros((N4, L.w.shape[1]), dtype=torch.float32, device=x.device)
             w4 = F.pad(L.w, (0, 0, 0, pad))
-            if L.db is not None:
+            if db4 is not None:
                 db4 = torch.zeros((N4,), dtype=torch.float32, device=x.device)
         else:
             dw4, w4 = L.dw, L.w
         _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
                                              _lib.ptr(dw4), _lib.ptr(db4), s))
-        if pad and L.db is not None:
+        if pad and db4 is not None:
             L.db.add_(db4[:N])
         if pad:
             L.dw.add_(dw4[:N])
@@ -122,6 +135,55 @@ class ResizeBilinearFn(torch.autograd.Function):
         return dx, None, None
 
 
+class BatchNormReluFn(torch.autograd.Function):
+    """y = relu((z - mean) / sqrt(var + eps) + beta) with BATCH statistics over (N, H, W) (slim.batch_norm,
+    is_training=True, scale=False, net_builder.py:76-87); updates the layer's moving statistics like the fused
+    TensorFlow kernel (biased variance to normalise, unbiased into the moving average); deposits d(beta) into L.db."""
+
+    @staticmethod
+    def forward(ctx, z, layer, token):
+        st = layer.batch_norm
+        z = z.contiguous()
+        C = z.shape[-1]
+        M = z.numel() // C
+        lib = _lib.lib()
+        sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
+        _lib.check(lib.mpsr_batch_norm_stats(_lib.ptr(z), M, C, sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
+        d = sums[0] / M
+        mean = z.reshape(M, C)[0].double() + d
+        var = torch.clamp(sums[1] / M - d * d, min=0.0)
+        with torch.no_grad():
+            st.moving_mean.mul_(st.decay).add_(mean.float(), alpha=1.0 - st.decay)
+            st.moving_variance.mul_(st.decay).add_((var * (M / max(M - 1, 1))).float(), alpha=1.0 - st.decay)
+        mean32 = mean.float().contiguous()
+        inv = torch.rsqrt(var + st.eps).float().contiguous()
+        y = torch.empty_like(z)
+        _lib.check(lib.mpsr_batch_norm_apply(_lib.ptr(z), M, C, _lib.ptr(mean32), _lib.ptr(inv), _lib.ptr(layer.b),
+                                             int(layer.relu), _lib.ptr(y), _lib.stream()))
+        ctx.layer = layer
+        ctx.save_for_backward(z, y if layer.relu else None, mean32, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = ctx.layer
+        z, y, mean32, inv = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = z.shape[-1]
+        M = z.numel() // C
+        lib = _lib.lib()
+        sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
+        _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
+                                                 _lib.ptr(inv), sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
+        L.db.add_(sums[0].float())
+        means = (sums / M).float().contiguous()
+        dz = torch.empty_like(z)
+        _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
+                                            _lib.ptr(inv), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
+                                            _lib.stream()))
+        return dz, None, None
+
+
 class CropAndResizeFn(torch.autograd.Function):
     """tf.image.crop_and_resize, differentiable w.r.t. the image (boxes are inputs of the graph)."""
 
@@ -155,7 +217,12 @@ def _token(device):
 
 
 def conv2d(x, layer, residual=None):
-    return Conv2dFn.apply(x, residual, layer, _token(x.device))
+    """One layer: convolution (+ bias + residual + ReLU), or convolution -> training-mode BatchNorm -> ReLU when the
+    layer carries a BatchNormState."""
+    y = Conv2dFn.apply(x, residual, layer, _token(x.device))
+    if layer.batch_norm is not None:
+        y = BatchNormReluFn.apply(y, layer, _token(x.device))
+    return y
 
 
 def max_pool(x, k, s, padding):

@@ -26,10 +26,17 @@ def _im2col_root(img, kpad):
 
 
 class TrainNet:
-    def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False):
+    def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False, decoder_bn='frozen'):
         """full_trunk: also hold (and train) the full-image ResNet-101 (`weights` must then carry both scopes); its
         layers follow the heads in the flat buffer, so the flat gradient is the reference's whole 100 M-parameter
         set (401 MB at full width)."""
+        """decoder_bn: 'frozen' = the map decoder's BatchNorm runs on its moving statistics, folded into the
+        convolutions like the trunks' (an inference-mode re-parameterisation); 'batch' = the reference's training
+        graph (net_builder.py:76-87, is_training=True): batch statistics over the step's instances, beta trained,
+        moving statistics updated with decay 0.999.  In data-parallel runs the statistics are per rank."""
+        if decoder_bn not in ('frozen', 'batch'):
+            raise ValueError("decoder_bn must be 'frozen' or 'batch'")
+        self.decoder_bn = decoder_bn
         self.device = torch.device(device)
         parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
         fc_names = [n for n, _, _, _ in W.head_fc_specs()] if with_heads else []
@@ -78,6 +85,23 @@ class TrainNet:
                                             bool(r["relu"])))
         self.n_trunk = len(parts[0][1])
         self.n_dec = len(parts[1][1])
+        if decoder_bn == 'batch':
+            # decoder records: squash (2 GEMMs), then one record per spec; BatchNorm layers get the UNFOLDED kernel
+            # in their weight slot and beta in their bias slot
+            idx = self.n_trunk + 1
+            for name, kh, kw, cin, cout, has_bn, has_bias, relu in W.scaled_decoder_specs(width_div):
+                if name.startswith("squash"):
+                    continue
+                idx += 1
+                if not has_bn:
+                    continue
+                L = self.layers[idx]
+                w_ok, _ = W.fold_conv(weights[name + "/weights"])
+                L.w.copy_(torch.from_numpy(w_ok).to(self.device))
+                L.b.copy_(torch.from_numpy(weights[name + "/BatchNorm/beta"].astype(np.float32)).to(self.device))
+                t = lambda a: torch.from_numpy(a.astype(np.float32)).to(self.device)
+                L.batch_norm = ops.BatchNormState(t(weights[name + "/BatchNorm/moving_mean"]),
+                                                  t(weights[name + "/BatchNorm/moving_variance"]), W.DECODER_BN_EPS)
 
     # ------------------------------------------------------------------ forward pieces
     def trunk(self, img, scope='crop'):

@@ -200,6 +200,11 @@ class InstanceTrainer:
         }
         if opt.shadow is not None:
             tensors['monopsr_amd/flat_params/ExponentialMovingAverage'] = opt.shadow.cpu().numpy()
+        for i, L in enumerate(net.layers):  # training-mode BatchNorm: the moving statistics are state, not parameters
+            if L.batch_norm is not None:
+                tensors['monopsr_amd/layer_%03d/BatchNorm/moving_mean' % i] = L.batch_norm.moving_mean.cpu().numpy()
+                tensors['monopsr_amd/layer_%03d/BatchNorm/moving_variance' % i] = \
+                    L.batch_norm.moving_variance.cpu().numpy()
         prefix = os.path.join(checkpoint_dir, '%s-%08d' % (name, self.global_step))
         tf_checkpoint.write_checkpoint(prefix, tensors)
         tf_checkpoint.write_checkpoint_state(checkpoint_dir, os.path.basename(prefix))
@@ -219,6 +224,12 @@ class InstanceTrainer:
         net.adam_v.copy_(torch.from_numpy(t['monopsr_amd/flat_params/Adam_1']).to(dev))
         net.step_count = int(t['monopsr_amd/adam_step'])
         self.global_step = int(t['global_step'])
+        for i, L in enumerate(net.layers):
+            if L.batch_norm is not None:
+                L.batch_norm.moving_mean.copy_(torch.from_numpy(
+                    t['monopsr_amd/layer_%03d/BatchNorm/moving_mean' % i]).to(dev))
+                L.batch_norm.moving_variance.copy_(torch.from_numpy(
+                    t['monopsr_amd/layer_%03d/BatchNorm/moving_variance' % i]).to(dev))
         ema = t.get('monopsr_amd/flat_params/ExponentialMovingAverage')
         self.optimizer.shadow = None if ema is None else torch.from_numpy(ema).to(dev)
         return self.global_step

@@ -1,0 +1,216 @@
+// Training-mode batch normalisation of the map decoder (net_builder.py:76-87: slim.conv2d(..., normalizer_fn=
+// slim.batch_norm, normalizer_params={'is_training': is_training}) -- batch statistics over (N, H, W), no scale,
+// epsilon 1e-3, followed by ReLU).  Inference folds the moving statistics into the convolution (core/weights.py);
+// these kernels are what a training step needs instead.  All of them stream an (M, C) activation once, float4 per
+// thread; per-channel reductions are per-thread float partials -> workgroup sums in double -> one fp64 atomic per
+// channel per workgroup (<= 512 workgroups, so the same-address atomics stay cheap).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 512;
+
+struct RowMap {  // thread -> (float4 column group, first row, row stride) for an (M, C) matrix, C % 4 == 0, C <= 1024
+    int groups, rstride, cg, r0;
+    __device__ RowMap(int C) : groups(C >> 2), rstride(kThreads / (C >> 2)), cg(threadIdx.x % (C >> 2)),
+                               r0(threadIdx.x / (C >> 2)) {}
+};
+
+// column sums of two per-thread float4 partials -> fp64 atomics into a[], b[]
+__device__ __forceinline__ void reduce_columns(const RowMap &m, float4 sa, float4 sb, double *a, double *b)
+{
+    __shared__ float4 pa[kThreads], pb[kThreads];
+    pa[threadIdx.x] = sa;
+    pb[threadIdx.x] = sb;
+    __syncthreads();
+    if ((int)threadIdx.x < m.groups) {
+        double ax = 0, ay = 0, az = 0, aw = 0, bx = 0, by = 0, bz = 0, bw = 0;
+        for (int r = 0; r < m.rstride; ++r) {
+            const float4 u = pa[r * m.groups + threadIdx.x], v = pb[r * m.groups + threadIdx.x];
+            ax += u.x; ay += u.y; az += u.z; aw += u.w;
+            bx += v.x; by += v.y; bz += v.z; bw += v.w;
+        }
+        const int c = 4 * threadIdx.x;
+        unsafeAtomicAdd(&a[c], ax); unsafeAtomicAdd(&a[c + 1], ay); unsafeAtomicAdd(&a[c + 2], az);
+        unsafeAtomicAdd(&a[c + 3], aw);
+        unsafeAtomicAdd(&b[c], bx); unsafeAtomicAdd(&b[c + 1], by); unsafeAtomicAdd(&b[c + 2], bz);
+        unsafeAtomicAdd(&b[c + 3], bw);
+    }
+}
+
+// sum[c] += sum_m z, sumsq[c] += sum_m (z - shift[c])^2 ... shift = z of row 0 keeps the variance well conditioned
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restrict__ z, long long M, int C,
+                                                            long long rows_per_block, double *__restrict__ sum,
+                                                            double *__restrict__ sumsq)
+{
+    const RowMap m(C);
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.r0 < m.rstride) {
+        const float4 sh = reinterpret_cast<const float4 *>(z)[m.cg];  // row 0 of this column group
+        for (long long r = m0 + m.r0; r < m1; r += m.rstride) {
+            float4 v = reinterpret_cast<const float4 *>(z)[(size_t)r * m.groups + m.cg];
+            v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    }
+    reduce_columns(m, s, q, sum, sumsq);
+}
+
+// y = act((z - mean) * inv_std + beta)
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restrict__ z, long long n4, int groups,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ inv_std,
+                                                            const float *__restrict__ beta, int relu,
+                                                            float *__restrict__ y)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+        const int cg = (int)(i % groups);
+        const float4 v = reinterpret_cast<const float4 *>(z)[i];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[cg], is = reinterpret_cast<const float4 *>(inv_std)[cg],
+                     be = reinterpret_cast<const float4 *>(beta)[cg];
+        float4 o = make_float4((v.x - mu.x) * is.x + be.x, (v.y - mu.y) * is.y + be.y, (v.z - mu.z) * is.z + be.z,
+                               (v.w - mu.w) * is.w + be.w);
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+// g = dy * (y > 0) (or dy);  sum_g[c] += sum_m g,  sum_gz[c] += sum_m g * zhat,  zhat = (z - mean) * inv_std
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float *__restrict__ dy,
+                                                                 const float *__restrict__ y,
+                                                                 const float *__restrict__ z, long long M, int C,
+                                                                 long long rows_per_block,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ inv_std,
+                                                                 double *__restrict__ sum_g, double *__restrict__ sum_gz)
+{
+    const RowMap m(C);
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.r0 < m.rstride) {
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[m.cg], is = reinterpret_cast<const float4 *>(inv_std)[m.cg];
+        for (long long r = m0 + m.r0; r < m1; r += m.rstride) {
+            const size_t o = (size_t)r * m.groups + m.cg;
+            float4 g = reinterpret_cast<const float4 *>(dy)[o];
+            if (y) {
+                const float4 a = reinterpret_cast<const float4 *>(y)[o];
+                g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
+                g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+            }
+            const float4 v = reinterpret_cast<const float4 *>(z)[o];
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * (v.x - mu.x) * is.x; q.y += g.y * (v.y - mu.y) * is.y;
+            q.z += g.z * (v.z - mu.z) * is.z; q.w += g.w * (v.w - mu.w) * is.w;
+        }
+    }
+    reduce_columns(m, s, q, sum_g, sum_gz);
+}
+
+// dz = inv_std * (g - mean_g - zhat * mean_gz)
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                const float *__restrict__ z, long long n4, int groups,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ inv_std,
+                                                                const float *__restrict__ mean_g,
+                                                                const float *__restrict__ mean_gz,
+                                                                float *__restrict__ dz)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+        const int cg = (int)(i % groups);
+        float4 g = reinterpret_cast<const float4 *>(dy)[i];
+        if (y) {
+            const float4 a = reinterpret_cast<const float4 *>(y)[i];
+            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
+            g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+        }
+        const float4 v = reinterpret_cast<const float4 *>(z)[i];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[cg], is = reinterpret_cast<const float4 *>(inv_std)[cg],
+                     mg = reinterpret_cast<const float4 *>(mean_g)[cg], mz = reinterpret_cast<const float4 *>(mean_gz)[cg];
+        reinterpret_cast<float4 *>(dz)[i] =
+            make_float4(is.x * (g.x - mg.x - (v.x - mu.x) * is.x * mz.x), is.y * (g.y - mg.y - (v.y - mu.y) * is.y * mz.y),
+                        is.z * (g.z - mg.z - (v.z - mu.z) * is.z * mz.z), is.w * (g.w - mg.w - (v.w - mu.w) * is.w * mz.w));
+    }
+}
+
+int check_mc(const char *op, long long M, int C)
+{
+    MPSR_REQUIRE(M >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "%s: M=%lld C=%d (C must be a multiple of 4, <= 1024)", op,
+                 M, C);
+    return MPSR_OK;
+}
+
+inline void slicing(long long M, int &blocks, long long &rows)
+{
+    long long b = (M + 63) / 64;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    rows = (M + b - 1) / b;
+    blocks = (int)((M + rows - 1) / rows);
+}
+
+inline int stream_grid(long long n4) { return (int)((n4 + kThreads - 1) / kThreads < 65536 ? (n4 + kThreads - 1) / kThreads : 65536); }
+
+}  // namespace
+
+extern "C" int mpsr_batch_norm_stats(const float *z, long long M, int C, double *sum, double *sumsq_shifted,
+                                     mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_stats", M, C)) return rc;
+    MPSR_REQUIRE(z && sum && sumsq_shifted && ((uintptr_t)z & 15) == 0, "batch_norm_stats: null or misaligned pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(hipMemsetAsync(sum, 0, sizeof(double) * C, s));
+    MPSR_CHECK_HIP(hipMemsetAsync(sumsq_shifted, 0, sizeof(double) * C, s));
+    int blocks;
+    long long rows;
+    slicing(M, blocks, rows);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(kThreads), 0, s, z, M, C, rows, sum, sumsq_shifted);
+    MPSR_CHECK_LAUNCH("bn_stats_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_apply(const float *z, long long M, int C, const float *mean, const float *inv_std,
+                                     const float *beta, int relu, float *y, mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_apply", M, C)) return rc;
+    MPSR_REQUIRE(z && mean && inv_std && beta && y, "batch_norm_apply: null pointer");
+    const long long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(kThreads), 0, mpsr::as_stream(stream), z, n4, C / 4,
+                       mean, inv_std, beta, relu, y);
+    MPSR_CHECK_LAUNCH("bn_apply_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_grad_sums(const float *dy, const float *y, const float *z, long long M, int C,
+                                         const float *mean, const float *inv_std, double *sum_g, double *sum_gz,
+                                         mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_grad_sums", M, C)) return rc;
+    MPSR_REQUIRE(dy && z && mean && inv_std && sum_g && sum_gz, "batch_norm_grad_sums: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(hipMemsetAsync(sum_g, 0, sizeof(double) * C, s));
+    MPSR_CHECK_HIP(hipMemsetAsync(sum_gz, 0, sizeof(double) * C, s));
+    int blocks;
+    long long rows;
+    slicing(M, blocks, rows);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kThreads), 0, s, dy, y, z, M, C, rows, mean, inv_std,
+                       sum_g, sum_gz);
+    MPSR_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_grad(const float *dy, const float *y, const float *z, long long M, int C,
+                                    const float *mean, const float *inv_std, const float *mean_g, const float *mean_gz,
+                                    float *dz, mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_grad", M, C)) return rc;
+    MPSR_REQUIRE(dy && z && mean && inv_std && mean_g && mean_gz && dz, "batch_norm_grad: null pointer");
+    const long long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(kThreads), 0, mpsr::as_stream(stream), dy, y, z,
+                       n4, C / 4, mean, inv_std, mean_g, mean_gz, dz);
+    MPSR_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return MPSR_OK;
+}

@@ -81,3 +81,93 @@ def test_training_step_with_both_trunks():
     net.params.copy_(p0)
     losses = [float(tr.step(sample)) for _ in range(6)]
     assert np.isfinite(losses).all() and min(losses[-3:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("shape,relu", [((3, 24, 24, 64), True), ((2, 7, 5, 8), False), ((1, 48, 48, 128), True)])
+def test_batch_norm_training_mode_vs_float64_autograd(shape, relu):
+    """conv -> BatchNorm(batch statistics, no scale, eps 1e-3) -> ReLU: outputs, input / weight / beta gradients and
+    the moving-statistics update vs torch float64 (F.batch_norm, training=True)."""
+    import torch.nn.functional as F
+    from monopsr_amd.core import autograd_ops as ops
+    rng = np.random.default_rng(shape[1])
+    B, H, Wd, C = shape
+    cin = 16
+    x = (rng.standard_normal((B, H, Wd, cin)) * 3 + 5).astype(np.float32)     # off-centre: exercises the conditioning
+    w = (rng.standard_normal((C, 9 * cin)) / np.sqrt(9 * cin)).astype(np.float32)
+    beta = rng.standard_normal(C).astype(np.float32)
+    mm, mv = rng.standard_normal(C).astype(np.float32), rng.uniform(0.5, 1.5, C).astype(np.float32)
+    up = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    wt, bt = _dev(w), _dev(beta)
+    dw, db = torch.zeros_like(wt), torch.zeros_like(bt)
+    L = ops.LayerRef(wt, bt, dw, db, cin, C, 3, 3, 1, relu)
+    L.batch_norm = ops.BatchNormState(_dev(mm), _dev(mv), 1e-3, 0.999)
+    xt = _dev(x).requires_grad_()
+    y = ops.conv2d(xt, L)
+    (y * _dev(up)).sum().backward()
+    # float64 reference
+    x64 = torch.from_numpy(x).double().requires_grad_()
+    w64 = torch.from_numpy(w).double().requires_grad_()
+    b64 = torch.from_numpy(beta).double().requires_grad_()
+    z = F.conv2d(x64.permute(0, 3, 1, 2), w64.reshape(C, 3, 3, cin).permute(0, 3, 1, 2), padding=1)
+    rm, rv = torch.from_numpy(mm).double(), torch.from_numpy(mv).double()
+    yr = F.batch_norm(z, rm, rv, None, b64, True, 1 - 0.999, 1e-3)
+    if relu:
+        yr = torch.relu(yr)
+    yr = yr.permute(0, 2, 3, 1)
+    (yr * torch.from_numpy(up).double()).sum().backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    assert rel(y.detach().cpu().numpy(), yr.detach().numpy()) < 2e-5
+    assert rel(xt.grad.cpu().numpy(), x64.grad.numpy()) < 1e-4
+    assert rel(dw.cpu().numpy(), w64.grad.numpy()) < 1e-4
+    assert rel(db.cpu().numpy(), b64.grad.numpy()) < 1e-4
+    assert rel(L.batch_norm.moving_mean.cpu().numpy(), rm.numpy()) < 1e-5          # F.batch_norm updated rm / rv in place
+    assert rel(L.batch_norm.moving_variance.cpu().numpy(), rv.numpy()) < 1e-5
+
+
+def test_training_step_with_decoder_batch_statistics():
+    """TrainNet(decoder_bn='batch'): the reference's training graph for the map decoder.  Directional derivative of
+    the whole loss along the decoder's gradient, beta included; moving statistics move."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    B, div = 4, 4
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=121, width_div=div)
+    net = train_net.TrainNet(weights, width_div=div, decoder_bn='batch')
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, lr=1e-4)
+    rng = np.random.default_rng(122)
+    y1, x1 = rng.uniform(100, 200, B), rng.uniform(100, 900, B)
+    boxes = np.stack([y1, x1, y1 + rng.uniform(40, 120, B), x1 + rng.uniform(60, 200, B)], 1).astype(np.float32)
+    sample = dict(rgb_image_crops=_dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
+                  full_img_feature_crop=_dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0)
+                                             .astype(np.float32)),
+                  boxes_2d=_dev(boxes),
+                  cam_p=_dev(np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.003]], np.float32)),
+                  est_view_angs=_dev(rng.uniform(-0.5, 0.5, B).astype(np.float32)),
+                  class_indices=torch.ones((B, 1), dtype=torch.int32, device="cuda"),
+                  mean_lwh=_dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                  prop_cen_z_offset=torch.full((B,), 2.178, device="cuda"))
+    sample.update(trainer.synthetic_ground_truth(sample, seed=123))
+    bn_layers = [L for L in net.layers if L.batch_norm is not None]
+    assert len(bn_layers) == 4
+    mm0 = bn_layers[0].batch_norm.moving_mean.clone()
+    net.zero_grad()
+    _, total = tr.loss(tr.forward(sample), sample)
+    total.backward()
+    tr.reducer.finish()
+    assert not torch.equal(mm0, bn_layers[0].batch_norm.moving_mean)
+    assert all(float(L.db.abs().max()) > 0 and float(L.dw.abs().max()) > 0 for L in bn_layers)
+    g, p0, L0 = net.grads.clone(), net.params.clone(), float(total)
+    first = bn_layers[0]
+    last = net.layers[net.n_trunk + net.n_dec - 1]
+    lo = (first.dw.data_ptr() - net.grads.data_ptr()) // 4
+    hi = (last.dw.data_ptr() - net.grads.data_ptr()) // 4
+    gs = torch.zeros_like(g)
+    gs[lo:hi] = g[lo:hi]                       # the four BatchNorm layers: kernels and betas
+    nrm = float(gs.double().norm())
+    net.params.copy_(p0 - 1e-3 * gs / nrm)
+    with torch.no_grad():
+        L1 = float(tr.loss(tr.forward(sample), sample)[1])
+    assert 0.9 < (L1 - L0) / (-1e-3 * nrm) < 1.1, (L0, L1, nrm)
+    net.params.copy_(p0)
+    losses = [float(tr.step(sample)) for _ in range(6)]
+    assert np.isfinite(losses).all()

@@ -89,7 +89,7 @@ def test_trainer_save_restore_resumes(tmp_path):
     B, div = 3, 8
 
     def make():
-        net = train_net.TrainNet(W.synthetic_weights(seed=101, width_div=div), width_div=div)
+        net = train_net.TrainNet(W.synthetic_weights(seed=101, width_div=div), width_div=div, decoder_bn='batch')
         return net, trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
     rng = np.random.default_rng(102)
     y1, x1 = rng.uniform(100, 200, B), rng.uniform(100, 900, B)
@@ -120,3 +120,8 @@ def test_trainer_save_restore_resumes(tmp_path):
     assert float((net_a.params - net_b.params).abs().max()) < 1e-5 * scale
     assert float((tr_a.optimizer.shadow - tr_b.optimizer.shadow).abs().max()) < 1e-5 * scale
     assert tr_a.global_step == tr_b.global_step == 5 and net_a.step_count == net_b.step_count
+    bn_a = [L.batch_norm for L in net_a.layers if L.batch_norm is not None]
+    bn_b = [L.batch_norm for L in net_b.layers if L.batch_norm is not None]
+    assert len(bn_a) == 4
+    for a, b in zip(bn_a, bn_b):
+        assert float((a.moving_mean - b.moving_mean).abs().max()) < 1e-5 * float(a.moving_mean.abs().max() + 1)

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--decoder-bn", default="batch", choices=["batch", "frozen"],
+                    help="map-decoder BatchNorm: batch statistics as in the reference's training graph (default), or "
+                         "frozen moving statistics folded into the convolutions")
     ap.add_argument("--full-image", action="store_true",
                     help="train BOTH trunks from a raw 375x1242 image + `--batch` boxes (the reference's step shape at "
                          "--batch 32) instead of the crop trunk over a precomputed full-image feature crop")
@@ -47,7 +50,8 @@ def main():
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
-    net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image)
+    net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
+                             decoder_bn=args.decoder_bn)
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
