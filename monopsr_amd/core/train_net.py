@@ -160,6 +160,65 @@ class TrainNet:
         B = x.shape[0]
         return ops.conv2d(x.reshape(B, 1, 1, L.cin), L).reshape(B, -1)
 
+    # ------------------------------------------------------------------ export
+    def export_weights(self, width_div=1):
+        """The trained parameters as a dict keyed by the reference's TF variable names (the layout
+        core/weights.py documents, what DeviceNet / checkpoint_utils.save_checkpoint take).  Layers trained in folded
+        form come back as an equivalent variable set: kernel = folded kernel, BatchNorm beta = folded bias,
+        gamma = 1, moving_mean = 0, moving_variance = 1 - eps (so that inference-mode BatchNorm is the identity plus
+        beta).  Decoder layers trained with batch statistics export their own kernel, beta and moving statistics."""
+        out = {}
+
+        def hwio(w_ok, kh, kw, cin):
+            cout = w_ok.shape[0]
+            return np.ascontiguousarray(w_ok.reshape(cout, kh, kw, cin).transpose(1, 2, 3, 0))
+
+        def identity_bn(name, b, eps, with_gamma):
+            c = b.shape[0]
+            if with_gamma:
+                out[name + "/BatchNorm/gamma"] = np.ones(c, np.float32)
+            out[name + "/BatchNorm/beta"] = b
+            out[name + "/BatchNorm/moving_mean"] = np.zeros(c, np.float32)
+            out[name + "/BatchNorm/moving_variance"] = np.full(c, 1.0 - eps, np.float32)
+
+        def trunk(scope, base):
+            for i, sp in enumerate(W.scaled_trunk_specs(scope, width_div)):
+                L = self.layers[base + i]
+                w, b = L.w.detach().cpu().numpy(), L.b.detach().cpu().numpy()
+                if sp["role"] == "root":
+                    out[sp["name"] + "/weights"] = hwio(w[:, :W.ROOT_K], 7, 7, 3)
+                else:
+                    out[sp["name"] + "/weights"] = hwio(w, sp["kh"], sp["kw"], sp["cin"])
+                identity_bn(sp["name"], b, W.TRUNK_BN_EPS, True)
+        trunk(W.CROP_SCOPE, 0)
+        if self.full_base is not None:
+            trunk(W.FULL_SCOPE, self.full_base)
+        idx = self.n_trunk
+        for name, kh, kw, cin, cout, has_bn, has_bias, relu in W.scaled_decoder_specs(width_div):
+            if name.startswith("squash"):
+                a, b2 = self.layers[idx], self.layers[idx + 1]
+                w = np.concatenate([a.w.detach().cpu().numpy(), b2.w.detach().cpu().numpy()], 1)
+                out[name + "/weights"] = hwio(w, 1, 1, cin)
+                out[name + "/biases"] = b2.b.detach().cpu().numpy()
+                idx += 2
+                continue
+            L = self.layers[idx]
+            idx += 1
+            out[name + "/weights"] = hwio(L.w.detach().cpu().numpy(), kh, kw, cin)
+            if not has_bn:
+                out[name + "/biases"] = L.b.detach().cpu().numpy()
+            elif L.batch_norm is not None:
+                out[name + "/BatchNorm/beta"] = L.b.detach().cpu().numpy()
+                out[name + "/BatchNorm/moving_mean"] = L.batch_norm.moving_mean.cpu().numpy()
+                out[name + "/BatchNorm/moving_variance"] = L.batch_norm.moving_variance.cpu().numpy()
+            else:
+                identity_bn(name, L.b.detach().cpu().numpy(), W.DECODER_BN_EPS, False)
+        for name, (i, fin) in self.fc_index.items():
+            L = self.layers[i]
+            out[name + "/weights"] = np.ascontiguousarray(L.w.detach().cpu().numpy()[:, :fin].T)
+            out[name + "/biases"] = L.b.detach().cpu().numpy()
+        return out
+
     # ------------------------------------------------------------------ optimisation
     def zero_grad(self):
         self.grads.zero_()

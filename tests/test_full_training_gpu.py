@@ -171,3 +171,46 @@ def test_training_step_with_decoder_batch_statistics():
     net.params.copy_(p0)
     losses = [float(tr.step(sample)) for _ in range(6)]
     assert np.isfinite(losses).all()
+
+
+def test_export_weights_round_trips_into_the_inference_net(tmp_path):
+    """TrainNet.export_weights() -> reference-named variables -> TensorFlow-format checkpoint -> DeviceNet computes
+    what the TrainNet computes (frozen-BatchNorm form: the same function); the batch-statistics form exports its
+    kernels, betas and moving statistics under the BatchNorm names."""
+    from monopsr_amd.core import checkpoint_utils, train_net
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    div, B = 4, 3
+    weights = W.synthetic_weights(seed=131, width_div=div, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
+    net = train_net.TrainNet(weights, width_div=div, full_trunk=True)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    net.params.add_(torch.randn(net.params.shape, device="cuda", generator=g) * 1e-3 * net.params.abs().mean())
+    exported = net.export_weights(width_div=div)
+    assert set(exported) == set(weights)
+    for k in weights:
+        assert exported[k].shape == weights[k].shape and exported[k].dtype == np.float32, k
+    prefix = checkpoint_utils.save_checkpoint(str(tmp_path / "monopsr"), exported, global_step=7)
+    restored = W.synthetic_weights(seed=999, width_div=div, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
+    names = checkpoint_utils.restore_monopsr_weights(restored, checkpoint_utils.load_checkpoint(prefix))
+    assert set(names) == set(weights)
+    inf = dn.DeviceNet(restored, width_div=div, full_trunk=True)
+    rng = np.random.default_rng(132)
+    crops = _dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32))
+    full = _dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0).astype(np.float32))
+    img = _dev((rng.standard_normal((1, 160, 608, 3)) * 50).astype(np.float32))
+    with torch.no_grad():
+        a = net.trunk(crops)
+        fa = net.squash_decoder(a, full)
+        af = net.trunk(img, 'full')
+    b = inf.trunk(crops)
+    fb = inf.squash_decoder(b, full)
+    bf = inf.trunk(img, 'full')
+    rel = lambda x, y: float((x - y).abs().max() / (y.abs().max() + 1e-30))
+    assert rel(b, a) < 1e-5 and rel(bf, af) < 1e-5
+    for x, y in zip(fb, fa):
+        assert rel(x, y) < 1e-5
+    net_b = train_net.TrainNet(weights, width_div=div, decoder_bn='batch')
+    eb = net_b.export_weights(width_div=div)
+    n = "map_decoder/conv2/conv2_1"
+    np.testing.assert_array_equal(eb[n + "/weights"], weights[n + "/weights"])
+    np.testing.assert_array_equal(eb[n + "/BatchNorm/moving_variance"], weights[n + "/BatchNorm/moving_variance"])
