@@ -537,7 +537,8 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         // 3 bf16 matrix instructions replace 8 fp32 ones at 1/16 of the cycles each, so LDS and the operand split
         // feed the matrix pipes: larger wave tiles (fewer fragment reads per instruction) win -- 128x128 on the big
         // decoder maps, 128x64 on the 12x12 trunk layers (tools/conv_layer_bench.py --math bf16x3)
-        if (g_tile_override < 0) sel = N <= 32 ? 4 : ((N <= 64 || p.M < 131072) ? 1 : 0);
+        // (small batches -- a single image's 32 crops -- need the small tile to have workgroups for every CU)
+        if (g_tile_override < 0) sel = N <= 32 ? 4 : (p.M < 16384 ? 3 : ((N <= 64 || p.M < 131072) ? 1 : 0));
         switch (sel) {
             case 0: rc = launch<128, 128, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
             case 1: rc = launch<128, 64, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;

@@ -26,8 +26,11 @@ def main():
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"])
     args = ap.parse_args()
     dev = torch.device("cuda")
+    from monopsr_amd import _lib
+    _lib.set_conv_math(args.math)
     cfg = config_utils.default_config()
     weights = W.synthetic_weights(seed=0, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
     net = dn.DeviceNet(weights, device=dev, full_trunk=True)
