@@ -335,6 +335,37 @@ def main():
                               "frac": round(achieved / peak, 4), "traffic": traffic if args.math == "fp32" else None,
                               "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
                               "flops_per_launch": round(flops / launches)}
+    if rank == 0 and not args.no_roofline:
+        # the Chamfer op alone, as the north star asks ("achieved HBM GB/s on nn_distance"): algorithmic bytes =
+        # b*(n+m)*20 forward (12 read + 8 written per point), b*(n+m)*32 backward; the kernel is VALU-bound, so the
+        # pair-evaluation rate is reported next to it
+        try:
+            from monopsr_amd.tf_ops.nn_distance import tf_nndistance as nnd
+            b, n = args.batch, args.points
+            c1 = torch.randn((b, n, 3), device=device)
+            c2 = torch.randn((b, n, 3), device=device)
+            ones = torch.ones((b, n), device=device)
+            d1, i1, d2, i2 = nnd.nn_distance(c1, c2)
+            nnd.nn_distance_grad(c1, c2, ones, i1, ones, i2)
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            reps = 20
+            ev[0].record()
+            for _ in range(reps):
+                nnd.nn_distance(c1, c2)
+            ev[1].record()
+            for _ in range(reps):
+                nnd.nn_distance_grad(c1, c2, ones, i1, ones, i2)
+            ev[2].record()
+            torch.cuda.synchronize()
+            tf_, tb_ = ev[0].elapsed_time(ev[1]) * 1e-3 / reps, ev[1].elapsed_time(ev[2]) * 1e-3 / reps
+            result["nn_distance"] = {
+                "shape": [b, n, n], "fwd_us": round(tf_ * 1e6, 1), "bwd_us": round(tb_ * 1e6, 1),
+                "fwd_alg_GBps": round(b * 2 * n * 20 / tf_ / 1e9, 1), "bwd_alg_GBps": round(b * 2 * n * 32 / tb_ / 1e9, 1),
+                "hbm_peak_GBps": 8000, "fwd_pair_evals_per_s": float("%.4g" % (2.0 * b * n * n / tf_)),
+                "bound": "valu (fwd), hbm/lds (bwd)"}
+        except Exception as e:
+            result["nn_distance"] = {"error": repr(e)}
     if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
         # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
         # on the same inputs (NOT the headline: `value` above is fp32)
