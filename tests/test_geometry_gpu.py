@@ -219,7 +219,7 @@ def test_format_boxes_vs_oracle():
 def test_model_train_outputs_and_loss_vs_oracle():
     """MonoPSRModel in 'train' mode on a 1/4-width net: global maps and every loss term vs the numpy restatement
     evaluated on the model's own head outputs; total = sum of terms; backward reaches the xyz-map head."""
-    from monopsr_amd.core import config_utils, constants, train_net, trainer
+    from monopsr_amd.core import config_utils, train_net, trainer
     from monopsr_amd.core import weights as W
     B, div = 5, 4
     cfg = config_utils.default_config()
