@@ -4,6 +4,8 @@ Same entry point, arguments and returned dict keys; the graph underneath is libm
 two ResNet-101 trunks (crop, full image) -> feature crop + 2x2 max-pool -> [concat] -> 1x1 squash ->
 2x2 max-pool (FEATURES_FOR_BOX_3D) / map decoder (FEATURES_FOR_MAP).
 """
+import torch
+
 from monopsr_amd.core import constants
 from monopsr_amd.core import device_net as dn
 
@@ -28,24 +30,42 @@ def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_
     net = model.device_net
     crop_img = input_dict[constants.NET_IN_RGB_CROP]
 
-    # BatchNorm runs on its moving statistics everywhere: the trunks are frozen in the reference too
-    # (faster_rcnn_resnet_v1_feature_extractor.py:63,238); the decoder's train-mode batch statistics
-    # (net_builder.py:78-79,86-87) are not implemented -- see DESIGN.md "out of scope".
-    crop_img_encoder_out = net.trunk(crop_img, 'crop')
-
+    # BatchNorm: the trunks run on their moving statistics (frozen in the reference too,
+    # faster_rcnn_resnet_v1_feature_extractor.py:63,238); the decoder's does so at inference and, in a trainable
+    # net built with decoder_bn='batch', uses batch statistics as net_builder.py:78-79,86-87 does when is_training.
     if constants.NET_IN_FULL_IMG_FEATURE_CROP in input_dict:
+        crop_img_encoder_out = net.trunk(crop_img, 'crop')
         full_img_feature_crop = input_dict[constants.NET_IN_FULL_IMG_FEATURE_CROP]
     else:
         full_img = input_dict[constants.NET_IN_FULL_IMG]
-        full_img_encoder_out = net.trunk(full_img, 'full')
-        # Crop and resize, then max pool the feature map from the full image (net_builder.py:54-60)
         half = (model.map_roi_size[0] // 2, model.map_roi_size[1] // 2)
-        # a trainable net brings differentiable versions of the two operators (the crop's image gradient feeds the
-        # full-image trunk's backward pass)
-        crop_and_resize = getattr(net, 'crop_and_resize', dn.crop_and_resize)
-        max_pool = getattr(net, 'max_pool', dn.max_pool)
-        full_img_feature_large_crop = crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
-        full_img_feature_crop = max_pool(full_img_feature_large_crop, 2, 2, "VALID")
+
+        def full_branch():
+            # full-image trunk, then crop and resize + max pool of its feature map (net_builder.py:46-60); a
+            # trainable net brings differentiable versions of the two operators (the crop's image gradient feeds
+            # the full-image trunk's backward pass)
+            crop_and_resize = getattr(net, 'crop_and_resize', dn.crop_and_resize)
+            max_pool = getattr(net, 'max_pool', dn.max_pool)
+            full_img_encoder_out = net.trunk(full_img, 'full')
+            large = crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
+            return max_pool(large, 2, 2, "VALID")
+
+        if hasattr(net, 'side_stream') and torch.cuda.is_available():
+            # Inference: the two trunks are independent and, at one image / a few dozen boxes, each leaves most
+            # CUs idle (M = 6080 and 32*144 rows) -- run the full-image branch on a second HIP stream next to the
+            # crop trunk.  (A trainable net keeps one stream: autograd replays the graph serially anyway.)
+            if net.side_stream is None:
+                net.side_stream = torch.cuda.Stream(device=crop_img.device)
+            main = torch.cuda.current_stream()
+            net.side_stream.wait_stream(main)
+            with torch.cuda.stream(net.side_stream):
+                full_img_feature_crop = full_branch()
+            crop_img_encoder_out = net.trunk(crop_img, 'crop')
+            main.wait_stream(net.side_stream)
+            full_img_feature_crop.record_stream(main)
+        else:
+            crop_img_encoder_out = net.trunk(crop_img, 'crop')
+            full_img_feature_crop = full_branch()
 
     # concat + 1x1 squash + pool + map decoder in one native call; the xyz-map head (a 3x3 conv on the map
     # features, monopsr_output_builder.py:95-104) rides along and is handed to the output builder

@@ -50,6 +50,8 @@ class DeviceNet:
         self.heads = PackedPart(*W.pack_heads(weights, feat_elems), self.device)
         self.feat_elems = feat_elems
         self.ws_trunk = Workspace(self.device)
+        self.ws_trunk_full = Workspace(self.device)  # own scratch: the two trunks may run on two streams at once
+        self.side_stream = None                      # created on first use (full-image branch, net_builder)
         self.ws_dec = Workspace(self.device)
         self.ws_heads = Workspace(self.device)
         self._weights = weights
@@ -62,6 +64,7 @@ class DeviceNet:
         other = copy.copy(self)
         other.ws_trunk, other.ws_dec, other.ws_heads = Workspace(self.device), Workspace(self.device), \
             Workspace(self.device)
+        other.ws_trunk_full, other.side_stream = Workspace(self.device), None
         return other
 
     # ------------------------------------------------------------------ single FC layers (output builder)
@@ -106,7 +109,7 @@ class DeviceNet:
         out = torch.empty((B, ph, pw, cout), dtype=torch.float32, device=self.device)
         lib = _lib.lib()
         nbytes = lib.mpsr_trunk_workspace_bytes(B, H, Wd)
-        ws = self.ws_trunk.get(nbytes)
+        ws = (self.ws_trunk if which == "crop" else self.ws_trunk_full).get(nbytes)
         _lib.check(lib.mpsr_trunk_fwd(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
                                       _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()))
         return out
