@@ -10,7 +10,12 @@ Everything runs through the C ABI of libmonopsr_hip.so on the current HIP stream
 in HBM before the timed region.  Multi-GPU: instances are sharded, one process per GPU, no data-path collective
 (weak scaling; `--allreduce-grads` adds an RCCL all-reduce of a gradient-sized buffer per step).
 
-Prints ONE JSON line on rank 0 (contract in the task description); `roofline` and `cpu_baseline` are extra objects.
+`--gpus N` with N > 1: under `python -m torch.distributed.run --nproc-per-node N` (WORLD_SIZE set) every process is
+one rank; started plainly (`python bench.py --gpus N`) this process only starts N rank processes of itself -- before
+torch is imported, so nothing here has touched a GPU -- waits for them and exits with their status.
+
+Prints ONE JSON line on rank 0 (contract in the task description); `roofline`, `cpu_baseline`, `nn_distance` and
+`emd` are extra objects.
 """
 import argparse
 import json
@@ -18,8 +23,56 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def _launch_ranks(argv):
+    """`bench.py --gpus N` outside a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment), wait, exit non-zero if any rank failed.  Runs before anything
+    GPU-related is imported; never re-executes a process that has initialised the GPU.  Returns only when this
+    process is itself a rank (N == 1, or a launcher already set WORLD_SIZE)."""
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    if n < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != n:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; launch with "
+                             "--nproc-per-node %d" % (n, os.environ["WORLD_SIZE"], n))
+        return
+    if n == 1:
+        return
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+    finally:
+        for p in procs:
+            if p.poll() is None:  # a rank died: do not leave its peers waiting in a collective
+                p.terminate()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or len(codes) != n:
+        raise SystemExit("bench.py: rank(s) failed (rank, exit code): %s" % bad)
+    raise SystemExit(0)
+
+
+if __name__ == "__main__":
+    _launch_ranks(sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -199,16 +252,45 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MPSR_BENCH_RENDEZVOUS_ONLY"):
+        # test hook (tests/test_bench_launch.py): the launch + rendezvous + max-over-ranks plumbing of an N-rank run
+        # on CPU (gloo), without the hot path
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.barrier()
+        dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "max_rank_plus_1": float(seen.item())}),
+                  flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # MPSR_BENCH_SHARE_GPU: test hook for 1-GPU boxes -- every rank computes on cuda:0 and the ranks meet over gloo
+    # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing, the N-rank code path does
+    share_gpu = bool(os.environ.get("MPSR_BENCH_SHARE_GPU"))
+    backend = "gloo" if share_gpu else "nccl"
+    if share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank,
+                                                                                torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("MPSR_BENCH_FORCE_DIST"):  # the env knob exercises the N > 1 code on one GPU
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world
+    red_dev = device if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
 
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
@@ -241,7 +323,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -267,7 +349,7 @@ def main():
                                (" + all-reduce(401 MB synthetic grad buffer)" if args.allreduce_grads else "")},
     }
 
-    if dist is not None and not args.allreduce_grads and not args.no_allreduce_probe:
+    if dist is not None and backend == "nccl" and not args.allreduce_grads and not args.no_allreduce_probe:
         # BASELINE config 4 adds "data-parallel RCCL all-reduce" to the sharded step.  The metric path itself has no
         # exchange (value above); this extra region repeats the step with an all-reduce of a buffer the size of the
         # model's fp32 gradient (100,204,832 floats, synthetic contents -- the forward path produces no parameter
@@ -291,7 +373,7 @@ def main():
                 ar_step()
             torch.cuda.synchronize()
             barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
             result["with_grad_allreduce"] = {
