@@ -21,14 +21,19 @@ class ReverseBucketReducer:
     trunk), so the first buckets are on the wire while the trunk is still back-propagating."""
 
     def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None):
+        """layer_spans[i]: the element range(s) of `flat` layer i's backward writes -- one (lo, hi) or a list of them
+        (weight gradient AND bias gradient: a bucket holding any part of either must wait for the layer)."""
         self.flat, self.group = flat, group
         n = max(1, bucket_bytes // flat.element_size())
         self.buckets = [(lo, min(lo + n, flat.numel())) for lo in range(0, flat.numel(), n)]
         # layers overlapping each bucket
         self.members = [set() for _ in self.buckets]
         self.layer_buckets = []
-        for li, (lo, hi) in enumerate(layer_spans):
-            ids = [bi for bi, (blo, bhi) in enumerate(self.buckets) if lo < bhi and hi > blo]
+        for li, spans in enumerate(layer_spans):
+            if spans and isinstance(spans[0], int):
+                spans = [spans]
+            ids = sorted({bi for lo, hi in spans for bi, (blo, bhi) in enumerate(self.buckets)
+                          if lo < bhi and hi > blo})
             self.layer_buckets.append(ids)
             for bi in ids:
                 self.members[bi].add(li)
@@ -122,9 +127,10 @@ class InstanceTrainer:
         self.global_step = 0
         self._clip = None
         spans = []
-        for L in net.layers:
-            lo = L.w.data_ptr() - net.params.data_ptr()
-            spans.append((lo // 4, lo // 4 + L.w.numel()))
+        base = net.grads.data_ptr()
+        for L in net.layers:  # everything a layer's backward deposits: weight gradient and bias / beta gradient
+            spans.append([((t.data_ptr() - base) // 4, (t.data_ptr() - base) // 4 + t.numel())
+                          for t in (L.dw, L.db) if t is not None])
         self.spans = spans
         self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group)
         for li, L in enumerate(net.layers):

@@ -63,6 +63,52 @@ def test_reverse_bucket_reducer_two_ranks():
     assert all(res.values()), res
 
 
+def _bias_worker(rank, world, port, q):
+    """Flat layout [w0 | b0 | w1 | b1] with a bucket boundary exactly between w0 and b0 (the bias slice then
+    sits in a bucket whose members must still include layer 0)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from monopsr_amd.core.trainer import ReverseBucketReducer
+        flat = torch.zeros(400)
+        spans = [[(0, 100), (100, 110)], [(110, 390), (390, 400)]]  # per layer: weight span, bias span
+        red = ReverseBucketReducer(flat, spans, bucket_bytes=100 * 4)
+        assert red.buckets == [(0, 100), (100, 200), (200, 300), (300, 400)]
+        assert red.members[1] == {0, 1}, red.members  # bucket [100,200) holds b0: it waits for layer 0 too
+        order = []
+        orig = red._launch
+        red._launch = lambda bi: (order.append(bi), orig(bi))[1]
+        # layer 1's backward completes first
+        flat[110:400] = float(rank + 1)
+        red.layer_ready(1)
+        launched_early = list(order)
+        # only now does layer 0 write its bias and weights
+        flat[0:110] = 10.0 * (rank + 1)
+        red.layer_ready(0)
+        red.finish(average=False)
+        tot = float(sum(range(1, world + 1)))
+        want = torch.cat([torch.full((110,), 10 * tot), torch.full((290,), tot)])
+        q.put((rank, bool(torch.equal(flat, want) and 1 not in launched_early and 0 not in launched_early
+                          and sorted(launched_early) == [2, 3])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_boundary_on_a_bias_slice():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bias_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert all(res.values()), res
+
+
 def test_reducer_single_process_is_a_noop():
     from monopsr_amd.core.trainer import ReverseBucketReducer
     flat = torch.arange(10, dtype=torch.float32)
