@@ -108,8 +108,14 @@ int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int
  *   w        (N, KH*KW*C) row-major: w[n][(ky*KW+kx)*C + c]  (the TF HWIO tensor transposed to O,HWI)
  *   bias     (N) or NULL;  residual (B,H,W,N) or NULL;  relu 0/1
  *   y        (B,H,W,N)
- *   split_k  >= 1; when > 1, `ws` must hold split_k*B*H*W*N floats (partial sums, reduced by a second kernel)
+ *   split_k  >= 1: one output tile per workgroup; when > 1 the K loop is cut into split_k slices, `ws` must hold
+ *            split_k*B*H*W*N floats (partial sums, reduced by a second kernel).
+ *            0: the library schedules the launch itself -- stream-K (persistent workgroups that each take the same
+ *            number of K steps of the launch's tile sequence; partial tiles meet in `ws`) when `ws` holds
+ *            mpsr_conv2d_scratch_floats(B,H,W,N) floats, otherwise as split_k = 1.  Results are deterministic for
+ *            a given shape and device, and equal to split_k = 1 up to fp32 summation order on the split tiles.
  * A fully-connected layer is H=W=KH=KW=1. */
+size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N);
 int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
                          const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                          int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mpsr_max_pool": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_conv2d_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                    c_sz, c_f]),
+    "mpsr_conv2d_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
     "mpsr_conv2d_wgrad_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
     "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -182,8 +182,9 @@ def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False
     B, H, Wd, C = x.shape
     N = w_ok.shape[0]
     y = torch.empty((B, H, Wd, N), dtype=torch.float32, device=x.device)
-    # split_k == 0: let the library cut an under-filled launch along K (up to 8 slices) inside this scratch
-    nws = (split_k if split_k > 1 else (8 if split_k == 0 else 0)) * B * H * Wd * N
+    # split_k == 0: the library schedules the launch itself (stream-K) inside this scratch
+    nws = split_k * B * H * Wd * N if split_k > 1 else (
+        _lib.lib().mpsr_conv2d_scratch_floats(B, H, Wd, N) if split_k == 0 else 0)
     ws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
     _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32(
         _lib.ptr(x), B, H, Wd, C, _lib.ptr(w_ok), _lib.ptr(bias.contiguous()) if bias is not None else None,

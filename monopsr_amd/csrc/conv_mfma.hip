@@ -29,6 +29,10 @@
 //     bit-identical to visiting the zero taps.
 //   * split_k > 1 writes raw partial tiles to a workspace; a second kernel reduces and applies the epilogue
 //     (used for the K = 18432 fully-connected layers where M = batch is small).
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -69,11 +73,12 @@ struct ConvParams {
     int ksteps_total, ksteps_per_split, cblocks;
     int mtiles_xcd, ntiles, splits;  // mtiles_xcd: M tiles per XCD (max over XCDs)
     unsigned xbytes, wbytes;
+    size_t ws_floats;
     int ncls;
     PixelClass cls[MAX_CLS];
 };
 
-template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -81,6 +86,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     constexpr int AV = BM / 32, BV = BN / 32;  // float4 loads per thread per tile
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE];
     float *As = lds, *Bs = lds + BM * LDS_STRIDE;
+#ifdef MPSR_TRACE
+    unsigned long long tr0 = __builtin_readcyclecounter(), tr1 = 0, tr2 = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness): XCD x takes M tiles
     // x, x+8, x+16, ... of EVERY pixel class -- so each XCD gets the same mix of long and short K loops -- and walks
@@ -159,24 +168,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         st_ky = pc.ky0 + ty;
         st_kx = pc.kx0 + (tap - ty * ntx);
     }
-    float4 ra[AV], rb[BV];
-    auto load_tile = [&]() {  // loads the tile of the current K-step state, then advances the state
+    // register staging: one tile in flight (DEPTH 1) or two (DEPTH 2: the loads of K step k + 2 are issued while step k
+    // computes, so a load has a whole K step of every resident wave to return -- what a launch's last tiles need,
+    // when only 2-4 waves per SIMD are left to hide the ~1.5 us the memory system takes under this load)
+    float4 ra[DEPTH][AV], rb[DEPTH][BV];
+    // loads the tile of the current K-step state into staging set `set` (a literal at every call), then advances
+    // the state; `live` false (past the last K step) turns every load into an out-of-range one (no traffic)
+    auto load_tile = [&](auto set_c, bool live) {
+        constexpr int set = decltype(set_c)::value;
         const int dy = (st_ky - (p.KH >> 1)) * p.dil, dx = (st_kx - (p.KW >> 1)) * p.dil;
         const int c = st_cb * BK + lcol;
-        const bool cok = c < p.C;
+        const bool cok = (c < p.C) & live;
         const int aoff = ((dy * p.W + dx) * p.C + c) * 4;
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
             const int yy = ay[j] + dy, xx = ax[j] + dx;
             const bool ok = cok & (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
             const unsigned off = ok ? abase[j] + (unsigned)aoff : p.xbytes;
-            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         const unsigned boff = (unsigned)(((st_ky * p.KW + st_kx) * p.C + c) * 4);
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
             const unsigned off = cok ? bbase[j] + boff : p.wbytes;
-            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+            rb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
         }
         if (++st_cb == p.cblocks) {
             st_cb = 0;
@@ -186,6 +201,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
             }
         }
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, DEPTH - 1>;
     // bf16x3: a row keeps its 144-byte stride: [32 hi bf16 | 32 lo bf16 | 16 B pad]
     auto store_split = [&](float *row, const float4 &v4) {
         const f32x4 v = {v4.x, v4.y, v4.z, v4.w};
@@ -195,16 +212,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         *reinterpret_cast<bf16x4 *>(r + lcol) = hi;
         *reinterpret_cast<bf16x4 *>(r + BK + lcol) = lo;
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
-            if constexpr (MATH == MATH_BF16X3) store_split(&As[(lrow + 32 * j) * LDS_STRIDE], ra[j]);
-            else *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDS_STRIDE + lcol]) = ra[j];
+            if constexpr (MATH == MATH_BF16X3) store_split(&As[(lrow + 32 * j) * LDS_STRIDE], ra[set][j]);
+            else *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDS_STRIDE + lcol]) = ra[set][j];
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
-            if constexpr (MATH == MATH_BF16X3) store_split(&Bs[(lrow + 32 * j) * LDS_STRIDE], rb[j]);
-            else *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDS_STRIDE + lcol]) = rb[j];
+            if constexpr (MATH == MATH_BF16X3) store_split(&Bs[(lrow + 32 * j) * LDS_STRIDE], rb[set][j]);
+            else *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDS_STRIDE + lcol]) = rb[set][j];
         }
     };
 
@@ -274,17 +292,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     // K loop; last tile peeled so the body has no conditional.  ks_begin >= ks_end only for an empty split-K slice
     // (block-uniform).
     if (ks_begin < ks_end) {
-        load_tile();
-        store_tile();
+        load_tile(Set0{}, true);
+        store_tile(Set0{});
         __syncthreads();
-        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
-            load_tile();
+#ifdef MPSR_TRACE
+        tr1 = __builtin_readcyclecounter();
+#endif
+        if constexpr (DEPTH == 1) {
+            for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+                load_tile(Set0{}, true);
+                compute_tile();
+                __syncthreads();
+                store_tile(Set0{});
+                __syncthreads();
+            }
             compute_tile();
-            __syncthreads();
-            store_tile();
-            __syncthreads();
+        } else {
+            // LDS holds step k; set 0 holds step k + 1 (in flight); two steps per trip, each staging set a literal
+            const int n = ks_end - ks_begin;
+            load_tile(Set0{}, n > 1);
+            int k = 0;
+            for (; k + 2 < n; k += 2) {
+                load_tile(Set1{}, true);  // step k + 2
+                compute_tile();
+                __syncthreads();
+                store_tile(Set0{});  // step k + 1
+                __syncthreads();
+                load_tile(Set0{}, k + 3 < n);  // step k + 3
+                compute_tile();
+                __syncthreads();
+                store_tile(Set1{});  // step k + 2
+                __syncthreads();
+            }
+            compute_tile();
+            if (n - k == 2) {  // block-uniform
+                __syncthreads();
+                store_tile(Set0{});
+                __syncthreads();
+                compute_tile();
+            }
         }
-        compute_tile();
     }
 
     // The 16-pass fp32 MFMA needs 18 wait states before its result is read.  hipcc (ROCm 7.2) was seen to place
@@ -295,6 +342,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
 
+#ifdef MPSR_TRACE
+    tr2 = __builtin_readcyclecounter();
+    auto trace_end = [&]() {
+        if (threadIdx.x == 0 && p.ws) {
+            unsigned long long *r = reinterpret_cast<unsigned long long *>(p.ws) + (size_t)blockIdx.x * 8;
+            r[0] = tr0; r[1] = tr1; r[2] = tr2; r[3] = __builtin_readcyclecounter();
+            r[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
+            r[5] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+            r[6] = rt0; r[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+#endif
     // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     const int col = lane & 31, rsub = (lane >> 5) * 4;
     float *dst = p.splits == 1 ? p.y : p.ws + (size_t)si * p.M * p.N;
@@ -342,6 +401,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+#ifdef MPSR_TRACE
+        trace_end();
+#endif
         return;
     }
     // scalar path (N not a multiple of 4: the 3-channel xyz head, the 27- and 2-wide head outputs)
@@ -382,6 +444,373 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         if (residual) v += residual[i];
         if (relu) v = fmaxf(v, 0.f);
         y[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stream-K
+// Persistent form of the same implicit GEMM.  A launch's work is the sequence of (tile, K step) "units" in tile order
+// (pixel classes heaviest first, the N tiles of an M tile back to back); exactly G = CUs x resident-workgroups-per-CU
+// workgroups are launched -- all resident at once -- and workgroup v takes the contiguous unit range
+// [bound(v), bound(v+1)), i.e. every workgroup gets the same number of K steps whatever the tile count, the class mix
+// or the tail.  (One tile per workgroup leaves the 12x12 layers' 2304 tiles on 1792 resident slots: the last 512 tiles
+// start when the first slots free up and the chip idles behind them.)
+// A range that ends inside a tile leaves a PARTIAL accumulator: it is written to the workgroup's slab, the
+// workgroup takes a ticket on the tile's arrival counter, and whichever contributor arrives LAST adds the partials in
+// K order (own registers in their place, so the sum does not depend on who was last) and runs the fused epilogue.
+// Nobody ever waits for another workgroup, so the kernel cannot deadlock whatever the residency turns out to be.
+// Inter-workgroup visibility follows cdna_hip_programming.md Guideline 16: plain slab stores, every wave drains
+// vmcnt, barrier, one lane's agent-scope release (+ an asm vmcnt(0) the compiler cannot drop) before the relaxed
+// agent-scope ticket; the last arriver's one lane does an agent-scope acquire, barrier, then plain loads.
+struct SkParams {
+    int G;                          // persistent workgroups, a multiple of 8
+    unsigned U;                     // units in the launch
+    unsigned q, r;                  // U = G * q + r: bound(v) = v * q + min(v, r)
+    float *slabs;                   // 2 slabs of BM * BN floats per workgroup (a partial that starts the workgroup's
+                                    // range: slot 0; one that ends it: slot 1)
+    int *counters;                  // one arrival counter per tile; zero on entry, zero again on exit
+    unsigned ubase[MAX_CLS + 1];    // first unit of class c
+    unsigned tbase[MAX_CLS + 1];    // first tile id of class c
+    int ks[MAX_CLS];                // K steps per tile of class c
+};
+
+__device__ __forceinline__ unsigned sk_bound(const SkParams &s, unsigned v) { return v * s.q + min(v, s.r); }
+
+// the workgroup whose range holds unit u (u < U)
+__device__ __forceinline__ unsigned sk_owner(const SkParams &s, unsigned u)
+{
+    const unsigned thr = s.r * (s.q + 1);
+    return u < thr ? u / (s.q + 1) : s.r + (u - thr) / s.q;
+}
+
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
+__global__ __launch_bounds__(256) void conv_sk_kernel(const ConvParams p, const SkParams sk)
+{
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AV = BM / 32, BV = BN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE + 4];
+    float *As = lds, *Bs = lds + BM * LDS_STRIDE;
+    int *flag = reinterpret_cast<int *>(lds + (BM + BN) * LDS_STRIDE);
+
+    // workgroup b is observed on XCD b % 8 (speed only): give each XCD one contiguous eighth of the unit sequence, so
+    // the workgroups sharing an L2 work on neighbouring M panels
+    const unsigned v = (blockIdx.x & 7) * ((unsigned)sk.G >> 3) + (blockIdx.x >> 3);
+    const unsigned ustart = sk_bound(sk, v), uend = sk_bound(sk, v + 1);
+    unsigned u = ustart;
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.wbytes, 0x00020000);
+    const int Ktot = p.KH * p.KW * p.C;
+
+    while (u < uend) {
+        // the thread id is made opaque per segment so that nothing derived from it is hoisted out of this loop and
+        // kept alive across it (that costs 14-20 VGPRs, i.e. one to two waves per SIMD of occupancy)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+        const int frag = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
+        const float *Aw = As + (wm * TM * 32) * LDS_STRIDE + frag;
+        const float *Bw = Bs + (wn * TN * 32) * LDS_STRIDE + frag;
+        int ci = 0;
+        while (u >= sk.ubase[ci + 1]) ++ci;
+        const PixelClass pc = p.cls[ci];
+        const int ksc = sk.ks[ci];
+        const unsigned local = u - sk.ubase[ci];
+        const unsigned tic = local / (unsigned)ksc;  // tile inside its class
+        const int ks_begin = (int)(local - tic * (unsigned)ksc);
+        const int ks_end = min(ksc, ks_begin + (int)(uend - u));
+        const int mt = (int)(tic / (unsigned)p.ntiles), ni = (int)(tic - (unsigned)mt * (unsigned)p.ntiles);
+        const int r0 = mt * BM, n0 = ni * BN;
+        const int ppi = pc.h * pc.w;
+        const int ntx = pc.kx1 - pc.kx0 + 1;
+
+        auto decode = [&](int row, int &yy, int &xx) -> int {
+            if (row >= pc.rows) {
+                yy = -(1 << 20);
+                xx = 0;
+                return -1;
+            }
+            const int img = row / ppi, pp = row - img * ppi;
+            const int py = pp / pc.w;
+            yy = pc.y0 + py;
+            xx = pc.x0 + (pp - py * pc.w);
+            return (img * p.H + yy) * p.W + xx;
+        };
+        int ay[AV], ax[AV];
+        unsigned abase[AV];
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            const int pix = decode(r0 + lrow + 32 * j, ay[j], ax[j]);
+            abase[j] = (unsigned)(pix < 0 ? 0 : pix) * (unsigned)p.C * 4u;
+        }
+        unsigned bbase[BV];
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            const int n = n0 + lrow + 32 * j;
+            bbase[j] = n < p.N ? (unsigned)n * (unsigned)Ktot * 4u : p.wbytes;
+        }
+        int st_cb, st_kx, st_ky;
+        {
+            const int tap = ks_begin / p.cblocks;
+            st_cb = ks_begin - tap * p.cblocks;
+            const int ty = tap / ntx;
+            st_ky = pc.ky0 + ty;
+            st_kx = pc.kx0 + (tap - ty * ntx);
+        }
+        float4 ra[AV], rb[BV];
+        auto load_tile = [&]() {
+            const int dy = (st_ky - (p.KH >> 1)) * p.dil, dx = (st_kx - (p.KW >> 1)) * p.dil;
+            const int c = st_cb * BK + lcol;
+            const bool cok = c < p.C;
+            const int aoff = ((dy * p.W + dx) * p.C + c) * 4;
+#pragma unroll
+            for (int j = 0; j < AV; ++j) {
+                const int yy = ay[j] + dy, xx = ax[j] + dx;
+                const bool ok = cok & (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
+                const unsigned off = ok ? abase[j] + (unsigned)aoff : p.xbytes;
+                ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            }
+            const unsigned boff = (unsigned)(((st_ky * p.KW + st_kx) * p.C + c) * 4);
+#pragma unroll
+            for (int j = 0; j < BV; ++j) {
+                const unsigned off = cok ? bbase[j] + boff : p.wbytes;
+                rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+            }
+            if (++st_cb == p.cblocks) {
+                st_cb = 0;
+                if (++st_kx > pc.kx1) {
+                    st_kx = pc.kx0;
+                    ++st_ky;
+                }
+            }
+        };
+        auto store_split = [&](float *row, const float4 &v4) {
+            const f32x4 vv = {v4.x, v4.y, v4.z, v4.w};
+            const bf16x4 hi = __builtin_convertvector(vv, bf16x4);
+            const bf16x4 lo = __builtin_convertvector(vv - __builtin_convertvector(hi, f32x4), bf16x4);
+            __bf16 *r = reinterpret_cast<__bf16 *>(row);
+            *reinterpret_cast<bf16x4 *>(r + lcol) = hi;
+            *reinterpret_cast<bf16x4 *>(r + BK + lcol) = lo;
+        };
+        auto store_tile = [&]() {
+#pragma unroll
+            for (int j = 0; j < AV; ++j) {
+                if constexpr (MATH == MATH_BF16X3) store_split(&As[(lrow + 32 * j) * LDS_STRIDE], ra[j]);
+                else *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDS_STRIDE + lcol]) = ra[j];
+            }
+#pragma unroll
+            for (int j = 0; j < BV; ++j) {
+                if constexpr (MATH == MATH_BF16X3) store_split(&Bs[(lrow + 32 * j) * LDS_STRIDE], rb[j]);
+                else *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDS_STRIDE + lcol]) = rb[j];
+            }
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        auto compute_tile = [&]() {
+            if constexpr (MATH == MATH_BF16X3) {
+                const __bf16 *Ah = reinterpret_cast<const __bf16 *>(As + (wm * TM * 32 + (lane & 31)) * LDS_STRIDE) +
+                                   (lane >> 5) * 8;
+                const __bf16 *Bh = reinterpret_cast<const __bf16 *>(Bs + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE) +
+                                   (lane >> 5) * 8;
+#pragma unroll
+                for (int sl = 0; sl < BK / 16; ++sl) {
+                    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDS_STRIDE * 2 + sl * 16);
+                        al[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDS_STRIDE * 2 + BK + sl * 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDS_STRIDE * 2 + sl * 16);
+                        bl[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDS_STRIDE * 2 + BK + sl * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+                return;
+            }
+#pragma unroll
+            for (int kb = 0; kb < BK / 8; ++kb) {
+                float4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(Aw + i * 32 * LDS_STRIDE + kb * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bw + j * 32 * LDS_STRIDE + kb * 8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        };
+
+        // K loop over this segment (always at least one step)
+        load_tile();
+        store_tile();
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+            load_tile();
+            compute_tile();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        compute_tile();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
+
+        const unsigned seg_first = u;
+        u += (unsigned)(ks_end - ks_begin);
+        bool finish = true;  // this workgroup runs the tile's epilogue
+        // partial tile: publish the raw accumulators, take a ticket; the last arriver reduces in the epilogue
+        int pieces = 1;
+        unsigned t0 = 0, vfirst = 0;
+        if (ks_begin != 0 || ks_end != ksc) {
+            t0 = sk.ubase[ci] + tic * (unsigned)ksc;
+            vfirst = sk_owner(sk, t0);
+            pieces = (int)(sk_owner(sk, t0 + (unsigned)ksc - 1) - vfirst) + 1;
+            int *cnt = sk.counters + (sk.tbase[ci] + tic);
+            float *slab = sk.slabs + (size_t)(2 * v + (seg_first == ustart ? 0 : 1)) * (BM * BN);
+            // lane-major float4: [wave][i][j][e / 4][lane]
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float4 val = make_float4(acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2],
+                                                       acc[i][j][4 * e4 + 3]);
+                        *reinterpret_cast<float4 *>(slab + ((((wave * TM + i) * TN + j) * 4 + e4) * 64 + lane) * 4) = val;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            finish = *flag == pieces - 1;
+            if (finish) {
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
+                }
+                __syncthreads();
+            }
+        }
+        // accumulator tile (i, j) of this wave: its own registers for a whole tile; for a split tile the K-ordered
+        // sum of every contributor's slab, this workgroup's own included (stored above) -- the same sum whoever
+        // arrives last, and only one 32x32 tile of it is live at a time
+        auto tile_values = [&](int i, int j, const f32x16 &own) -> f32x16 {
+            if (pieces == 1) return own;
+            f32x16 t;
+            for (int qq = 0; qq < pieces; ++qq) {
+                const unsigned vq = vfirst + (unsigned)qq;
+                const float *src = sk.slabs + (size_t)(2 * vq + (sk_bound(sk, vq) < t0 ? 1 : 0)) * (BM * BN) +
+                                   (((wave * TM + i) * TN + j) * 4 * 64 + lane) * 4;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 val = *reinterpret_cast<const float4 *>(src + e4 * 256);
+                    if (qq == 0) {
+                        t[4 * e4] = val.x; t[4 * e4 + 1] = val.y; t[4 * e4 + 2] = val.z; t[4 * e4 + 3] = val.w;
+                    } else {
+                        t[4 * e4] += val.x; t[4 * e4 + 1] += val.y; t[4 * e4 + 2] += val.z; t[4 * e4 + 3] += val.w;
+                    }
+                }
+            }
+            return t;
+        };
+
+        if (finish) {
+            const int col = lane & 31, rsub = (lane >> 5) * 4;
+            int dy_, dx_;
+            if ((p.N & 3) == 0) {
+                __syncthreads();  // every wave is done with the last A/B tile
+                float *ep = lds + wave * (32 * LDS_STRIDE);
+                const int erow = lane >> 3, ecol = (lane & 7) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int pix[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) pix[it] = decode(r0 + (wm * TM + i) * 32 + erow + 8 * it, dy_, dx_);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + (wn * TN + j) * 32 + ecol;
+                        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.bias && n < p.N) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+                        const f32x16 tv = tile_values(i, j, acc[i][j]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + rsub) * LDS_STRIDE + col] = tv[e];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            float4 vv = *reinterpret_cast<const float4 *>(&ep[(erow + 8 * it) * LDS_STRIDE + ecol]);
+                            if (pix[it] >= 0 && n < p.N) {
+                                const size_t o = (size_t)pix[it] * p.N + n;
+                                vv.x += bias.x; vv.y += bias.y; vv.z += bias.z; vv.w += bias.w;
+                                if (p.residual) {
+                                    const float4 rr = *reinterpret_cast<const float4 *>(p.residual + o);
+                                    vv.x += rr.x; vv.y += rr.y; vv.z += rr.z; vv.w += rr.w;
+                                }
+                                if (p.relu) {
+                                    vv.x = fmaxf(vv.x, 0.f); vv.y = fmaxf(vv.y, 0.f);
+                                    vv.z = fmaxf(vv.z, 0.f); vv.w = fmaxf(vv.w, 0.f);
+                                }
+                                *reinterpret_cast<float4 *>(p.y + o) = vv;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + (wn * TN + j) * 32 + col;
+                        const f32x16 tv = tile_values(i, j, acc[i][j]);
+                        if (n >= p.N) continue;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int pix = decode(r0 + (wm * TM + i) * 32 + rsub + (e & 3) + 8 * (e >> 2), dy_, dx_);
+                            if (pix < 0) continue;
+                            const size_t o = (size_t)pix * p.N + n;
+                            float vv = tv[e];
+                            if (p.bias) vv += p.bias[n];
+                            if (p.residual) vv += p.residual[o];
+                            if (p.relu) vv = fmaxf(vv, 0.f);
+                            p.y[o] = vv;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // LDS (tiles, epilogue slices, flag) is reused by the next segment
     }
 }
 
@@ -432,23 +861,119 @@ void build_classes(ConvParams &p, int B, int BM, bool use_classes)
     for (int i = 0; i < p.ncls; ++i) p.mtiles_xcd += mpsr::ceil_div(p.cls[i].tiles, 8);
 }
 
-template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1>
 int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
 {
     build_classes(p, B, BM, use_classes);
     p.ntiles = mpsr::ceil_div(p.N, BN);
     const long long blocks = 8LL * p.mtiles_xcd * p.ntiles * p.splits;
     if (blocks > 0x7fffffffLL) return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv2d: grid too large");
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     MPSR_CHECK_LAUNCH("conv_igemm_kernel");
     return MPSR_OK;
 }
 
+// Resident workgroups of a stream-K instantiation: CUs x workgroups per CU, from the occupancy query, once per device
+// and instantiation.  The query can be one per CU too high for SGPR-heavy kernels (MI355X_MICROARCH.md); the kernel
+// never waits on another workgroup, so an over-estimate only costs balance, not correctness.
+struct SkSlots {
+    std::once_flag once[16];
+    int slots[16] = {0};
+};
+
+template <int BM, int BN, int WM, int WN, int MATH>
+int sk_slots(int &out)
+{
+    static SkSlots cache;
+    int dev = 0;
+    MPSR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) dev = 0;
+    hipError_t err = hipSuccess;
+    std::call_once(cache.once[dev], [&]() {
+        int per_cu = 0, cus = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, reinterpret_cast<const void *>(conv_sk_kernel<BM, BN, WM, WN, MATH>), 256, 0);
+        if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (err == hipSuccess && per_cu > 0 && cus > 0) cache.slots[dev] = per_cu * cus;
+    });
+    if (err != hipSuccess) return mpsr::fail(MPSR_ERR_HIP, "stream-K occupancy query: %s", hipGetErrorString(err));
+    out = cache.slots[dev] > 0 ? cache.slots[dev] : 256 * 4;
+    return MPSR_OK;
+}
+
 // tuning knobs (tests sweep them): tile -1 = heuristic, 0=128x128 1=128x64 2=64x128 3=64x64 4=128x32 5=96x128;
-// classes -1 = heuristic, 0 = never, 1 = whenever the geometry allows
-int g_tile_override = -1;
-int g_class_override = -1;
-int g_math = MATH_FP32;  // mpsr_set_conv_math
+// classes -1 = heuristic, 0 = never, 1 = whenever the geometry allows;
+// sched -1 = heuristic, 0 = one tile per workgroup, 1 = stream-K;
+// sk_per_cu > 0 overrides the resident-workgroups-per-CU figure of the occupancy query, < 0 sets the workgroup count
+std::atomic<int> g_tile_override{-1};
+std::atomic<int> g_class_override{-1};
+std::atomic<int> g_sched_override{-1};
+std::atomic<int> g_sk_per_cu{0};
+std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
+std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
+
+// Scratch a stream-K launch needs behind `ws`: two partial-tile slabs per workgroup, then one counter per tile.
+inline size_t sk_scratch_floats(int G, int BM, int BN, long long tiles)
+{
+    return (size_t)G * 2 * BM * BN + (size_t)tiles;
+}
+
+// Returns MPSR_OK and sets `done` when the layer was launched in stream-K form; leaves `done` false when the scratch
+// is too small (the caller then takes the one-tile-per-workgroup kernel).
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32>
+int launch_sk(ConvParams &p, int B, bool use_classes, int mode, bool counters_clean, hipStream_t s, bool &done)
+{
+    done = false;
+    build_classes(p, B, BM, use_classes);
+    p.ntiles = mpsr::ceil_div(p.N, BN);
+    p.splits = 1;
+    SkParams sk;
+    unsigned long long U = 0, T = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+        const PixelClass &pc = p.cls[c];
+        sk.ks[c] = (pc.ky1 - pc.ky0 + 1) * (pc.kx1 - pc.kx0 + 1) * p.cblocks;
+        sk.ubase[c] = (unsigned)U;
+        sk.tbase[c] = (unsigned)T;
+        const unsigned long long tiles = (unsigned long long)pc.tiles * p.ntiles;
+        T += tiles;
+        U += tiles * sk.ks[c];
+    }
+    for (int c = p.ncls; c <= MAX_CLS; ++c) {
+        sk.ubase[c] = (unsigned)U;
+        sk.tbase[c] = (unsigned)T;
+        if (c < MAX_CLS) sk.ks[c] = 1;
+    }
+    if (U == 0 || U > 0x7fffffffULL || T > 0x7fffffffULL) return MPSR_OK;
+    int slots = 0;
+    if (int rc = sk_slots<BM, BN, WM, WN, MATH>(slots)) return rc;
+    const int per_cu = g_sk_per_cu.load();  // tuning: > 0 workgroups per CU, < 0 absolute workgroup count
+    if (per_cu > 0) {
+        int dev = 0, cus = 256;
+        MPSR_CHECK_HIP(hipGetDevice(&dev));
+        MPSR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        slots = per_cu * cus;
+    } else if (per_cu < 0) {
+        slots = -per_cu;
+    }
+    // every workgroup should keep at least ~4 K steps; G a multiple of 8 (one eighth of the sequence per XCD)
+    long long G = slots;
+    if (G > (long long)(U / 4)) G = (long long)(U / 4);
+    G = G / 8 * 8;
+    if (G < 8) G = 8;
+    while (G > 8 && sk_scratch_floats((int)G, BM, BN, (long long)T) > (p.ws ? p.ws_floats : 0)) G -= 8;
+    if (!p.ws || sk_scratch_floats((int)G, BM, BN, (long long)T) > p.ws_floats) return MPSR_OK;
+    sk.G = (int)G;
+    sk.U = (unsigned)U;
+    sk.q = (unsigned)(U / G);
+    sk.r = (unsigned)(U % G);
+    sk.slabs = p.ws;
+    sk.counters = reinterpret_cast<int *>(p.ws + (size_t)G * 2 * BM * BN);
+    if (!counters_clean) MPSR_CHECK_HIP(hipMemsetAsync(sk.counters, 0, sizeof(int) * (size_t)T, s));
+    hipLaunchKernelGGL((conv_sk_kernel<BM, BN, WM, WN, MATH>), dim3((unsigned)G), dim3(256), 0, s, p, sk);
+    MPSR_CHECK_LAUNCH("conv_sk_kernel");
+    done = true;
+    return MPSR_OK;
+}
 
 }  // namespace
 
@@ -457,13 +982,20 @@ namespace mpsr {
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s);  // image_ops.hip
 
-// split_k == 0 ("auto"): a launch whose 64x64 tiles would leave most of the 256 CUs with one workgroup or none
-// (32 proposal crops: M = 4608; the 40x152 full-image map: M = 6080) is cut along K so that ~3 workgroups per CU
-// exist, each keeping at least 4 K steps; bounded by the scratch the caller provides.  kAutoSplitFloats covers every
-// case the rule can produce: (768 + tiles) * 64 * 64 floats with tiles < 768.
-// Measured at 32 crops (tools/conv_layer_bench.py --batch 32 --split 0): 768 workgroups / >= 4 K steps per slice is
-// the sweet spot (conv time 5.02 -> 4.47 ms); asking for 1536+ workgroups loses again to partial-sum traffic.
+// Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
+//  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
+//    instantiation by 8 workgroups/CU x 64x64 or 4/CU x 96x128 / 128x64 or 3/CU x 128x128 on 256 CUs, i.e.
+//    1024 x 2 x 96 x 128 floats, plus (ceil(M / 64) + 9) * ceil(N / 32) counters (smallest tile, 9 pixel classes);
+//  * the older automatic split-K of the one-tile-per-workgroup kernel (kept for callers whose scratch is smaller):
+//    a launch whose 64x64 tiles would leave most CUs with one workgroup or none is cut along K so that ~3 workgroups
+//    per CU exist, each keeping at least 4 K steps: (768 + tiles) * 64 * 64 floats with tiles < 768.
 size_t conv_auto_split_floats() { return (size_t)1536 * 64 * 64; }
+size_t conv_scratch_floats(long long M, int N)
+{
+    const size_t slabs = (size_t)1024 * 2 * 96 * 128;
+    const size_t counters = (size_t)((M + 63) / 64 + 9) * (size_t)((N + 31) / 32);
+    return slabs + counters;
+}
 
 constexpr int g_auto_split_target = 768;  // workgroups wanted per launch
 constexpr int g_auto_split_min_ksteps = 4;
@@ -500,15 +1032,61 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // N <= 4 3x3 layers (the xyz-map head) are input-bandwidth-bound: direct VALU kernel instead of a 32-wide MFMA
     // tile (an explicit tile override keeps them on the MFMA path so tests cover both)
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
-        g_tile_override < 0 && ((uintptr_t)w & 3) == 0)
+        g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
         return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream);
     ConvParams p;
-    p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws;
+    p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;
     p.xbytes = (unsigned)(M64 * C * 4);
     p.wbytes = (unsigned)((long long)N * KH * KW * C * 4);
     p.cblocks = ceil_div(C, BK);
     p.ksteps_total = KH * KW * p.cblocks;
+    // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little)
+    bool use_classes = KH == 3 && KW == 3 && dilation > 1;
+    const int class_override = g_class_override.load(), tile_override = g_tile_override.load();
+    const int math = g_math.load();
+    if (class_override == 0) use_classes = false;
+    if (class_override == 1) use_classes = KH == 3 && KW == 3;
+    int sel = tile_override;
+    if (sel < 0) {
+        // measured on MI355X (tools/conv_layer_bench.py --rounds, profiles/): 128x128 wins once there are >= ~18 tiles
+        // per CU (the 24x24 / 48x48 decoder layers, 130-138 TFLOP/s); the 12x12 trunk layers (M = 36864 at B = 256)
+        // only make 2.25 tiles of 128x128 per CU, so 64x64 tiles (9 per CU, 7 waves/SIMD) balance and overlap
+        // better; the wide 1x1 layers among them (block3 conv1 / shortcut, squash: C >= 512, N a multiple of 128)
+        // take 96x128 tiles -- 3 per CU, all resident at once, 40 % less L2 -> LDS traffic per multiply-add
+        if (N <= 32) sel = 4;
+        else if (p.M >= 131072) sel = 0;
+        else if (KH == 1 && KW == 1 && C >= 512 && N >= 256 && N % 128 == 0 && p.M >= 24576 && math == MATH_FP32) sel = 5;
+        else sel = 3;
+        // bf16x3: 3 bf16 matrix instructions replace 8 fp32 ones at 1/16 of the cycles each, so LDS and the operand
+        // split feed the matrix pipes: larger wave tiles (fewer fragment reads per instruction) win -- 128x128 on the
+        // big decoder maps, 128x64 on the 12x12 trunk layers (tools/conv_layer_bench.py --math bf16x3); small
+        // batches -- a single image's 32 crops -- need the small tile to have workgroups for every CU
+        if (math == MATH_BF16X3) sel = N <= 32 ? 4 : (p.M < 16384 ? 3 : ((N <= 64 || p.M < 131072) ? 1 : 0));
+    }
+    // schedule: stream-K only where it measured faster than the alternatives -- fully-connected layers with a very
+    // long K and few rows (img_fc: 256 x 18432 x 2048: 216 us against 358 us for sliced K + a reduce kernel); on the
+    // convolution layers its partial-tile hand-offs cost more than the balance buys
+    int sched = g_sched_override.load();
+    if (sched < 0) sched = (split_k == 0 && ws && p.M <= 2048 && p.ksteps_total >= 128) ? 1 : 0;
+    if (sched == 1 && split_k <= 1 && ws) {
+        bool done = false;
+        int rc = MPSR_OK;
+#define MPSR_SK(BM_, BN_, WM_, WN_)                                                                               \
+    rc = math == MATH_BF16X3 ? launch_sk<BM_, BN_, WM_, WN_, MATH_BF16X3>(p, B, use_classes, sched, false, stream, done) \
+                             : launch_sk<BM_, BN_, WM_, WN_, MATH_FP32>(p, B, use_classes, sched, false, stream, done)
+        switch (sel) {
+            case 0: MPSR_SK(128, 128, 2, 2); break;
+            case 1: MPSR_SK(128, 64, 2, 2); break;
+            case 2: MPSR_SK(64, 128, 2, 2); break;
+            case 3: MPSR_SK(64, 64, 2, 2); break;
+            case 5: MPSR_SK(96, 128, 1, 4); break;
+            default: MPSR_SK(128, 32, 4, 1); break;
+        }
+#undef MPSR_SK
+        if (rc) return rc;
+        if (done) return MPSR_OK;
+    }
     if (split_k == 0) split_k = auto_split_k(p.M, N, p.ksteps_total, ws, ws_floats);  // fill an under-filled launch
     if (split_k < 1) split_k = 1;
     if (split_k > p.ksteps_total) split_k = p.ksteps_total;
@@ -519,44 +1097,24 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
             return fail(MPSR_ERR_WORKSPACE, "conv2d: split_k=%d needs %zu workspace floats, got %zu", p.splits,
                         (size_t)p.splits * p.M * N, ws_floats);
     }
-    // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little)
-    bool use_classes = KH == 3 && KW == 3 && dilation > 1;
-    if (g_class_override == 0) use_classes = false;
-    if (g_class_override == 1) use_classes = KH == 3 && KW == 3;
     int rc;
-    int sel = g_tile_override;
-    if (sel < 0) {
-        // measured on MI355X (tools/conv_layer_bench.py, profiles/): 128x128 wins once there are >= ~18 tiles per CU
-        // (the 24x24 / 48x48 decoder layers, 130-137 TFLOP/s); the 12x12 trunk layers (M = 36864 at B = 256) only
-        // make 2.25 tiles of 128x128 per CU, so 64x64 tiles (9 per CU, 7 waves/SIMD) balance and overlap better
-        if (N <= 32) sel = 4;
-        else if (p.M < 131072) sel = 3;
-        else sel = 0;
+    // two staging register sets (loads two K steps ahead) pay on the atrous 3x3 layers of the trunk (block3 conv2:
+    // 228 -> 213 us) and with the 96x128 tile at N = 256; elsewhere the lost occupancy costs as much as it buys
+    int depth = g_depth_override.load();
+    if (depth < 0) depth = ((sel == 3 && use_classes) || (sel == 5 && N <= 256)) ? 2 : 1;
+#define MPSR_TILE(BM_, BN_, WM_, WN_)                                                                        \
+    rc = math == MATH_BF16X3 ? launch<BM_, BN_, WM_, WN_, MATH_BF16X3>(p, B, use_classes, stream)           \
+         : depth == 2        ? launch<BM_, BN_, WM_, WN_, MATH_FP32, 2>(p, B, use_classes, stream)          \
+                             : launch<BM_, BN_, WM_, WN_, MATH_FP32, 1>(p, B, use_classes, stream)
+    switch (sel) {
+        case 0: MPSR_TILE(128, 128, 2, 2); break;
+        case 1: MPSR_TILE(128, 64, 2, 2); break;
+        case 2: MPSR_TILE(64, 128, 2, 2); break;
+        case 3: MPSR_TILE(64, 64, 2, 2); break;
+        case 5: MPSR_TILE(96, 128, 1, 4); break;
+        default: MPSR_TILE(128, 32, 4, 1); break;
     }
-    if (g_math == MATH_BF16X3) {
-        // 3 bf16 matrix instructions replace 8 fp32 ones at 1/16 of the cycles each, so LDS and the operand split
-        // feed the matrix pipes: larger wave tiles (fewer fragment reads per instruction) win -- 128x128 on the big
-        // decoder maps, 128x64 on the 12x12 trunk layers (tools/conv_layer_bench.py --math bf16x3)
-        // (small batches -- a single image's 32 crops -- need the small tile to have workgroups for every CU)
-        if (g_tile_override < 0) sel = N <= 32 ? 4 : (p.M < 16384 ? 3 : ((N <= 64 || p.M < 131072) ? 1 : 0));
-        switch (sel) {
-            case 0: rc = launch<128, 128, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
-            case 1: rc = launch<128, 64, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
-            case 2: rc = launch<64, 128, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
-            case 3: rc = launch<64, 64, 2, 2, MATH_BF16X3>(p, B, use_classes, stream); break;
-            case 5: rc = launch<96, 128, 1, 4, MATH_BF16X3>(p, B, use_classes, stream); break;
-            default: rc = launch<128, 32, 4, 1, MATH_BF16X3>(p, B, use_classes, stream); break;
-        }
-    } else {
-        switch (sel) {
-            case 0: rc = launch<128, 128, 2, 2>(p, B, use_classes, stream); break;
-            case 1: rc = launch<128, 64, 2, 2>(p, B, use_classes, stream); break;
-            case 2: rc = launch<64, 128, 2, 2>(p, B, use_classes, stream); break;
-            case 3: rc = launch<64, 64, 2, 2>(p, B, use_classes, stream); break;
-            case 5: rc = launch<96, 128, 1, 4>(p, B, use_classes, stream); break;
-            default: rc = launch<128, 32, 4, 1>(p, B, use_classes, stream); break;
-        }
-    }
+#undef MPSR_TILE
     if (rc) return rc;
     if (p.splits > 1) {
         const long long MN = (long long)p.M * N;
@@ -574,6 +1132,12 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 // and for the tests that sweep every instantiation.  Process-wide, not thread-safe.
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
 extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
+extern "C" void mpsr_debug_set_conv_depth(int depth) { g_depth_override = depth; }
+extern "C" void mpsr_debug_set_conv_sched(int mode, int per_cu)
+{
+    g_sched_override = mode;
+    g_sk_per_cu = per_cu;
+}
 
 extern "C" int mpsr_set_conv_math(int mode)
 {
@@ -583,10 +1147,108 @@ extern "C" int mpsr_set_conv_math(int mode)
 }
 extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
+extern "C" size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || N <= 0) return 0;
+    return mpsr::conv_scratch_floats((long long)B * H * W, N);
+}
+
 extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
                                     const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                                     int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream)
 {
     return mpsr::conv2d(x, B, H, W, C, w, bias, residual, y, N, KH, KW, dilation, relu, split_k, ws, ws_floats,
                         mpsr::as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ calibration
+// What this box's matrix pipes sustain in fp32: nothing but v_mfma_f32_32x32x2_f32 on `chains` independent
+// accumulators per wave (1 = one dependent chain, like a 32x32 wave tile; 4 = like a 64x64 wave tile).  MI355X boards
+// differ in sustained clock under this load by up to ~20 % (power capping), so bench.py and the tuning tools quote
+// kernel rates next to this figure measured in the same process, not only next to the 2.4 GHz datasheet peak.
+namespace {
+template <int CHAINS>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, float a0, float b0)
+{
+    f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16 / CHAINS; ++r)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[c][e];
+    if (s == 12345.678f) out[0] = s;  // keeps the chain live; never true for the inputs used
+}
+}  // namespace
+
+namespace {
+// The K loop's instruction mix without its memory traffic: per step 8 ds_read_b128 feeding 16 dependent MFMAs, waits
+// placed as hipcc places them in conv_igemm_kernel<64,64> (MODE 1), or reads issued but never waited for (MODE 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_lds_kernel(float *out, int iters)
+{
+    __shared__ __attribute__((aligned(16))) float lds[128 * LDS_STRIDE];
+    for (int i = threadIdx.x; i < 128 * LDS_STRIDE; i += 256) lds[i] = 1e-3f * (float)(i & 15);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *Aw = lds + ((wave >> 1) * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const float *Bw = lds + (64 + (wave & 1) * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 a = *reinterpret_cast<const f32x4 *>(Aw + kb * 8 + (i & 1) * 4);
+            f32x4 b = *reinterpret_cast<const f32x4 *>(Bw + kb * 8 + (i & 1) * 4);
+            if (MODE == 0) {
+                asm volatile("" ::"v"(a), "v"(b));
+                a = keep;
+                b = keep;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[e];
+    if (s == 12345.678f) out[0] = s;
+}
+}  // namespace
+
+extern "C" int mpsr_debug_mfma_lds(float *out, int cus, int waves_per_simd, int mode, int iters, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0, "mfma_lds: bad arguments");
+    const dim3 grid((unsigned)(cus * waves_per_simd));
+    if (mode == 0) hipLaunchKernelGGL(mfma_lds_kernel<0>, grid, dim3(256), 0, mpsr::as_stream(stream), out, iters);
+    else hipLaunchKernelGGL(mfma_lds_kernel<1>, grid, dim3(256), 0, mpsr::as_stream(stream), out, iters);
+    MPSR_CHECK_LAUNCH("mfma_lds_kernel");
+    return MPSR_OK;
+}
+
+// Launches `waves_per_simd` waves on every SIMD of `cus` CUs, each issuing iters * 16 MFMAs.  The caller times it
+// (FLOP = cus * 4 * waves_per_simd * iters * 16 * 4096).
+extern "C" int mpsr_debug_mfma_peak(float *out, int cus, int waves_per_simd, int chains, int iters, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 && (chains == 1 || chains == 4),
+                 "mfma_peak: bad arguments");
+    const dim3 grid((unsigned)(cus * waves_per_simd));
+    if (chains == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, grid, dim3(256), 0, mpsr::as_stream(stream), out, iters, 1.f, 1e-3f);
+    else hipLaunchKernelGGL(mfma_peak_kernel<4>, grid, dim3(256), 0, mpsr::as_stream(stream), out, iters, 1.f, 1e-3f);
+    MPSR_CHECK_LAUNCH("mfma_peak_kernel");
+    return MPSR_OK;
 }

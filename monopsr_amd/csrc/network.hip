@@ -10,7 +10,7 @@ namespace mpsr {
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
            hipStream_t stream);
-size_t conv_auto_split_floats();
+size_t conv_scratch_floats(long long M, int N);
 }
 
 namespace {
@@ -68,9 +68,9 @@ extern "C" size_t mpsr_trunk_workspace_bytes(int B, int H, int W)
     const TrunkDims d = trunk_dims(H, W);
     const size_t Mr = (size_t)B * d.OH * d.OW, Mp = (size_t)B * d.PH * d.PW;
     // cols, root, pooled, 3 x (Mp x 1024) ping/pong/shortcut, 2 x (Mp x 256) bottleneck temporaries
-    // + the split-K scratch small batches use to fill the chip (conv_mfma.hip auto_split_k)
+    // + the scheduling scratch of the convolution launches (stream-K partial tiles and counters, conv_mfma.hip)
     return fbytes(Mr * 160) + fbytes(Mr * 64) + fbytes(Mp * 64) + 3 * fbytes(Mp * 1024) + 2 * fbytes(Mp * 256) +
-           fbytes(mpsr::conv_auto_split_floats());
+           fbytes(mpsr::conv_scratch_floats((long long)(Mr > Mp ? Mr : Mp), 1024));
 }
 
 extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
@@ -99,7 +99,7 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
     float *pooled = ar.floats(Mp * root.cout);
     float *ping = ar.floats(Mp * cmax), *pong = ar.floats(Mp * cmax), *scut = ar.floats(Mp * cmax);
     float *t1 = ar.floats(Mp * bmax), *t2 = ar.floats(Mp * bmax);
-    const size_t skn = mpsr::conv_auto_split_floats();
+    const size_t skn = mpsr::conv_scratch_floats((long long)(Mr > Mp ? Mr : Mp), cmax > 1024 ? cmax : 1024);
     float *sk = ar.floats(skn);
     if (!ar.ok)
         return mpsr::fail(MPSR_ERR_WORKSPACE, "trunk_fwd: workspace %zu bytes too small (see mpsr_trunk_workspace_bytes)",
@@ -107,7 +107,7 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
 
     int rc;
     if ((rc = mpsr_im2col_root(img, B, H, W, cols, root.cin, stream))) return rc;
-    if ((rc = run_layer(blob, root, cols, (int)Mr, 1, 1, nullptr, rootout, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, root, cols, (int)Mr, 1, 1, nullptr, rootout, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(rootout, B, d.OH, d.OW, root.cout, 3, 2, 1, pooled, stream))) return rc;
 
     const float *cur = pooled;
@@ -145,7 +145,8 @@ extern "C" size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, in
 {
     if (B <= 0) return 0;
     const size_t Mf = (size_t)B * fh * fw, Mh = (size_t)B * (mh / 2) * (mw / 2), Mm = (size_t)B * mh * mw;
-    return 2 * fbytes(Mf * 512) + fbytes(Mh * 512) + 2 * fbytes(Mh * 256) + fbytes(Mm * 256) + 2 * fbytes(Mm * 128);
+    return 2 * fbytes(Mf * 512) + fbytes(Mh * 512) + 2 * fbytes(Mh * 256) + fbytes(Mm * 256) + 2 * fbytes(Mm * 128) +
+           fbytes(mpsr::conv_scratch_floats((long long)Mm, 512));
 }
 
 extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh,
@@ -172,19 +173,23 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
     float *r1 = ar.floats(Mh * csq), *a = ar.floats(Mh * c2), *b = ar.floats(Mh * c2);
     float *r2 = ar.floats(Mm * c2), *c = ar.floats(Mm * c3);
     float *fm = feat_map ? feat_map : ar.floats(Mm * c3);
+    int cwide = csq;
+    for (int i = 2; i < n_layers; ++i) cwide = L[i].cout > cwide ? L[i].cout : cwide;
+    const size_t skn = mpsr::conv_scratch_floats((long long)Mm, cwide > 512 ? cwide : 512);
+    float *sk = ar.floats(skn);
     if (!ar.ok)
         return mpsr::fail(MPSR_ERR_WORKSPACE, "squash_decoder_fwd: workspace %zu bytes too small", workspace_bytes);
     int rc;
     // 1x1 over concat([crop, full]) == two GEMMs over the halves of K; the second adds the first as its residual
-    if ((rc = run_layer(blob, L[0], crop_feat, B, fh, fw, nullptr, part, 1, nullptr, 0, s))) return rc;
-    if ((rc = run_layer(blob, L[1], full_feat, B, fh, fw, part, sq, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[0], crop_feat, B, fh, fw, nullptr, part, 0, sk, skn, s))) return rc;
+    if ((rc = run_layer(blob, L[1], full_feat, B, fh, fw, part, sq, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(sq, B, fh, fw, csq, 2, 2, 0, feat_box3d, stream))) return rc;
     if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
-    if ((rc = run_layer(blob, L[2], r1, B, hh, hw, nullptr, a, 1, nullptr, 0, s))) return rc;
-    if ((rc = run_layer(blob, L[3], a, B, hh, hw, nullptr, b, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[2], r1, B, hh, hw, nullptr, a, 0, sk, skn, s))) return rc;
+    if ((rc = run_layer(blob, L[3], a, B, hh, hw, nullptr, b, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_resize_bilinear(b, B, hh, hw, c2, mh, mw, 1, r2, stream))) return rc;
-    if ((rc = run_layer(blob, L[4], r2, B, mh, mw, nullptr, c, 1, nullptr, 0, s))) return rc;
-    if ((rc = run_layer(blob, L[5], c, B, mh, mw, nullptr, fm, 1, nullptr, 0, s))) return rc;
+    if ((rc = run_layer(blob, L[4], r2, B, mh, mw, nullptr, c, 0, sk, skn, s))) return rc;
+    if ((rc = run_layer(blob, L[5], c, B, mh, mw, nullptr, fm, 0, sk, skn, s))) return rc;
     if (xyz_map && (rc = run_layer(blob, L[6], fm, B, mh, mw, nullptr, xyz_map, 1, nullptr, 0, s))) return rc;
     return MPSR_OK;
 }
@@ -303,25 +308,16 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadIn in, const float 
     }
 }
 
-inline int img_fc_splits(int B, int nout, int ksteps)
-{
-    const int tiles = mpsr::ceil_div(B, 64) * mpsr::ceil_div(nout, 64);
-    int s = 768 / (tiles > 0 ? tiles : 1);
-    if (s < 1) s = 1;
-    if (s > 16) s = 16;
-    if (s > ksteps) s = ksteps;
-    return s;
-}
-
 }  // namespace
 
 extern "C" size_t mpsr_heads_workspace_bytes(int B, int feat_elems)
 {
     if (B <= 0 || feat_elems <= 0) return 0;
     const size_t b = (size_t)B;
-    // img_fc (2 x 1024 wide) + its split-K partials, two concat rows, four hidden activations, small outputs
-    return fbytes(b * 2048) + fbytes(16 * b * 2048) + 2 * fbytes(b * 1152) + 4 * fbytes(b * 1024) + fbytes(b * 64) +
-           fbytes(b * 2) + fbytes(b * 2);
+    // img_fc (2 x 1024 wide) + the scheduling scratch of its launch (stream-K partial tiles), two concat rows, four
+    // hidden activations, small outputs
+    return fbytes(b * 2048) + fbytes(mpsr::conv_scratch_floats(B, 2048)) + 2 * fbytes(b * 1152) + 4 * fbytes(b * 1024) +
+           fbytes(b * 64) + fbytes(b * 2) + fbytes(b * 2);
 }
 
 extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d,
@@ -348,10 +344,9 @@ extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, co
     hipStream_t s = mpsr::as_stream(stream);
     Arena ar(workspace, workspace_bytes);
     const size_t b = (size_t)B;
-    const int ksteps = mpsr::ceil_div(feat_elems, 32);
-    const int splits = img_fc_splits(B, L[0].cout, ksteps);
     float *imgfc = ar.floats(b * L[0].cout);
-    float *skws = ar.floats((size_t)splits * b * L[0].cout);
+    const size_t skn = mpsr::conv_scratch_floats(B, L[0].cout > 2048 ? L[0].cout : 2048);
+    float *skws = ar.floats(skn);
     float *cat_p = ar.floats(b * L[1].cin), *cat_r = ar.floats(b * L[4].cin);
     float *h1 = ar.floats(b * L[1].cout), *h2 = ar.floats(b * L[2].cout);
     float *g1 = ar.floats(b * L[4].cout), *g2 = ar.floats(b * L[5].cout);
@@ -363,8 +358,7 @@ extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, co
     in.cls = class_idx; in.k = *consts;
     int rc;
     // both img_fc layers share the flattened features: one GEMM, N = 2 x 1024, split along K = 18432
-    if ((rc = run_layer(blob, L[0], feat_box3d, B, 1, 1, nullptr, imgfc, splits, skws, (size_t)splits * b * L[0].cout, s)))
-        return rc;
+    if ((rc = run_layer(blob, L[0], feat_box3d, B, 1, 1, nullptr, imgfc, 0, skws, skn, s))) return rc;
     {
         const int total = B * L[1].cin;
         hipLaunchKernelGGL(head_concat_prop_kernel, dim3(mpsr::ceil_div(total, 256)), dim3(256), 0, s, in, imgfc,

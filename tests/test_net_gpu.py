@@ -98,11 +98,13 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("depth", [1, 2])
 @pytest.mark.parametrize("classes", [-1, 0, 1])
 @pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_vs_fp64(case, tile, classes):
-    """Every tile instantiation x border-class tiling off / forced on (also at dilation 1) / heuristic."""
+def test_conv2d_vs_fp64(case, tile, classes, depth):
+    """Every tile instantiation x border-class tiling off / forced on (also at dilation 1) / heuristic x one or two
+    staging register sets."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
@@ -116,13 +118,80 @@ def test_conv2d_vs_fp64(case, tile, classes):
     w_ok, _ = W.fold_conv(w)
     _lib.lib().mpsr_debug_set_conv_tile(tile)
     _lib.lib().mpsr_debug_set_conv_classes(classes)
+    _lib.lib().mpsr_debug_set_conv_depth(depth)
     try:
         got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, k, k,
                         rate, relu)
     finally:
         _lib.lib().mpsr_debug_set_conv_tile(-1)
         _lib.lib().mpsr_debug_set_conv_classes(-1)
-    _close(got, ref, 2e-6, "conv %s tile %d classes %d" % (case, tile, classes))
+        _lib.lib().mpsr_debug_set_conv_depth(-1)
+    _close(got, ref, 2e-6, "conv %s tile %d classes %d depth %d" % (case, tile, classes, depth))
+
+
+@pytest.mark.parametrize("groups", [0, -8, -40, 3])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_stream_k_vs_fp64(case, tile, groups):
+    """The stream-K schedule for every tile instantiation and several workgroup counts: the device's own (0), 8 and
+    40 workgroups (many tiles per workgroup) and 3 per CU."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    B, H, Wd, C, N, k, rate, has_bias, has_res, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((k, k, C, N)) / np.sqrt(k * k * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+    ref = _conv_ref(x, w, bias, res, rate, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    lib.mpsr_debug_set_conv_tile(tile)
+    lib.mpsr_debug_set_conv_sched(1, groups)
+    try:
+        got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, k, k,
+                        rate, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_tile(-1)
+        lib.mpsr_debug_set_conv_sched(-1, 0)
+    _close(got, ref, 2e-6, "stream-K conv %s tile %d groups %d" % (case, tile, groups))
+
+
+@pytest.mark.parametrize("shape", [(64, 12, 256, 256, 1, 1), (64, 12, 256, 256, 3, 4), (96, 12, 128, 512, 1, 1),
+                                   (8, 48, 64, 128, 3, 1), (37, 1, 4608, 200, 1, 1)])
+def test_stream_k_against_one_tile_per_workgroup(shape):
+    """Thousands of units over every XCD: stream-K equals the one-tile-per-workgroup kernel to fp32 summation order
+    (bit-identical where no tile is split), is deterministic run to run, and leaves its counters clean (a second
+    call on the same scratch gives the same bits)."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    B, H, C, N, k, d = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + C)
+    x = torch.randn((B, H, H, C), device="cuda", generator=g)
+    w = torch.randn((N, k * k * C), device="cuda", generator=g) / np.sqrt(k * k * C)
+    bias = torch.randn((N,), device="cuda", generator=g)
+    res = torch.randn((B, H, H, N), device="cuda", generator=g)
+    nws = lib.mpsr_conv2d_scratch_floats(B, H, H, N)
+    ws = torch.full((nws,), float("nan"), device="cuda")  # poisoned scratch: counters must be reset by the library
+
+    def run(split, sched, groups=0):
+        y = torch.empty((B, H, H, N), device="cuda")
+        lib.mpsr_debug_set_conv_sched(1, groups)
+        try:
+            _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, H, C, w.data_ptr(), bias.data_ptr(),
+                                                res.data_ptr(), y.data_ptr(), N, k, k, d, 1, split, ws.data_ptr(), nws,
+                                                _lib.stream()))
+        finally:
+            lib.mpsr_debug_set_conv_sched(-1, 0)
+        return y
+    base = run(1, 0)
+    for groups in (0, 5, -1000):
+        a = run(0, 1, groups)
+        b = run(0, 1, groups)
+        assert torch.equal(a, b), "stream-K not deterministic (groups %d)" % groups
+        err = float((a - base).abs().max() / base.abs().max())
+        assert err < 2e-6, "groups %d: %.3e" % (groups, err)
 
 
 def test_border_class_tiling_is_bit_identical():

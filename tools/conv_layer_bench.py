@@ -43,6 +43,12 @@ def main():
     ap.add_argument("--classes", type=int, default=-1)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--split", type=int, default=1, help="split_k passed to the library (0 = automatic)")
+    ap.add_argument("--sched", default="-1", help="comma list of schedules to time per tile: -1 heuristic, 0 one tile "
+                    "per workgroup, 1 stream-K; 1:G or 1:-N pins the workgroups per CU / the workgroup count")
+    ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
+                    "kernel: -1 heuristic, 1, 2")
+    ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
+                    "median over rounds is reported (boxes and power states drift: compare within one run only)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--shape", action="append", default=[],
@@ -52,10 +58,17 @@ def main():
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
     lib.mpsr_debug_set_conv_classes(args.classes)
+    depths = [int(d) for d in args.depth.split(",")]
     dev = torch.device("cuda")
     B = args.batch
-    print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("tile%2d TF/s (us)" % t for t in tiles)))
-    total = {t: 0.0 for t in tiles}
+    scheds = []
+    for sp in args.sched.split(","):
+        a, _, b = sp.partition(":")
+        scheds.append((int(a), int(b) if b else 0))
+    combos = [(t, sc, d) for t in tiles for sc in scheds for d in depths]
+    print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("t%d s%d:%d d%d TF/s (us)" % (t, a, b, d)
+                                                                   for t, (a, b), d in combos)))
+    total = {c: 0.0 for c in combos}
     shapes = SHAPES
     if args.shape:
         shapes = []
@@ -70,34 +83,47 @@ def main():
         bias = torch.randn((N,), device=dev)
         r = torch.randn((B, H, W, N), device=dev) if res else None
         y = torch.empty((B, H, W, N), device=dev)
-        nws = (8 if args.split == 0 else (args.split if args.split > 1 else 0)) * B * H * W * N
+        nws = lib.mpsr_conv2d_scratch_floats(B, H, W, N) if args.split == 0 else (
+            args.split * B * H * W * N if args.split > 1 else 0)
         ws = torch.empty((nws,), device=dev) if nws else None
         flop = 2.0 * B * H * W * C * k * k * N
         cells = []
-        for t in tiles:
-            if t == 4 and N > 32:
+        samples = {c: [] for c in combos}
+        for rnd in range(args.rounds):
+            for c in combos:
+                t, sc, d = c
+                if t == 4 and N > 32:
+                    continue
+                lib.mpsr_debug_set_conv_tile(t)
+                lib.mpsr_debug_set_conv_sched(sc[0], sc[1])
+                lib.mpsr_debug_set_conv_depth(d)
+
+                def run():
+                    _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
+                                                        r.data_ptr() if res else None, y.data_ptr(), N, k, k, dil, 1,
+                                                        args.split, ws.data_ptr() if nws else None, nws, _lib.stream()))
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                samples[c].append(e0.elapsed_time(e1) * 1e3 / args.reps)
+        for c in combos:
+            if not samples[c]:
                 cells.append("      -        ")
                 continue
-            lib.mpsr_debug_set_conv_tile(t)
-
-            def run():
-                _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
-                                                    r.data_ptr() if res else None, y.data_ptr(), N, k, k, dil, 1,
-                                                    args.split, ws.data_ptr() if nws else None, nws, _lib.stream()))
-            run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.reps):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.reps
-            total[t] += us * count
+            us = sorted(samples[c])[len(samples[c]) // 2]
+            total[c] += us * count
             cells.append("%6.1f (%7.1f)" % (flop / us / 1e6, us))
         lib.mpsr_debug_set_conv_tile(-1)
+        lib.mpsr_debug_set_conv_sched(-1, 0)
+        lib.mpsr_debug_set_conv_depth(-1)
         print("%-28s %3d %9.2f | %s" % (name, count, flop / 1e9, "  ".join(cells)))
-    print("per-step conv time (ms): " + "  ".join("tile%d %.2f" % (t, total[t] / 1e3) for t in tiles))
+    print("per-step conv time (ms): " + "  ".join("t%d s%d:%d d%d %.2f" % (t, sc[0], sc[1], d, total[(t, sc, d)] / 1e3)
+                                                    for t, sc, d in combos))
 
 
 if __name__ == "__main__":
