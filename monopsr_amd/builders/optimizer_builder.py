@@ -3,7 +3,8 @@
 The reference returns a tf.train optimizer (Adam for model 000, wrapped in MovingAverageOptimizer) fed by
 tf.train.exponential_decay.  Here `build` returns an object that owns the same three things over the trainable
 net's FLAT fp32 parameter buffer: the learning-rate schedule, the fused Adam step (mpsr_adam_step) and the
-moving average of the parameters that the reference's swapping saver writes to checkpoints.
+moving average of the parameters.  (The reference saves with a plain tf.train.Saver, core/trainer.py:85: a
+checkpoint holds the RAW variables under their own names and the averages under `<name>/ExponentialMovingAverage`.)
 """
 import math
 
@@ -51,7 +52,8 @@ class AdamWithMovingAverage:
         return lr
 
     def averaged_params(self, net):
-        """What the reference's swapping saver stores: the moving averages (or the raw parameters)."""
+        """The moving averages -- what a checkpoint holds under `<name>/ExponentialMovingAverage` -- or the raw
+        parameters when averaging is off."""
         return self.shadow if self.shadow is not None else net.params
 
 

@@ -346,12 +346,13 @@ def read_checkpoint(path, names=None, verify=True):
 # ------------------------------------------------------------------------------------------------ table writer
 
 class _BlockBuilder:
-    def __init__(self):
+    def __init__(self, restart_interval=None):
         self.buf, self.restarts, self.count, self.last = bytearray(), [0], 0, b""
+        self.interval = _RESTART_INTERVAL if restart_interval is None else restart_interval
 
     def add(self, key, value):
         shared = 0
-        if self.count and self.count % _RESTART_INTERVAL == 0:
+        if self.count and self.count % self.interval == 0:
             self.restarts.append(len(self.buf))
         elif self.count:
             m = min(len(key), len(self.last))
@@ -372,6 +373,25 @@ class _BlockBuilder:
 
     def size(self):
         return len(self.buf) + 4 * len(self.restarts) + 4
+
+
+def _shortest_separator(start, limit):
+    """A short key k with start <= k < limit (bytewise order), as the table builder puts between two data blocks."""
+    n = min(len(start), len(limit))
+    i = 0
+    while i < n and start[i] == limit[i]:
+        i += 1
+    if i < n and start[i] < 0xff and start[i] + 1 < limit[i]:
+        return start[:i] + bytes([start[i] + 1])
+    return start
+
+
+def _short_successor(key):
+    """A short key >= key: the index entry of the last data block."""
+    for i, b in enumerate(key):
+        if b != 0xff:
+            return key[:i] + bytes([b + 1])
+    return key
 
 
 def _write_block(f, contents):
@@ -405,20 +425,28 @@ def write_checkpoint(prefix, tensors, block_size=_BLOCK_SIZE):
             items.append((name.encode("utf-8"),
                           _encode_entry(_DTYPE_IDS[a.dtype], shape, off, a.nbytes, mask_crc(_crc32c_array(a)))))
     with open(prefix + ".index", "wb") as f:
-        index = _BlockBuilder()
+        # as TensorFlow's table builder: data blocks restart every 16 entries, the index block at every entry, and an
+        # index key is the shortest separator between a block's last key and the next block's first one
+        index = _BlockBuilder(restart_interval=1)
         block = _BlockBuilder()
         block.add(b"", _HEADER_PB)
+        pending = None  # (last key, handle) of the block just written, waiting for its successor's first key
 
         def flush():
-            nonlocal block
+            nonlocal block, pending
             if block.count:
-                index.add(block.last, _write_block(f, block.finish()))
+                pending = (block.last, _write_block(f, block.finish()))
                 block = _BlockBuilder()
         for key, value in items:
+            if pending is not None and block.count == 0:
+                index.add(_shortest_separator(pending[0], key), pending[1])
+                pending = None
             block.add(key, value)
             if block.size() >= block_size:
                 flush()
         flush()
+        if pending is not None:
+            index.add(_short_successor(pending[0]), pending[1])
         meta_handle = _write_block(f, _BlockBuilder().finish())
         index_handle = _write_block(f, index.finish())
         footer = meta_handle + index_handle

@@ -159,11 +159,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
         bbase[j] = n < p.N ? (unsigned)n * (unsigned)Ktot * 4u : p.wbytes;  // past the end -> zeros
     }
 
-    // K-step state, advanced incrementally (channel block fastest, then kx, then ky over the class's taps)
+    // K-step state, advanced incrementally: taps fastest (kx, then ky over the class's taps), channel block slowest.
+    // The taps of one 32-channel block re-read the same few KB of pixels (shifted), so their gathers hit L1 / L2;
+    // with the channel block fastest a pixel came back after a whole channel sweep (1/9 of the K loop, far more than
+    // the XCD's L2 holds across its resident tiles) and the 3x3 layers fetched their input ~4.7x from HBM.
     int st_cb, st_kx, st_ky;
     {
-        const int tap = ks_begin / p.cblocks;
-        st_cb = ks_begin - tap * p.cblocks;
+        const int ntaps = (pc.ky1 - pc.ky0 + 1) * ntx;
+        st_cb = ks_begin / ntaps;
+        const int tap = ks_begin - st_cb * ntaps;
         const int ty = tap / ntx;
         st_ky = pc.ky0 + ty;
         st_kx = pc.kx0 + (tap - ty * ntx);
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
             const unsigned off = cok ? bbase[j] + boff : p.wbytes;
             rb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
         }
-        if (++st_cb == p.cblocks) {
-            st_cb = 0;
-            if (++st_kx > pc.kx1) {
-                st_kx = pc.kx0;
-                ++st_ky;
+        if (++st_kx > pc.kx1) {
+            st_kx = pc.kx0;
+            if (++st_ky > pc.ky1) {
+                st_ky = pc.ky0;
+                ++st_cb;
             }
         }
     };
@@ -555,8 +559,9 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvParams p, const 
         }
         int st_cb, st_kx, st_ky;
         {
-            const int tap = ks_begin / p.cblocks;
-            st_cb = ks_begin - tap * p.cblocks;
+            const int ntaps = (pc.ky1 - pc.ky0 + 1) * ntx;
+            st_cb = ks_begin / ntaps;
+            const int tap = ks_begin - st_cb * ntaps;
             const int ty = tap / ntx;
             st_ky = pc.ky0 + ty;
             st_kx = pc.kx0 + (tap - ty * ntx);
@@ -580,11 +585,11 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvParams p, const 
                 const unsigned off = cok ? bbase[j] + boff : p.wbytes;
                 rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
             }
-            if (++st_cb == p.cblocks) {
-                st_cb = 0;
-                if (++st_kx > pc.kx1) {
-                    st_kx = pc.kx0;
-                    ++st_ky;
+            if (++st_kx > pc.kx1) {
+                st_kx = pc.kx0;
+                if (++st_ky > pc.ky1) {
+                    st_ky = pc.ky0;
+                    ++st_cb;
                 }
             }
         };

@@ -114,3 +114,33 @@ def test_restore_from_a_bundle_with_the_reference_name_logic(tmp_path):
     assert set(got) == set(model)
     for k in model:
         np.testing.assert_array_equal(fresh[k], model[k])
+
+
+def test_index_keys_are_short_separators():
+    """Index entries follow the table builder's rule (shortest separator between blocks, short successor for the
+    last), and a multi-block file written that way reads back."""
+    import numpy as np
+    from monopsr_amd.core import tf_checkpoint as T
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        a = bytes(rng.integers(97, 100, rng.integers(1, 6)).astype(np.uint8))
+        b = bytes(rng.integers(97, 100, rng.integers(1, 6)).astype(np.uint8))
+        lo, hi = sorted([a, b])
+        if lo == hi:
+            continue
+        sep = T._shortest_separator(lo, hi)
+        assert lo <= sep < hi and len(sep) <= len(lo)
+        assert T._short_successor(lo) >= lo
+    assert T._shortest_separator(b"block1/unit_1", b"block3/unit_2") == b"block2"
+    assert T._short_successor(b"\xff\xffa") == b"\xff\xffb"
+
+
+def test_many_small_blocks_round_trip(tmp_path):
+    import numpy as np
+    from monopsr_amd.core import tf_checkpoint as T
+    tensors = {"scope/layer_%03d/weights" % i: np.full((3,), i, np.float32) for i in range(200)}
+    T.write_checkpoint(str(tmp_path / "m"), tensors, block_size=256)  # dozens of data blocks
+    back = T.read_checkpoint(str(tmp_path / "m"))
+    assert sorted(back) == sorted(tensors)
+    for k, v in tensors.items():
+        np.testing.assert_array_equal(back[k], v)
