@@ -59,15 +59,44 @@ int mpsr_nn_distance_bwd(int b, int n, const float *xyz1, int m, const float *xy
 
 /* ------------------------------------------------------------------------------------------------ EMD */
 
-/* Scratch floats mpsr_approx_match needs in `temp` (the reference uses b*(n+m)*2, tf_approxmatch.cpp:168;
- * this implementation keeps per-level ratios so that match is written exactly once). */
+/* The reference has TWO implementations of the matching, and they differ numerically: its device kernel
+ * (tf_approxmatch_g.cu:1-179: 10 annealing levels, fp32 state, match laid out (b,m,n) as tf_approxmatch.py:15-23
+ * documents) and its CPU kernel (tf_approxmatch.cpp:23-84, the path BASELINE config 1 runs: 11 levels, double state,
+ * the receiver capacity reduced by what was actually taken, match laid out (b,n,m)).  MPSR_EMD_DEVICE is the default
+ * and the fast path; MPSR_EMD_HOST reproduces the CPU kernel's arithmetic on the GPU (fp64 state, libm-grade expf) so
+ * that outputs can be compared with a TF1-CPU run; a few times slower. */
+enum { MPSR_EMD_DEVICE = 0, MPSR_EMD_HOST = 1 };
+
+/* Scratch floats behind `temp` for the full-speed path of the given semantics: per cloud (n+m) * (1 + levels) state
+ * words (fp32, or fp64 for MPSR_EMD_HOST) -- the ratios of every level are kept so that match is written exactly once
+ * (or never, mpsr_emd_loss).  mpsr_approx_match_temp_floats(b,n,m) == mpsr_emd_temp_floats(b,n,m,MPSR_EMD_DEVICE). */
+size_t mpsr_emd_temp_floats(int b, int n, int m, int semantics);
 size_t mpsr_approx_match_temp_floats(int b, int n, int m);
 
 /* Replaces approxmatchLauncher (tf_approxmatch.cpp:141, tf_approxmatch_g.cu:1-182), op ApproxMatch
- * (tf_approxmatch.cpp:7-10).  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n), GPU-kernel semantics: 10 annealing
- * levels, fp32 state. */
+ * (tf_approxmatch.cpp:7-10): the launcher's arguments, then the size of `temp` in floats and the stream.
+ * xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n), device-kernel semantics.
+ *   temp_floats >= mpsr_approx_match_temp_floats(b,n,m): fast path (match written once);
+ *   temp_floats >= b*(n+m)*2, what the reference's op shell allocates (tf_approxmatch.cpp:168): same result bit for
+ *     bit, match accumulated level by level as the reference does (about 2x slower);
+ *   less: MPSR_ERR_WORKSPACE, nothing is written. */
 int mpsr_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                      mpsr_stream_t stream);
+                      size_t temp_floats, mpsr_stream_t stream);
+
+/* The same with the semantics chosen.  MPSR_EMD_HOST: match is (b,n,m) like the CPU kernel's output, temp must hold
+ * mpsr_emd_temp_floats(b,n,m,MPSR_EMD_HOST) floats and be 8-byte aligned.  (mpsr_match_cost / mpsr_match_cost_grad
+ * take a (b,n,m) match when called with the clouds swapped: cost(b, m, n, xyz2, xyz1, match), and
+ * grad(b, m, n, xyz2, xyz1, match, grad2, grad1).) */
+int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                         size_t temp_floats, int semantics, mpsr_stream_t stream);
+
+/* EarthMoversDistance (losses_custom.py:135-165: approx_match -> match_cost, gradient by MatchCostGrad with match
+ * held constant) in one call that never materialises match: cost (b), grad1 = d cost / d xyz1 (b,n,3),
+ * grad2 (b,m,3).  Every match entry is recomputed from the per-level ratios where it is consumed; results equal
+ * mpsr_approx_match + mpsr_match_cost + mpsr_match_cost_grad to fp32 summation order.  grad1 / grad2 may be NULL
+ * (cost only: the metric of monopsr_model.py:1143-1149).  temp: mpsr_emd_temp_floats(b,n,m,semantics) floats. */
+int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                  float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream);
 
 /* Replaces matchcostLauncher (tf_approxmatch.cpp:142, tf_approxmatch_g.cu:183-228), op MatchCost.
  * -> out (b). */

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPSR_LIB_PATH: development knob for A/B-ing two builds of the library inside one GPU session
 LIB_PATH = os.environ.get("MPSR_LIB_PATH") or os.path.join(_HERE, "libmonopsr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -58,7 +58,10 @@ SIGNATURES = {
     "mpsr_nn_distance_fwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_approx_match_temp_floats": (c_sz, [c_i, c_i, c_i]),
-    "mpsr_approx_match": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_emd_temp_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "mpsr_approx_match": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "mpsr_approx_match_ex": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_sz, c_i, c_f]),
+    "mpsr_emd_loss": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_f]),
     "mpsr_match_cost": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_match_cost_grad": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_crop_and_resize": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f]),

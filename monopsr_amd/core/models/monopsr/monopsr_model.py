@@ -296,8 +296,9 @@ class MonoPSRModel:
         valid_gt_points = (gt * mask).reshape(B, -1, 3)
         num_valid_pixels = mask[0:num_objs].sum(dim=(1, 2, 3))
         with torch.no_grad():
-            match = tf_approxmatch.approx_match(valid_pred_inst_points, valid_gt_points)
-            all_distances = tf_approxmatch.match_cost(valid_pred_inst_points, valid_gt_points, match)
+            # approx_match + match_cost (monopsr_model.py:1143-1149), fused: no match tensor
+            all_distances = tf_approxmatch.emd_loss_fwd_bwd(valid_pred_inst_points, valid_gt_points,
+                                                            want_grads=False)[0]
             metrics_dict[constants.METRIC_EMD] = all_distances[0:num_objs] / num_valid_pixels
             dist1, _, dist2, _ = tf_nndistance.nn_distance(valid_pred_inst_points, valid_gt_points)
             all_chamfer_dists = dist1.sum(dim=1) + dist2.sum(dim=1)

@@ -1,185 +1,467 @@
 // Approximate Earth Mover's Distance (ops ApproxMatch / MatchCost / MatchCostGrad) for gfx950.
 //
-// Algorithm = the reference's device kernel (tf_ops/approxmatch/tf_approxmatch_g.cu:1-179): 10 annealing levels
-// (level = -4^j, j = 7..-1, then 0), fp32 state, capacities multiL/multiR, three O(n*m) sweeps per level, and a
-// match tensor laid out [m][n] per cloud as the (b, m, n) op output documents (tf_approxmatch.py:15-23).
+// Two arithmetic "semantics" of the same annealed soft assignment are provided, because the reference has two:
+//   MPSR_EMD_DEVICE  the reference's device kernel (tf_ops/approxmatch/tf_approxmatch_g.cu:1-179): 10 annealing
+//                    levels (level = -4^j, j = 7..-1, then 0), fp32 state, match laid out [m][n] per cloud as the
+//                    (b, m, n) op output documents (tf_approxmatch.py:15-23).  The default and the fast path.
+//   MPSR_EMD_HOST    the reference's CPU kernel (tf_approxmatch.cpp:23-84), the path BASELINE config 1 names:
+//                    11 levels (j = 8..-1, then 0), double-precision state and sums, expf of the float-rounded
+//                    exponent, the receiver capacity reduced by what was actually taken, match laid out [n][m].
+//                    Exists so that the HIP path can be checked directly against the oracle's pinned restatement of
+//                    that kernel; a few times slower (fp64 arithmetic, libm-grade exponentials).
 //
-// MI355X design.  The reference read-modify-writes the b*n*m match tensor once per level (10x); here the sweeps
-// only update the O(n+m) state and record each level's giver/receiver ratios, and a second kernel emits
-//     match[l][k] = sum_levels exp(level * |p2_l - p1_k|^2) * ratioL[level][k] * ratioR[level][l]
-// (same terms, same summation order as the reference's accumulation) so match is written exactly once:
-// b*n*m*4 bytes of HBM traffic instead of ~19x that, for 10 extra exponentials per pair.
-//   * sweeps: one launch per sweep, 512 own points per 256-thread workgroup; the opposite cloud is staged through
-//     LDS as float4 (x, y, z, weight) tiles and read with wave-uniform ds_read_b128; each thread carries kPT own
-//     points;
-//   * exp(x) is evaluated as exp2(x * log2 e) with log2 e folded into the level constant (v_exp_f32).
+// One level of the algorithm, for givers k (cloud 1, capacity remL) and receivers l (cloud 2, capacity remR), with
+// e(k,l) = exp(level * |p1_k - p2_l|^2):
+//   sweep 1 (per k):  ratL[k] = remL[k] / (1e-9 + sum_l e * remR[l])
+//   sweep 2 (per l):  t = sum_k e * ratL[k];  DEVICE: offered = t * remR, ratR = min(remR / (offered + 1e-9), 1) * remR,
+//                     remR = max(0, remR - offered);  HOST: c = min(remR / (1e-9 + remR * t), 1), ratR = c * remR,
+//                     remR = max(0, remR - c * remR * t)
+//   sweep 3 (per k):  remL[k] = max(0, remL[k] - ratL[k] * sum_l e * ratR[l])
+//   match[k,l] += e * ratL[k] * ratR[l]
+//
+// MI355X design.
+//   * The reference read-modify-writes the b*n*m match tensor once per level (10x).  Here the sweeps only update the
+//     O(n+m) state and record each level's ratios; one emit kernel then writes match[k,l] = sum_levels e * ratL * ratR
+//     (same terms, same order) exactly once -- or, for the loss, mpsr_emd_loss never materialises match at all: two
+//     passes recompute each entry from the ratios in registers and reduce it straight into cost / grad1 and grad2
+//     (4.3 GB less HBM traffic per 256 x 2048^2 batch than writing match once and reading it three times).
+//   * Sweep 3 of level i and sweep 1 of level i+1 both walk the receivers for a fixed giver and both depend only on
+//     sweep 2 of level i, so they are ONE pass ("giver pass"): 2L+1 launches instead of 3L, and because consecutive
+//     levels differ by a factor 4 in the exponent, e_i = e_{i+1}^4 -- one v_exp_f32 and two multiplies serve both.
+//     The emit / loss kernels need all levels of a pair: three exponentials (j = -1, 2, 5) and repeated fourth powers
+//     give the other six (relative error <= ~2e-6, against the op's 1e-3 budget).
+//   * One launch per pass, 512 own points per 256-thread workgroup, so a cloud spreads over many workgroups and 32
+//     clouds already fill the chip; the opposite cloud is staged through LDS as float4 (x, y, z, weight) tiles and read
+//     with wave-uniform ds_read_b128; a thread's two own points sit in the halves of 2-wide vectors so the distance
+//     arithmetic issues as packed fp32 (v_pk_add/mul/fma_f32).
+//   * Scratch: (n+m) * (1 + levels) state words per cloud.  With only the reference shell's (n+m)*2 floats
+//     (tf_approxmatch.cpp:168) the DEVICE path still works: ratios of one level at a time, match accumulated level by
+//     level (the reference's own traffic pattern; bit-identical result, ~2x slower).
 #include "common.h"
 
 namespace {
 
-constexpr int kLevels = 10;
-constexpr int kSweepThreads = 256;
-constexpr int kPT = 2;         // own points per thread in the sweeps
-constexpr int kTile = 2048;    // opposite-cloud points per LDS tile (32 KiB)
+constexpr int kThreads = 256;
+#ifndef MPSR_EMD_PT
+#define MPSR_EMD_PT 2
+#endif
+constexpr int kPT = MPSR_EMD_PT;  // own points per thread in the passes (even)
+constexpr int kPV = kPT / 2;       // ... as 2-wide vectors
+constexpr int kTile = 1024;  // opposite-cloud points per LDS tile
 constexpr float kLog2e = 1.4426950408889634f;
 
-// level constant for annealing step lev (0..9), pre-multiplied by log2(e)
-__device__ __forceinline__ float level_log2e(int lev)
+template <bool HOST>
+struct Sem {
+    using S = float;
+    static constexpr int levels = 10;
+    static constexpr int j0 = 7;
+};
+template <>
+struct Sem<true> {
+    using S = double;
+    static constexpr int levels = 11;
+    static constexpr int j0 = 8;
+};
+
+// level constant of annealing step i: -4^j with j = j0 - i, and 0 for the last step
+template <bool HOST>
+__host__ __device__ inline float level_value(int i)
 {
-    const int j = 7 - lev;  // 7..-2
-    if (j == -2) return 0.f;
-    return -exp2f(2.f * (float)j) * kLog2e;
+    const int j = Sem<HOST>::j0 - i;
+    if (i >= Sem<HOST>::levels - 1) return 0.f;
+    return -exp2f(2.f * (float)j);
 }
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-__device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, float by, float bz)
+__device__ __forceinline__ float pow4(float v)
 {
-    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    v *= v;
+    return v * v;
+}
+
+// DEVICE semantics: e[i] = exp(level_i * d2) for the nine non-zero levels i = 0..8 (j = 7..-1) from three
+// exponentials; e of the tenth level is 1.
+__device__ __forceinline__ void device_level_exps(float d2, float e[9])
+{
+    e[8] = __builtin_amdgcn_exp2f(-0.25f * kLog2e * d2);  // j = -1
+    e[7] = pow4(e[8]);
+    e[6] = pow4(e[7]);
+    e[5] = __builtin_amdgcn_exp2f(-16.f * kLog2e * d2);  // j = 2
+    e[4] = pow4(e[5]);
+    e[3] = pow4(e[4]);
+    e[2] = __builtin_amdgcn_exp2f(-1024.f * kLog2e * d2);  // j = 5
+    e[1] = pow4(e[2]);
+    e[0] = pow4(e[1]);
+}
+
+// the same value for one level only (the compact path accumulates match level by level)
+__device__ __forceinline__ float device_level_exp(float d2, int i)
+{
+    if (i >= 9) return 1.f;
+    const int anchor = i >= 6 ? 8 : (i >= 3 ? 5 : 2);
+    float v = __builtin_amdgcn_exp2f((anchor == 8 ? -0.25f : (anchor == 5 ? -16.f : -1024.f)) * kLog2e * d2);
+    for (int s = anchor; s > i; --s) v = pow4(v);
+    return v;
+}
+
+// HOST semantics: expf of the float-rounded product of the double level and the double squared distance
+__device__ __forceinline__ float host_exp(double level, double d2) { return expf((float)(level * d2)); }
+
+__device__ __forceinline__ double sqdist_d(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const double dx = (double)ax - (double)bx, dy = (double)ay - (double)by, dz = (double)az - (double)bz;
     return dx * dx + dy * dy + dz * dz;
 }
 
-// Stage `cnt` points (xyz from `pts`, 4th lane from `wgt`, or the constant `wconst` when wgt == nullptr).
-__device__ __forceinline__ void stage_tile(float4 *tile, const float *__restrict__ pts, const float *__restrict__ wgt,
-                                           float wconst, int first, int cnt)
-{
-    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
-        const float *s = pts + (size_t)(first + p) * 3;
-        tile[p] = make_float4(s[0], s[1], s[2], wgt ? wgt[first + p] : wconst);
+// ---------------------------------------------------------------------------------------------------- state
+// Per cloud, in words of S: remL[n] remR[m] ratL[slots][n] ratR[slots][m]; slots = levels (ratios of every level
+// kept for the emit / loss kernels) or 1 (compact path).
+template <bool HOST>
+struct State {
+    using S = typename Sem<HOST>::S;
+    S *remL, *remR, *ratL, *ratR;
+    __host__ __device__ State(void *temp, int cloud, int n, int m, int slots)
+    {
+        S *base = static_cast<S *>(temp) + (size_t)cloud * ((size_t)(n + m) * (1 + slots));
+        remL = base;
+        remR = base + n;
+        ratL = base + n + m;
+        ratR = ratL + (size_t)slots * n;
     }
-}
+};
 
-// State per cloud in `temp`: remL[n] remR[m] ratL[kLevels][n] ratR[kLevels][m].
-//
-// One launch per sweep (3 per level, 30 in all): every sweep is independent per OWN point (sweeps 1 and 3 per giver
-// k, sweep 2 per receiver l) and only needs the previous sweep finished, so the launch boundary is the only
-// synchronisation and a cloud spreads over ceil(points / 512) workgroups instead of one -- the reference's
-// 32-cloud evaluation batches fill the chip too.  grid = (ceil(own / (kSweepThreads * kPT)), b).
-//   SWEEP 1: ratL[k] = remL[k] / (1e-9 + sum_l e(k,l) * remR[l])
-//   SWEEP 2: s = remR[l] * sum_k e(k,l) * ratL[k];  ratR[l] = min(remR[l] / (s + 1e-9), 1) * remR[l];
-//            remR[l] = max(0, remR[l] - s)
-//   SWEEP 3: remL[k] = max(0, remL[k] - ratL[k] * sum_l e(k,l) * ratR[l])
-// At level 0 the capacities are the constants multiL / multiR (no initialisation pass).
-template <int SWEEP>
-__global__ __launch_bounds__(kSweepThreads) void approx_match_sweep_kernel(int n, int m,
-                                                                          const float *__restrict__ xyz1,
-                                                                          const float *__restrict__ xyz2,
-                                                                          float *__restrict__ temp, int lev)
+// ---------------------------------------------------------------------------------------------------- giver pass
+// Own points = givers k.  MODE 0: sweep 1 of level `lev` only (the first launch); 1: sweep 3 of level lev-1 and sweep
+// 1 of level lev; 2: sweep 3 of level lev-1 only (the last launch).  grid (ceil(n / 512), b).
+template <bool HOST, int MODE>
+__global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                            const float *__restrict__ xyz2, void *temp, int lev,
+                                                            int slots)
 {
-    __shared__ float4 tile[kTile];
+    using S = typename Sem<HOST>::S;
+    constexpr bool kDo3 = MODE != 0, kDo1 = MODE != 2;
+    __shared__ float4 tile[kTile];  // x, y, z, (DEVICE) weight of sweep 3
+    __shared__ S w1s[kTile];        // weight of sweep 1 (remR)
+    __shared__ S w3s[HOST ? kTile : 1];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
     const float *p2 = xyz2 + (size_t)cloud * m * 3;
-    float *st = temp + (size_t)cloud * ((size_t)(n + m) * (1 + kLevels));
-    float *remL = st, *remR = st + n;
-    float *ratL = st + n + m + (size_t)lev * n;
-    float *ratR = st + n + m + (size_t)kLevels * n + (size_t)lev * m;
-    const float multiL = n >= m ? 1.f : (float)(m / n);
-    const float multiR = n >= m ? (float)(n / m) : 1.f;
-    const bool first = lev == 0;
-    const float lv = level_log2e(lev);
-    constexpr bool kOwnIsL = SWEEP != 2;           // own points come from cloud 1 (givers) in sweeps 1 and 3
-    const int nown = kOwnIsL ? n : m, nother = kOwnIsL ? m : n;
-    const float *own = kOwnIsL ? p1 : p2, *other = kOwnIsL ? p2 : p1;
-    const float *wgt = SWEEP == 1 ? (first ? nullptr : remR) : (SWEEP == 2 ? ratL : ratR);
+    const State<HOST> st(temp, cloud, n, m, slots);
+    const int cur = slots > 1 ? lev : 0, prev = slots > 1 ? lev - 1 : 0;
+    S *ratL_cur = st.ratL + (size_t)cur * n;
+    const S *ratL_prev = st.ratL + (size_t)prev * n, *ratR_prev = st.ratR + (size_t)prev * m;
+    const S multiL = n >= m ? 1 : (S)(m / n), multiR = n >= m ? (S)(n / m) : 1;
+    const bool first = lev == 0;           // sweep 1 of level 0 reads the initial capacities
+    const bool first3 = kDo3 && lev == 1;  // sweep 3 of level 0 reads the initial giver capacity
+    const float lv_cur = kDo1 ? level_value<HOST>(lev) : 0.f, lv_prev = kDo3 ? level_value<HOST>(lev - 1) : 0.f;
 
-    const int base = blockIdx.x * (kSweepThreads * kPT);
-    // the two own points of a thread live in the halves of 2-wide vectors: the distance / weighting arithmetic then
-    // compiles to packed fp32 instructions (v_pk_add/mul/fma_f32: two points per VALU slot); only the two exp2 stay
-    // scalar (quarter-rate transcendental unit)
-    static_assert(kPT == 2, "packed sweep arithmetic pairs two own points per thread");
-    f32x2 x, y, z, sv;
+    const int base = blockIdx.x * (kThreads * kPT);
+    float ox[kPT], oy[kPT], oz[kPT];
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kSweepThreads + tid;
-        const bool live = i < nown;
-        x[u] = live ? own[3 * i] : 0.f;
-        y[u] = live ? own[3 * i + 1] : 0.f;
-        z[u] = live ? own[3 * i + 2] : 0.f;
-        sv[u] = SWEEP == 1 ? 1e-9f : 0.f;
+        const int i = base + u * kThreads + tid;
+        const bool live = i < n;
+        ox[u] = live ? p1[3 * i] : 0.f;
+        oy[u] = live ? p1[3 * i + 1] : 0.f;
+        oz[u] = live ? p1[3 * i + 2] : 0.f;
     }
-    for (int o0 = 0; o0 < nother; o0 += kTile) {
-        const int cnt = min(kTile, nother - o0);
+    S s1[kPT], s3[kPT];
+#pragma unroll
+    for (int u = 0; u < kPT; ++u) {
+        s1[u] = (S)1e-9;
+        s3[u] = 0;
+    }
+    f32x2 vx[kPV], vy[kPV], vz[kPV], a1[kPV], a3[kPV];
+#pragma unroll
+    for (int v = 0; v < kPV; ++v) {
+        vx[v] = f32x2{ox[2 * v], ox[2 * v + 1]};
+        vy[v] = f32x2{oy[2 * v], oy[2 * v + 1]};
+        vz[v] = f32x2{oz[2 * v], oz[2 * v + 1]};
+        a1[v] = f32x2{1e-9f, 1e-9f};
+        a3[v] = f32x2{0.f, 0.f};
+    }
+    // DEVICE: the exponent of the smaller level in magnitude; the other one is its fourth power.  When the current
+    // level is the zero level (e = 1) the exponential belongs to the previous level instead.
+    const bool cur_zero = kDo1 && lv_cur == 0.f;
+    const float c_small = (kDo1 && !cur_zero ? lv_cur : lv_prev) * kLog2e;
+
+    for (int o0 = 0; o0 < m; o0 += kTile) {
+        const int cnt = min(kTile, m - o0);
         __syncthreads();
-        stage_tile(tile, other, wgt, multiR, o0, cnt);
+        for (int q = tid; q < cnt; q += kThreads) {
+            const float *s = p2 + (size_t)(o0 + q) * 3;
+            const S w3 = kDo3 ? ratR_prev[o0 + q] : (S)0;
+            tile[q] = make_float4(s[0], s[1], s[2], HOST ? 0.f : (float)w3);
+            if (HOST) w3s[q] = w3;
+            if (kDo1) w1s[q] = first ? multiR : st.remR[o0 + q];
+        }
         __syncthreads();
+        if constexpr (HOST) {
+            for (int o = 0; o < cnt; ++o) {
+                const float4 t = tile[o];
+                const S w1 = kDo1 ? w1s[o] : 0, w3 = kDo3 ? w3s[o] : 0;
+#pragma unroll
+                for (int u = 0; u < kPT; ++u) {
+                    const double d2 = sqdist_d(ox[u], oy[u], oz[u], t.x, t.y, t.z);
+                    if (kDo1) s1[u] += (double)host_exp((double)lv_cur, d2) * w1;
+                    if (kDo3) s3[u] += (double)host_exp((double)lv_prev, d2) * w3;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int o = 0; o < cnt; ++o) {
-            const float4 t = tile[o];
-            // distance evaluated as (other - own) for givers, (own - other) for receivers: the reference's operand
-            // order (x2 - x1); squares are identical either way
-            const f32x2 dx = kOwnIsL ? t.x - x : x - t.x, dy = kOwnIsL ? t.y - y : y - t.y,
-                        dz = kOwnIsL ? t.z - z : z - t.z;
-            const f32x2 d2 = dx * dx + dy * dy + dz * dz;
-            const f32x2 a = lv * d2;
-            f32x2 e;
-            e[0] = __builtin_amdgcn_exp2f(a[0]);
-            e[1] = __builtin_amdgcn_exp2f(a[1]);
-            sv += e * t.w;
+            for (int o = 0; o < cnt; ++o) {
+                const float4 t = tile[o];
+                const float w1 = kDo1 ? w1s[o] : 0.f;
+#pragma unroll
+                for (int v = 0; v < kPV; ++v) {
+                    const f32x2 dx = t.x - vx[v], dy = t.y - vy[v], dz = t.z - vz[v];  // the reference's order (x2 - x1)
+                    const f32x2 d2 = dx * dx + dy * dy + dz * dz;
+                    const f32x2 a = c_small * d2;
+                    f32x2 es, eb;  // e of the smaller / of the 4x larger level
+                    es[0] = __builtin_amdgcn_exp2f(a[0]);
+                    es[1] = __builtin_amdgcn_exp2f(a[1]);
+                    if (MODE == 1 && !cur_zero) {
+                        eb = es * es;
+                        eb = eb * eb;
+                    }
+                    if (MODE == 0) a1[v] += es * w1;
+                    if (MODE == 2) a3[v] += es * t.w;
+                    if (MODE == 1) {
+                        if (cur_zero) {  // block-uniform: e_cur = 1, the exponential is e_prev
+                            a1[v] += w1;
+                            a3[v] += es * t.w;
+                        } else {
+                            a1[v] += es * w1;
+                            a3[v] += eb * t.w;
+                        }
+                    }
+                }
+            }
         }
     }
-    float s[kPT] = {sv[0], sv[1]};
+    if constexpr (!HOST) {
+#pragma unroll
+        for (int u = 0; u < kPT; ++u) {
+            s1[u] = a1[u / 2][u % 2];
+            s3[u] = a3[u / 2][u % 2];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kSweepThreads + tid;
-        if (i >= nown) continue;
-        if (SWEEP == 1) {
-            ratL[i] = (first ? multiL : remL[i]) / s[u];
-        } else if (SWEEP == 2) {
-            const float rem = first ? multiR : remR[i];
-            const float offered = s[u] * rem;
-            const float consumption = fminf(rem / (offered + 1e-9f), 1.0f);
-            ratR[i] = consumption * rem;
-            remR[i] = fmaxf(0.0f, rem - offered);
+        const int i = base + u * kThreads + tid;
+        if (i >= n) continue;
+        S rem = first ? multiL : (first3 ? multiL : st.remL[i]);
+        if (kDo3) {
+            // the reference multiplies every term by ratL[k] inside the sum; factoring it out changes the rounding of
+            // the sum by < 1 ulp per term
+            const S given = s3[u] * ratL_prev[i];
+            rem = rem - given > 0 ? rem - given : 0;
+            st.remL[i] = rem;
+        }
+        if (kDo1) ratL_cur[i] = rem / s1[u];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- receiver pass
+// Own points = receivers l: sweep 2 of level `lev`.  grid (ceil(m / 512), b).
+template <bool HOST>
+__global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2, void *temp, int lev,
+                                                               int slots)
+{
+    using S = typename Sem<HOST>::S;
+    __shared__ float4 tile[kTile];
+    __shared__ S ws[HOST ? kTile : 1];
+    const int cloud = blockIdx.y, tid = threadIdx.x;
+    const float *p1 = xyz1 + (size_t)cloud * n * 3;
+    const float *p2 = xyz2 + (size_t)cloud * m * 3;
+    const State<HOST> st(temp, cloud, n, m, slots);
+    const int cur = slots > 1 ? lev : 0;
+    const S *ratL_cur = st.ratL + (size_t)cur * n;
+    S *ratR_cur = st.ratR + (size_t)cur * m;
+    const S multiR = n >= m ? (S)(n / m) : 1;
+    const bool first = lev == 0;
+    const float lv = level_value<HOST>(lev);
+    const float c = lv * kLog2e;
+
+    const int base = blockIdx.x * (kThreads * kPT);
+    float ox[kPT], oy[kPT], oz[kPT];
+#pragma unroll
+    for (int u = 0; u < kPT; ++u) {
+        const int i = base + u * kThreads + tid;
+        const bool live = i < m;
+        ox[u] = live ? p2[3 * i] : 0.f;
+        oy[u] = live ? p2[3 * i + 1] : 0.f;
+        oz[u] = live ? p2[3 * i + 2] : 0.f;
+    }
+    S t_[kPT];
+    f32x2 vx[kPV], vy[kPV], vz[kPV], acc[kPV];
+#pragma unroll
+    for (int u = 0; u < kPT; ++u) t_[u] = 0;
+#pragma unroll
+    for (int v = 0; v < kPV; ++v) {
+        vx[v] = f32x2{ox[2 * v], ox[2 * v + 1]};
+        vy[v] = f32x2{oy[2 * v], oy[2 * v + 1]};
+        vz[v] = f32x2{oz[2 * v], oz[2 * v + 1]};
+        acc[v] = f32x2{0.f, 0.f};
+    }
+    for (int o0 = 0; o0 < n; o0 += kTile) {
+        const int cnt = min(kTile, n - o0);
+        __syncthreads();
+        for (int q = tid; q < cnt; q += kThreads) {
+            const float *s = p1 + (size_t)(o0 + q) * 3;
+            const S w = ratL_cur[o0 + q];
+            tile[q] = make_float4(s[0], s[1], s[2], HOST ? 0.f : (float)w);
+            if (HOST) ws[q] = w;
+        }
+        __syncthreads();
+        if constexpr (HOST) {
+            for (int o = 0; o < cnt; ++o) {
+                const float4 t = tile[o];
+                const S w = ws[o];
+#pragma unroll
+                for (int u = 0; u < kPT; ++u)
+                    t_[u] += (double)host_exp((double)lv, sqdist_d(t.x, t.y, t.z, ox[u], oy[u], oz[u])) * w;
+            }
         } else {
-            // the reference multiplies every term by ratL[k] inside the sum; factoring it out changes the rounding
-            // of the sum by < 1 ulp per term and stays far inside the 1e-3 bar
-            const float given = s[u] * ratL[i];
-            remL[i] = fmaxf(0.0f, (first ? multiL : remL[i]) - given);
+#pragma unroll 4
+            for (int o = 0; o < cnt; ++o) {
+                const float4 t = tile[o];
+#pragma unroll
+                for (int v = 0; v < kPV; ++v) {
+                    const f32x2 dx = vx[v] - t.x, dy = vy[v] - t.y, dz = vz[v] - t.z;
+                    const f32x2 a = c * (dx * dx + dy * dy + dz * dz);
+                    f32x2 e;
+                    e[0] = __builtin_amdgcn_exp2f(a[0]);
+                    e[1] = __builtin_amdgcn_exp2f(a[1]);
+                    acc[v] += e * t.w;
+                }
+            }
+        }
+    }
+    if constexpr (!HOST) {
+#pragma unroll
+        for (int u = 0; u < kPT; ++u) t_[u] = acc[u / 2][u % 2];
+    }
+#pragma unroll
+    for (int u = 0; u < kPT; ++u) {
+        const int i = base + u * kThreads + tid;
+        if (i >= m) continue;
+        const S rem = first ? multiR : st.remR[i];
+        if constexpr (HOST) {
+            const double colsum = 1e-9 + rem * t_[u];
+            const double r = rem / colsum < 1.0 ? rem / colsum : 1.0;
+            ratR_cur[i] = r * rem;
+            const double left = rem - r * rem * t_[u];
+            st.remR[i] = left > 0.0 ? left : 0.0;
+        } else {
+            const float offered = t_[u] * rem;
+            const float consumption = fminf(rem / (offered + 1e-9f), 1.0f);
+            ratR_cur[i] = consumption * rem;
+            st.remR[i] = fmaxf(0.0f, rem - offered);
         }
     }
 }
 
-constexpr int kEmitRows = 64;  // receiver rows (l) per workgroup in the emit kernel
-
-// match[l][k] for one cloud; grid (ceil(n/256), ceil(m/kEmitRows), b).
-__global__ __launch_bounds__(256) void approx_match_emit_kernel(int n, int m, const float *__restrict__ xyz1,
-                                                                const float *__restrict__ xyz2,
-                                                                const float *__restrict__ temp,
-                                                                float *__restrict__ match)
+// ---------------------------------------------------------------------------------------------------- match value
+// match entry of one pair from the per-level ratios: rl = giver ratios (one per level), rr = receiver ratios.
+// DEVICE: fp32 sum over the levels in order.  HOST: every level's double term is added to the float match entry
+// (the reference's `match[k] += weight[k]` on a float tensor).
+template <bool HOST, typename RL, typename RR>
+__device__ __forceinline__ float pair_match(float ax, float ay, float az, float bx, float by, float bz, const RL &rl,
+                                            const RR &rr)
 {
-    __shared__ float rowp[kEmitRows][4];            // x, y, z of receiver l
-    __shared__ float rowr[kEmitRows][kLevels + 2];  // its ratio per level (padded)
-    const int cloud = blockIdx.z, tid = threadIdx.x;
-    const int k = blockIdx.x * 256 + tid;
-    const int l0 = blockIdx.y * kEmitRows;
-    const int rows = min(kEmitRows, m - l0);
-    const float *p1 = xyz1 + (size_t)cloud * n * 3;
-    const float *p2 = xyz2 + (size_t)cloud * m * 3;
-    const float *st = temp + (size_t)cloud * ((size_t)(n + m) * (1 + kLevels));
-    const float *ratLall = st + n + m, *ratRall = ratLall + (size_t)kLevels * n;
-    for (int i = tid; i < rows * 3; i += 256) rowp[i / 3][i % 3] = p2[(size_t)l0 * 3 + i];
-    for (int i = tid; i < rows * kLevels; i += 256) {
-        const int r = i / kLevels, lev = i % kLevels;
-        rowr[r][lev] = ratRall[(size_t)lev * m + l0 + r];
-    }
-    float lvl[kLevels], rl[kLevels];
-    const bool live = k < n;
-    const float x = live ? p1[3 * k] : 0.f, y = live ? p1[3 * k + 1] : 0.f, z = live ? p1[3 * k + 2] : 0.f;
-#pragma unroll
-    for (int lev = 0; lev < kLevels; ++lev) {
-        lvl[lev] = level_log2e(lev);
-        rl[lev] = live ? ratLall[(size_t)lev * n + k] : 0.f;
-    }
-    __syncthreads();
-    if (!live) return;
-    float *out = match + ((size_t)cloud * m + l0) * n + k;
-    for (int r = 0; r < rows; ++r) {
-        const float d2 = sq3(rowp[r][0], rowp[r][1], rowp[r][2], x, y, z);
+    constexpr int L = Sem<HOST>::levels;
+    if constexpr (HOST) {
+        const double d2 = sqdist_d(ax, ay, az, bx, by, bz);
         float acc = 0.f;
 #pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) acc += __builtin_amdgcn_exp2f(lvl[lev] * d2) * rl[lev] * rowr[r][lev];
-        out[(size_t)r * n] = acc;
+        for (int i = 0; i < L; ++i) {
+            const double w = (double)host_exp((double)level_value<true>(i), d2) * rl[i] * rr[i];
+            acc = (float)((double)acc + w);
+        }
+        return acc;
+    } else {
+        const float dx = ax - bx, dy = ay - by, dz = az - bz;
+        float e[9];
+        device_level_exps(dx * dx + dy * dy + dz * dz, e);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc += e[i] * rl[i] * rr[i];
+        return acc + rl[9] * rr[9];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- emit
+constexpr int kEmitRows = 64;
+
+// Writes match once from the ratios of every level.  The contiguous index ("column") of the output is the giver k in
+// the DEVICE layout [m][n] and the receiver l in the HOST layout [n][m]; threads run along it.
+// grid (ceil(cols / 256), ceil(rows / kEmitRows), b).
+template <bool HOST>
+__global__ __launch_bounds__(256) void emd_emit_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                      const float *__restrict__ xyz2, void *temp,
+                                                      float *__restrict__ match)
+{
+    using S = typename Sem<HOST>::S;
+    constexpr int L = Sem<HOST>::levels;
+    __shared__ float rowp[kEmitRows][4];
+    __shared__ S rowr[kEmitRows][L + 1];
+    const int cloud = blockIdx.z, tid = threadIdx.x;
+    const int cols = HOST ? m : n, rows = HOST ? n : m;
+    const float *pc = (HOST ? xyz2 : xyz1) + (size_t)cloud * cols * 3;  // column points
+    const float *pr = (HOST ? xyz1 : xyz2) + (size_t)cloud * rows * 3;  // row points
+    const State<HOST> st(temp, cloud, n, m, L);
+    const S *ratC = HOST ? st.ratR : st.ratL, *ratRow = HOST ? st.ratL : st.ratR;
+    const int c = blockIdx.x * 256 + tid;
+    const int r0 = blockIdx.y * kEmitRows;
+    const int nr = min(kEmitRows, rows - r0);
+    for (int i = tid; i < nr * 3; i += 256) rowp[i / 3][i % 3] = pr[(size_t)r0 * 3 + i];
+    for (int i = tid; i < nr * L; i += 256) rowr[i / L][i % L] = ratRow[(size_t)(i % L) * rows + r0 + i / L];
+    const bool live = c < cols;
+    const float x = live ? pc[3 * c] : 0.f, y = live ? pc[3 * c + 1] : 0.f, z = live ? pc[3 * c + 2] : 0.f;
+    S rc[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) rc[i] = live ? ratC[(size_t)i * cols + c] : (S)0;
+    __syncthreads();
+    if (!live) return;
+    float *out = match + ((size_t)cloud * rows + r0) * cols + c;
+    for (int r = 0; r < nr; ++r) {
+        // DEVICE: column = giver, row = receiver; HOST: column = receiver, row = giver
+        const float v = HOST ? pair_match<true>(rowp[r][0], rowp[r][1], rowp[r][2], x, y, z, rowr[r], rc)
+                             : pair_match<false>(x, y, z, rowp[r][0], rowp[r][1], rowp[r][2], rc, rowr[r]);
+        out[(size_t)r * cols] = v;
+    }
+}
+
+// Compact path (DEVICE only): match[l][k] (+)= e_lev * ratL[k] * ratR[l] from the single ratio slot, once per level.
+__global__ __launch_bounds__(256) void emd_accumulate_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                            const float *__restrict__ xyz2, void *temp,
+                                                            float *__restrict__ match, int lev)
+{
+    __shared__ float rowp[kEmitRows][4];
+    const int cloud = blockIdx.z, tid = threadIdx.x;
+    const float *p1 = xyz1 + (size_t)cloud * n * 3, *p2 = xyz2 + (size_t)cloud * m * 3;
+    const State<false> st(temp, cloud, n, m, 1);
+    const int k = blockIdx.x * 256 + tid;
+    const int l0 = blockIdx.y * kEmitRows;
+    const int nr = min(kEmitRows, m - l0);
+    for (int i = tid; i < nr; i += 256) {
+        rowp[i][0] = p2[(size_t)(l0 + i) * 3];
+        rowp[i][1] = p2[(size_t)(l0 + i) * 3 + 1];
+        rowp[i][2] = p2[(size_t)(l0 + i) * 3 + 2];
+        rowp[i][3] = st.ratR[l0 + i];
+    }
+    __syncthreads();
+    if (k >= n) return;
+    const float x = p1[3 * k], y = p1[3 * k + 1], z = p1[3 * k + 2], rl = st.ratL[k];
+    float *out = match + ((size_t)cloud * m + l0) * n + k;
+    for (int r = 0; r < nr; ++r) {
+        const float dx = x - rowp[r][0], dy = y - rowp[r][1], dz = z - rowp[r][2];
+        const float term = device_level_exp(dx * dx + dy * dy + dz * dz, lev) * rl * rowp[r][3];
+        // level 0 starts the sum from 0: 0 + term == term exactly, as in the emit kernel
+        out[(size_t)r * n] = lev == 0 ? term : out[(size_t)r * n] + term;
     }
 }
 
@@ -190,6 +472,96 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- fused loss
+// Cost and gradients straight from the ratios: match is never stored.  ROLE 0: own = givers k -> grad1[k] and the
+// cloud's cost (atomic add of per-workgroup sums into the pre-zeroed output); ROLE 1: own = receivers l -> grad2[l].
+// Every pair's match entry is recomputed in both roles (13 flops + 3 exponentials each) instead of being written once
+// and read three times.  grid (ceil(own / 256), b).
+constexpr int kLossTile = 256;
+
+template <bool HOST, int ROLE>
+__global__ __launch_bounds__(256) void emd_loss_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                      const float *__restrict__ xyz2, void *temp,
+                                                      float *__restrict__ cost, float *__restrict__ grad)
+{
+    using S = typename Sem<HOST>::S;
+    constexpr int L = Sem<HOST>::levels;
+    __shared__ float4 tp[kLossTile];
+    __shared__ S tr[kLossTile][L + 1];
+    __shared__ double part[4];
+    const int cloud = blockIdx.y, tid = threadIdx.x;
+    const int nown = ROLE == 0 ? n : m, nother = ROLE == 0 ? m : n;
+    const float *own = (ROLE == 0 ? xyz1 : xyz2) + (size_t)cloud * nown * 3;
+    const float *other = (ROLE == 0 ? xyz2 : xyz1) + (size_t)cloud * nother * 3;
+    const State<HOST> st(temp, cloud, n, m, L);
+    const S *ratOwn = ROLE == 0 ? st.ratL : st.ratR, *ratOther = ROLE == 0 ? st.ratR : st.ratL;
+    const int i = blockIdx.x * 256 + tid;
+    const bool live = i < nown;
+    const float x = live ? own[3 * i] : 0.f, y = live ? own[3 * i + 1] : 0.f, z = live ? own[3 * i + 2] : 0.f;
+    S ro[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) ro[q] = live ? ratOwn[(size_t)q * nown + i] : (S)0;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    S csum = 0;
+    for (int o0 = 0; o0 < nother; o0 += kLossTile) {
+        const int cnt = min(kLossTile, nother - o0);
+        __syncthreads();
+        if (tid < cnt) {
+            const float *s = other + (size_t)(o0 + tid) * 3;
+            tp[tid] = make_float4(s[0], s[1], s[2], 0.f);
+        }
+        for (int q = tid; q < cnt * L; q += 256) tr[q % cnt][q / cnt] = ratOther[(size_t)(q / cnt) * nother + o0 + q % cnt];
+        __syncthreads();
+        if (!live) continue;
+        for (int o = 0; o < cnt; ++o) {
+            const float4 t = tp[o];
+            // giver first, receiver second, whatever the role
+            const float mv = ROLE == 0 ? pair_match<HOST>(x, y, z, t.x, t.y, t.z, ro, tr[o])
+                                       : pair_match<HOST>(t.x, t.y, t.z, x, y, z, tr[o], ro);
+            const float dx = x - t.x, dy = y - t.y, dz = z - t.z;  // own - other
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if constexpr (HOST) {
+                // tf_approxmatch.cpp:85-140: unit vector by a division, distance floored at 1e-20
+                const float d = fmaxf(sqrtf(d2), 1e-20f);
+                gx += mv * (dx / d);
+                gy += mv * (dy / d);
+                gz += mv * (dz / d);
+                if (ROLE == 0) csum += (double)(sqrtf(d2) * mv);
+            } else {
+                // tf_approxmatch_g.cu:183-291: rsqrt of the squared distance floored at 1e-20
+                const float s = mv * rsqrtf(fmaxf(d2, 1e-20f));
+                gx += dx * s;
+                gy += dy * s;
+                gz += dz * s;
+                if (ROLE == 0) csum += sqrtf(d2) * mv;
+            }
+        }
+    }
+    if (live && grad) {
+        float *g = grad + ((size_t)cloud * nown + i) * 3;
+        g[0] = gx;
+        g[1] = gy;
+        g[2] = gz;
+    }
+    if (ROLE == 0) {
+        double v = wave_sum_d((double)csum);
+        __syncthreads();
+        if ((tid & 63) == 0) part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) atomicAdd(&cost[cloud], (float)(part[0] + part[1] + part[2] + part[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- cost / grad of
+// a materialised match (DEVICE layout [m][n]; a HOST-layout match is the DEVICE layout of the swapped clouds)
+
 // cost[cloud] = sum_{l,k} |p2_l - p1_k| * match[l][k]; the match slab is streamed once.  grid (b, slices): a
 // workgroup takes `rows` receiver rows of one cloud; with more than one slice per cloud the partial sums meet in an
 // fp32 atomic on the pre-zeroed output.
@@ -198,7 +570,7 @@ __global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, int rows
                                                           const float *__restrict__ match, float *__restrict__ out,
                                                           int atomic)
 {
-    __shared__ float4 tile[kTile];
+    __shared__ float4 tile[2048];
     __shared__ float part[16];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
@@ -206,8 +578,8 @@ __global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, int rows
     const float *mt = match + (size_t)cloud * n * m;
     const int lbeg = blockIdx.y * rows, lend = min(m, lbeg + rows);
     float acc = 0.f;
-    for (int l0 = lbeg; l0 < lend; l0 += kTile) {
-        const int cnt = min(kTile, lend - l0);
+    for (int l0 = lbeg; l0 < lend; l0 += 2048) {
+        const int cnt = min(2048, lend - l0);
         __syncthreads();
         for (int p = tid; p < cnt; p += 1024) {
             const float *s = p2 + (size_t)(l0 + p) * 3;
@@ -220,7 +592,8 @@ __global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, int rows
 #pragma unroll 8
             for (int l = 0; l < cnt; ++l) {
                 const float4 t = tile[l];
-                acc += sqrtf(sq3(t.x, t.y, t.z, x, y, z)) * col[(size_t)l * n];
+                const float dx = t.x - x, dy = t.y - y, dz = t.z - z;
+                acc += sqrtf(dx * dx + dy * dy + dz * dz) * col[(size_t)l * n];
             }
         }
     }
@@ -243,7 +616,7 @@ __global__ __launch_bounds__(256) void match_cost_grad1_kernel(int n, int m, con
                                                                const float *__restrict__ match,
                                                                float *__restrict__ grad1)
 {
-    __shared__ float4 tile[kTile];
+    __shared__ float4 tile[2048];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const int k = blockIdx.x * 256 + tid;
     const bool live = k < n;
@@ -252,8 +625,8 @@ __global__ __launch_bounds__(256) void match_cost_grad1_kernel(int n, int m, con
     const float *mt = match + (size_t)cloud * n * m;
     const float x = live ? p1[3 * k] : 0.f, y = live ? p1[3 * k + 1] : 0.f, z = live ? p1[3 * k + 2] : 0.f;
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int l0 = 0; l0 < m; l0 += kTile) {
-        const int cnt = min(kTile, m - l0);
+    for (int l0 = 0; l0 < m; l0 += 2048) {
+        const int cnt = min(2048, m - l0);
         __syncthreads();
         for (int p = tid; p < cnt; p += 256) {
             const float *s = p2 + (size_t)(l0 + p) * 3;
@@ -324,32 +697,123 @@ int check_emd_args(const char *op, int b, int n, int m)
     return MPSR_OK;
 }
 
-}  // namespace
-
-extern "C" size_t mpsr_approx_match_temp_floats(int b, int n, int m)
+size_t state_floats(int b, int n, int m, int levels, bool host)
 {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return (size_t)b * ((size_t)(n + m) * (1 + kLevels));
+    return (size_t)b * ((size_t)(n + m) * (1 + levels)) * (host ? 2 : 1);
 }
 
-extern "C" int mpsr_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
-                                 float *temp, mpsr_stream_t stream)
+// the 2L + 1 passes; `slots` = levels (ratios of every level kept) or 1; `between` runs after the receiver pass of
+// each level (the compact path accumulates match there)
+template <bool HOST, typename F>
+int run_passes(int b, int n, int m, const float *xyz1, const float *xyz2, void *temp, int slots, hipStream_t s,
+               F between)
+{
+    constexpr int L = Sem<HOST>::levels;
+    const dim3 gl(mpsr::ceil_div(n, kThreads * kPT), b), gr(mpsr::ceil_div(m, kThreads * kPT), b);
+    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots);
+    for (int lev = 0; lev < L; ++lev) {
+        hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots);
+        if (int rc = between(lev)) return rc;
+        if (lev + 1 < L)
+            hipLaunchKernelGGL((emd_giver_kernel<HOST, 1>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev + 1,
+                               slots);
+        // the giver capacity after the last level is never read: no trailing sweep 3
+    }
+    MPSR_CHECK_LAUNCH("emd passes");
+    return MPSR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mpsr_emd_temp_floats(int b, int n, int m, int semantics)
+{
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return semantics == MPSR_EMD_HOST ? state_floats(b, n, m, Sem<true>::levels, true)
+                                      : state_floats(b, n, m, Sem<false>::levels, false);
+}
+
+extern "C" size_t mpsr_approx_match_temp_floats(int b, int n, int m) { return mpsr_emd_temp_floats(b, n, m, MPSR_EMD_DEVICE); }
+
+extern "C" int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                    float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream)
 {
     if (int rc = check_emd_args("approx_match", b, n, m)) return rc;
+    MPSR_REQUIRE(semantics == MPSR_EMD_DEVICE || semantics == MPSR_EMD_HOST, "approx_match: unknown semantics %d",
+                 semantics);
     if (b == 0) return MPSR_OK;
     MPSR_REQUIRE(xyz1 && xyz2 && match && temp, "approx_match: null pointer");
     hipStream_t s = mpsr::as_stream(stream);
-    const dim3 gl(mpsr::ceil_div(n, kSweepThreads * kPT), b), gr(mpsr::ceil_div(m, kSweepThreads * kPT), b);
-    for (int lev = 0; lev < kLevels; ++lev) {
-        hipLaunchKernelGGL(approx_match_sweep_kernel<1>, gl, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
-        hipLaunchKernelGGL(approx_match_sweep_kernel<2>, gr, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
-        hipLaunchKernelGGL(approx_match_sweep_kernel<3>, gl, dim3(kSweepThreads), 0, s, n, m, xyz1, xyz2, temp, lev);
+    const size_t full = mpsr_emd_temp_floats(b, n, m, semantics);
+    const size_t compact = state_floats(b, n, m, 1, false);
+    if (semantics == MPSR_EMD_HOST) {
+        MPSR_REQUIRE(((uintptr_t)temp & 7) == 0, "approx_match: temp must be 8-byte aligned for the host semantics");
+        if (temp_floats < full)
+            return mpsr::fail(MPSR_ERR_WORKSPACE, "approx_match (host semantics): temp holds %zu floats, needs %zu",
+                              temp_floats, full);
+        if (int rc = run_passes<true>(b, n, m, xyz1, xyz2, temp, Sem<true>::levels, s, [](int) { return 0; })) return rc;
+        dim3 grid(mpsr::ceil_div(m, 256), mpsr::ceil_div(n, kEmitRows), b);
+        MPSR_REQUIRE(grid.y <= 65535, "approx_match: n=%d too large", n);
+        hipLaunchKernelGGL(emd_emit_kernel<true>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match);
+        MPSR_CHECK_LAUNCH("emd_emit_kernel");
+        return MPSR_OK;
     }
-    MPSR_CHECK_LAUNCH("approx_match_sweep_kernel");
     dim3 grid(mpsr::ceil_div(n, 256), mpsr::ceil_div(m, kEmitRows), b);
     MPSR_REQUIRE(grid.y <= 65535, "approx_match: m=%d too large", m);
-    hipLaunchKernelGGL(approx_match_emit_kernel, grid, dim3(256), 0, s, n, m, xyz1, xyz2, temp, match);
-    MPSR_CHECK_LAUNCH("approx_match_emit_kernel");
+    if (temp_floats >= full) {
+        if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
+            return rc;
+        hipLaunchKernelGGL(emd_emit_kernel<false>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match);
+        MPSR_CHECK_LAUNCH("emd_emit_kernel");
+        return MPSR_OK;
+    }
+    if (temp_floats < compact)
+        return mpsr::fail(MPSR_ERR_WORKSPACE,
+                          "approx_match: temp holds %zu floats; needs %zu (b*(n+m)*2, the reference shell's scratch) "
+                          "or %zu (mpsr_approx_match_temp_floats, the fast path)",
+                          temp_floats, compact, full);
+    // the reference shell's scratch: one ratio slot, match accumulated level by level
+    return run_passes<false>(b, n, m, xyz1, xyz2, temp, 1, s, [&](int lev) {
+        hipLaunchKernelGGL(emd_accumulate_kernel, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match, lev);
+        return 0;
+    });
+}
+
+extern "C" int mpsr_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                 size_t temp_floats, mpsr_stream_t stream)
+{
+    return mpsr_approx_match_ex(b, n, m, xyz1, xyz2, match, temp, temp_floats, MPSR_EMD_DEVICE, stream);
+}
+
+extern "C" int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                             float *grad2, float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream)
+{
+    if (int rc = check_emd_args("emd_loss", b, n, m)) return rc;
+    MPSR_REQUIRE(semantics == MPSR_EMD_DEVICE || semantics == MPSR_EMD_HOST, "emd_loss: unknown semantics %d", semantics);
+    if (b == 0) return MPSR_OK;
+    MPSR_REQUIRE(xyz1 && xyz2 && cost && temp, "emd_loss: null pointer");
+    const size_t full = mpsr_emd_temp_floats(b, n, m, semantics);
+    if (temp_floats < full)
+        return mpsr::fail(MPSR_ERR_WORKSPACE, "emd_loss: temp holds %zu floats, needs %zu (mpsr_emd_temp_floats)",
+                          temp_floats, full);
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(hipMemsetAsync(cost, 0, sizeof(float) * b, s));
+    const dim3 g1(mpsr::ceil_div(n, 256), b), g2(mpsr::ceil_div(m, 256), b);
+    if (semantics == MPSR_EMD_HOST) {
+        MPSR_REQUIRE(((uintptr_t)temp & 7) == 0, "emd_loss: temp must be 8-byte aligned for the host semantics");
+        if (int rc = run_passes<true>(b, n, m, xyz1, xyz2, temp, Sem<true>::levels, s, [](int) { return 0; })) return rc;
+        hipLaunchKernelGGL((emd_loss_kernel<true, 0>), g1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1);
+        if (grad2)
+            hipLaunchKernelGGL((emd_loss_kernel<true, 1>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost,
+                               grad2);
+    } else {
+        if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
+            return rc;
+        hipLaunchKernelGGL((emd_loss_kernel<false, 0>), g1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1);
+        if (grad2)
+            hipLaunchKernelGGL((emd_loss_kernel<false, 1>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost,
+                               grad2);
+    }
+    MPSR_CHECK_LAUNCH("emd_loss_kernel");
     return MPSR_OK;
 }
 

@@ -81,6 +81,18 @@ def main():
                   "match_cost_GBps": round(mbytes / t_c / 1e9, 1),
                   "match_cost_grad_GBps": round(2 * mbytes / t_g / 1e9, 1),
                   "clouds_per_s(match+cost+grad)": round(b / (t_m + t_c + t_g), 1)}
+    with torch.no_grad():
+        t_f = timeit(lambda: am.emd_loss_fwd_bwd(y1, y2), 3)
+        t_fc = timeit(lambda: am.emd_loss_fwd_bwd(y1, y2, want_grads=False), 3)
+        t_cp = timeit(lambda: am.approx_match(y1, y2, temp_floats=b * 2 * n * 2), 2)
+        hb = max(1, b // 16)
+        t_h = timeit(lambda: am.emd_loss_fwd_bwd(y1[:hb], y2[:hb], semantics="host"), 1) * (b / hb)
+    # pair evaluations of the fused loss: 21 passes x 1 exponential + 2 loss passes x 3 exponentials
+    out["emd"].update({"fused_loss_ms": round(t_f * 1e3, 2), "fused_cost_only_ms": round(t_fc * 1e3, 2),
+                       "approx_match_compact_scratch_ms": round(t_cp * 1e3, 2),
+                       "fused_loss_host_semantics_ms(extrapolated from %d clouds)" % hb: round(t_h * 1e3, 1),
+                       "fused_loss_clouds_per_s": round(b / t_f, 1),
+                       "fused_loss_Gexp_per_s": round((21.0 + 6.0) * b * n * n / t_f / 1e9, 1)})
     c = 2
     a1, a2 = y1[:c].cpu().numpy(), y2[:c].cpu().numpy()
     t0 = time.perf_counter()
