@@ -5,7 +5,13 @@
  * an explicit HIP stream (passed as void* so this header needs no HIP include), returns an int status
  * (MPSR_OK == 0) and never allocates, frees or synchronises.  Outputs and scratch are caller-allocated; the
  * *_bytes / *_floats helpers say how much.  All tensors are contiguous; floats are fp32, indices int32,
- * images/activations NHWC.  Thread-safe and stateless (the last error string is thread-local).
+ * images/activations NHWC.
+ *
+ * Threads: every entry point may be called from any number of threads at once (on different streams, with different
+ * scratch); the library keeps no per-call state and the last-error string is thread-local.  The one piece of
+ * process-wide configuration is the contraction arithmetic (mpsr_set_conv_math): it is an atomic setting read at every
+ * launch, so changing it while another thread is in the middle of a network entry point gives that pass a mix of both
+ * arithmetics -- set it before starting work, as bench.py and the tests do.
  *
  * Each declaration cites the reference interface it replaces (paths under /root/reference/src).
  * The first five keep the argument order of the reference's launcher functions so the reference's TF op
