@@ -185,15 +185,84 @@ def conv_replay(net, B):
     for k in range(1, hd.n):  # img_fc (split-K + reduce kernel) is left out: it is not a pure conv launch
         add(hd, k, (B, 1, 1), {1: 1043, 4: 1060}.get(k))
 
+    # the network entry points hand every layer the scheduling scratch and leave the schedule to the library
+    # (split_k = 0); the replay does the same, so it launches the kernels a step launches
+    nws = max(lib.mpsr_conv2d_scratch_floats(Bq, H, W, r["cout"]) for _, _, _, r, Bq, H, W, _ in jobs)
+    ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+
     def run():
         s = _lib.stream()
         for x, y, blob, r, Bq, H, W, _ in jobs:
             bias = blob.data_ptr() + 4 * r["b_off"] if r["b_off"] >= 0 else None
             _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), Bq, H, W, r["cin"], blob.data_ptr() + 4 * r["w_off"],
                                                 bias, None, y.data_ptr(), r["cout"], r["kh"], r["kw"], r["dilation"],
-                                                r["relu"], 1, None, 0, s))
+                                                r["relu"], 0, ws.data_ptr(), nws, s))
     flops = sum(2.0 * Bq * H * W * cin * r["kh"] * r["kw"] * r["cout"] for _, _, _, r, Bq, H, W, cin in jobs)
-    return run, len(jobs), flops
+    # algorithmic HBM bytes of a launch: its input, weights and output once each
+    alg_bytes = sum(4.0 * (Bq * H * W * (r["cin"] + r["cout"]) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
+                    for _, _, _, r, Bq, H, W, _ in jobs)
+    return run, len(jobs), flops, alg_bytes
+
+
+def mfma_box_peak(device):
+    """fp32 MFMA rate this board sustains with nothing but v_mfma_f32_32x32x2_f32 (4 waves per SIMD): MI355X boards
+    differ in sustained clock, so the roofline fraction is quoted against the 157.3 TFLOP/s datasheet peak AND next to
+    this figure measured in the same process."""
+    from monopsr_amd import _lib
+    import ctypes
+    lib = _lib.lib()
+    fn = lib.mpsr_debug_mfma_peak
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    out = torch.zeros(4, device=device)
+    waves, iters = 4, 2000
+    _lib.check(fn(out.data_ptr(), cus, waves, 4, 100, _lib.stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        _lib.check(fn(out.data_ptr(), cus, waves, 4, iters, _lib.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    return cus * 4 * waves * iters * 16 * 4096.0 * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def emd_object(device, b=256, n=2048):
+    """BASELINE config 5's per-GPU share (256 clouds x 2048^2 points) through the EMD loss: the fused path
+    (mpsr_emd_loss: 21 passes + 2 loss passes, no match tensor) and the materialising ops next to it."""
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    g = torch.Generator(device=device).manual_seed(6)
+    x1 = torch.rand((b, n, 3), device=device, generator=g) * 2 - 1
+    x2 = torch.rand((b, n, 3), device=device, generator=g) * 2 - 1
+
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    t_f = timeit(lambda: am.emd_loss_fwd_bwd(x1, x2), 5)
+    match = am.approx_match(x1, x2)
+    t_m = timeit(lambda: am.approx_match(x1, x2), 3)
+    t_c = timeit(lambda: am.match_cost(x1, x2, match), 3)
+    t_g = timeit(lambda: am.match_cost_grad(x1, x2, match), 3)
+    pairs = float(b) * n * n
+    exps = (21.0 + 6.0) * pairs  # one exponential per pair and pass, three per pair in each of the two loss passes
+    return {"shape": [b, n, n], "workload": "BASELINE cfg5 per-GPU share: approx_match + match_cost + gradients",
+            "fused_loss_ms": round(t_f * 1e3, 3), "fused_clouds_per_s": round(b / t_f, 1),
+            "fused_exp_per_s": float("%.4g" % (exps / t_f)), "exp_peak_per_s": 9.83e12,
+            "fused_exp_frac_of_quarter_rate_peak": round(exps / t_f / 9.83e12, 3),
+            "materialising_ops_ms": {"approx_match": round(t_m * 1e3, 3), "match_cost": round(t_c * 1e3, 3),
+                                     "match_cost_grad": round(t_g * 1e3, 3)},
+            "match_bytes": int(4 * pairs), "approx_match_write_GBps": round(4 * pairs / t_m / 1e9, 1),
+            "match_cost_read_GBps": round(4 * pairs / t_c / 1e9, 1),
+            "match_cost_grad_read_GBps": round(8 * pairs / t_g / 1e9, 1), "hbm_peak_GBps": 8000,
+            "bound": "v_exp_f32 issue (passes), HBM (materialised match)"}
 
 
 def cpu_baseline(weights, host, sample, npts):
@@ -238,6 +307,7 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="also all-reduce a 100,204,832-float buffer per step (size of the model's gradient)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-emd", action="store_true", help="skip the extra EMD (BASELINE config 5) object")
     ap.add_argument("--streams", type=int, default=1,
                     help="split each GPU's batch into this many instance shards on separate HIP streams")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
@@ -386,7 +456,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel alone: every conv/FC launch of one step, timed with events on the launch stream
-        run, launches, flops = conv_replay(net, args.batch)
+        run, launches, flops, alg_bytes = conv_replay(net, args.batch)
         run()
         torch.cuda.synchronize()
         reps = max(3, min(10, args.steps))
@@ -398,14 +468,19 @@ def main():
         torch.cuda.synchronize()
         avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * launches)
         achieved = flops / launches / avg_s / 1e12
-        # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes
-        # over this same command (profiles/rNN_pmc_traffic.json, bytes per conv launch), newest round first
-        traffic = None
+        # HBM traffic and MFMA-busy cycles cannot be counted from inside the process: they come from the newest
+        # committed rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/
+        # rNN_pmc_traffic.json), quoted with the round and commit they were collected at
+        traffic = busy = src = None
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 with open(path) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                    pm = json.load(f)
+                traffic = round(pm["hbm_bytes_per_launch"])
+                busy = pm.get("mfma_busy")
+                src = {"file": os.path.relpath(path, ROOT), "round": pm.get("round"), "commit": pm.get("commit"),
+                       "collected": pm.get("collected")}
                 break
             except Exception:
                 pass
@@ -416,7 +491,19 @@ def main():
                               "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                               "frac": round(achieved / peak, 4), "traffic": traffic if args.math == "fp32" else None,
                               "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
-                              "flops_per_launch": round(flops / launches)}
+                              "flops_per_launch": round(flops / launches),
+                              "algorithmic_bytes": round(alg_bytes / launches)}
+        if args.math == "fp32":
+            if traffic:
+                result["roofline"]["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
+                result["roofline"]["mfma_busy"] = busy
+                result["roofline"]["traffic_source"] = src
+            try:
+                box = mfma_box_peak(device)
+                result["roofline"]["peak_measured_on_this_board"] = round(box, 1)
+                result["roofline"]["frac_of_measured"] = round(achieved / box, 4)
+            except Exception as e:
+                result["roofline"]["peak_measured_on_this_board"] = repr(e)
     if rank == 0 and not args.no_roofline:
         # the Chamfer op alone, as the north star asks ("achieved HBM GB/s on nn_distance"): algorithmic bytes =
         # b*(n+m)*20 forward (12 read + 8 written per point), b*(n+m)*32 backward; the kernel is VALU-bound, so the
@@ -448,6 +535,11 @@ def main():
                 "bound": "valu (fwd), hbm/lds (bwd)"}
         except Exception as e:
             result["nn_distance"] = {"error": repr(e)}
+    if rank == 0 and not args.no_roofline and not args.no_emd:
+        try:
+            result["emd"] = emd_object(device)
+        except Exception as e:
+            result["emd"] = {"error": repr(e)}
     if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
         # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
         # on the same inputs (NOT the headline: `value` above is fp32)
