@@ -914,6 +914,7 @@ std::atomic<int> g_tile_override{-1};
 std::atomic<int> g_class_override{-1};
 std::atomic<int> g_sched_override{-1};
 std::atomic<int> g_sk_per_cu{0};
+std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
 
@@ -986,6 +987,11 @@ namespace mpsr {
 
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s);  // image_ops.hip
+// winograd.hip
+size_t winograd_scratch_floats(int C, int N);
+bool winograd_applies(int H, int W, int C, int N);
+int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
+                     int N, float *ws, size_t ws_floats, hipStream_t s);
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
@@ -1039,6 +1045,16 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
         g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
         return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream);
+    // the big dense 3x3 layers (map decoder) go to the Winograd F(2x2,3x3) kernel when the caller leaves the schedule
+    // to the library: 2.25x fewer multiply-adds (winograd.hip)
+    {
+        int wino = g_wino_override.load();
+        const bool can = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws &&
+                         g_math.load() == MATH_FP32 && winograd_applies(H, W, C, N) &&
+                         ws_floats >= winograd_scratch_floats(C, N);
+        if (wino < 0) wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
+        if (wino == 1 && can) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+    }
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;
@@ -1138,6 +1154,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
 extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
 extern "C" void mpsr_debug_set_conv_depth(int depth) { g_depth_override = depth; }
+extern "C" void mpsr_debug_set_conv_winograd(int mode) { g_wino_override = mode; }
 extern "C" void mpsr_debug_set_conv_sched(int mode, int per_cu)
 {
     g_sched_override = mode;

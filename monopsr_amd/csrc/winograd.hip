@@ -1,0 +1,394 @@
+// 3x3 stride-1 SAME convolution by the Winograd minimal-filtering algorithm F(2x2, 3x3) on fp32 MFMA, for the map
+// decoder's layers (24x24 / 48x48 maps, 128-512 channels: 32 % of the direct-convolution multiply-adds of a step).
+//
+//   y (2x2 block of output pixels) = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A,   d = the 4x4 input patch around it.
+// 16 products per output pair of (channel, 2x2 block) instead of 36: the contraction shrinks 2.25x.  The 16 elementwise
+// positions are 16 independent GEMMs  M_p[tile][n] = sum_c V_p[tile][c] * U_p[n][c]  (tile = one 2x2 output block).
+//
+// MI355X design: ONE kernel does input transform, the 16 GEMMs and the output transform -- neither V nor M ever reach
+// HBM (as separate passes they would move 8x the layer's own bytes).
+//   * workgroup = 64 tiles x 64 output channels x all 16 positions; 4 waves as 2 x 2, each wave 32 tiles x 32 channels
+//     x 16 positions = 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 accumulator registers (one wave per SIMD:
+//     the kernel is built for the 512-register budget that gives);
+//   * per K step of 16 input channels every thread loads the 16 pixels of one tile's patch for 4 channels (16-byte
+//     loads, out-of-image pixels by the buffer bounds check), transforms them in registers (32 add/sub per channel) and
+//     writes the 16 positions' A rows to LDS; the transformed filters U (made once per call by wino_filter_kernel, laid
+//     out [channel block][position][n][16] so a workgroup's slab is one contiguous 64 KiB read) go to LDS unchanged;
+//     the loads of step k+1 are in flight while step k's 128 MFMAs per wave run;
+//   * LDS rows are 16 + 4 floats: conflict-free ds_read_b128 fragments, one read feeds four MFMAs (same k-ordering
+//     trick as conv_mfma.hip);
+//   * the output transform is register arithmetic: all 16 position accumulators of a wave have the same lane layout,
+//     so A^T M A is 24 adds per element; bias + ReLU fused; each store instruction writes two 128-byte rows.
+// Numerics: fp32 throughout; transform constants are 0, +-1, +-1/2 (exact); measured error against float64
+// ~1e-6 of the tensor scale (direct fp32 MFMA path: ~5e-7), three orders inside the path's 1e-3 budget.
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int KC = 16;            // input channels per K step
+constexpr int ROW = KC + 4;       // floats per LDS row
+constexpr int MT = 64, NT = 64;   // tiles x output channels per workgroup
+constexpr int kLdsFloats = 2 * 16 * 64 * ROW;
+
+struct WinoParams {
+    const float *x, *u, *bias;
+    float *y;
+    int B, H, W, C, N, th, tw, T;  // th x tw tiles per image, T tiles in all
+    int cblocks, nblocks, mblocks, relu;
+    unsigned xbytes, ubytes;
+    unsigned long long *trace;  // -DWINO_TRACE builds: per-workgroup timestamps (tools/wino_trace.py)
+};
+
+// U[cb][pos][n][KC] = (G g G^T)[pos] for filter g = w[n][(ky*3+kx)*C + c], c = cb*KC + j.  One thread per (n, c).
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float *__restrict__ w, int N, int C, float *__restrict__ u)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * C) return;
+    const int n = (int)(i / C), c = (int)(i - (long long)n * C);
+    double g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(size_t)n * 9 * C + (size_t)(ky * 3 + kx) * C + c];
+    double t[4][3];  // G g
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        t[0][kx] = g[0][kx];
+        t[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+        t[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+        t[3][kx] = g[2][kx];
+    }
+    float *dst = u + ((size_t)(c / KC) * 16 * N + n) * KC + (c % KC);
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        const double r0 = t[xi][0], r1 = 0.5 * (t[xi][0] + t[xi][1] + t[xi][2]),
+                     r2 = 0.5 * (t[xi][0] - t[xi][1] + t[xi][2]), r3 = t[xi][2];
+        dst[(size_t)(xi * 4 + 0) * N * KC] = (float)r0;
+        dst[(size_t)(xi * 4 + 1) * N * KC] = (float)r1;
+        dst[(size_t)(xi * 4 + 2) * N * KC] = (float)r2;
+        dst[(size_t)(xi * 4 + 3) * N * KC] = (float)r3;
+    }
+}
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// a float4 as two packed pairs: the transforms then issue as v_pk_add_f32 (two adds per VALU slot)
+struct F4 {
+    f32x2 lo, hi;
+};
+__device__ __forceinline__ F4 ld4(const float4 &v) { return F4{f32x2{v.x, v.y}, f32x2{v.z, v.w}}; }
+__device__ __forceinline__ F4 operator+(const F4 &a, const F4 &b) { return F4{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ F4 operator-(const F4 &a, const F4 &b) { return F4{a.lo - b.lo, a.hi - b.hi}; }
+__device__ __forceinline__ void st4(float *dst, const F4 &v)
+{
+    *reinterpret_cast<float4 *>(dst) = make_float4(v.lo[0], v.lo[1], v.hi[0], v.hi[1]);
+}
+
+// K-loop schedule.  The 16 positions form two groups (g0 = positions 0-7, g1 = 8-15) with their own LDS regions.
+// One wave per SIMD means nothing else covers the time a wave spends filling LDS, so the fill of the NEXT data is
+// woven between the MFMAs of the CURRENT data, one 16-byte store per half step of 4 MFMAs:
+//     first half  of step k:  multiply g0(k)   while storing g1(k)      | barrier
+//     second half of step k:  multiply g1(k)   while storing g0(k+1)    | barrier
+// (a region is rewritten only after the barrier that follows its last read, and read only after the barrier that
+// follows its last store).  Global loads run a whole half step or more ahead of the store that consumes them; their
+// addresses are per-thread constants plus a scalar offset, so a load costs no vector ALU work.
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                   // [16][MT][ROW]
+    float *Bs = lds + 16 * MT * ROW;   // [16][NT][ROW]
+
+    // XCD x (workgroup b runs on XCD b % 8: speed only) takes M blocks x, x+8, ...; the N blocks of one M block run
+    // back to back on it, so the patches are fetched from HBM once
+    const int xcd = blockIdx.x & 7, l_ = blockIdx.x >> 3;
+    const int nb = l_ % p.nblocks;
+    const int mb = (l_ / p.nblocks) * 8 + xcd;
+    if (mb >= p.mblocks) return;  // block-uniform
+    const int n0 = nb * NT, t0 = mb * MT;
+#ifdef WINO_TRACE
+    unsigned long long ts[8];
+    int nts = 0;
+    ts[nts++] = __builtin_readcyclecounter();
+#define WINO_STAMP() do { if (nts < 8) ts[nts++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WINO_STAMP() do { } while (0)
+#endif
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, (int)p.ubytes, 0x00020000);
+
+    // ---- A loader: thread = (tile, channel quad); the 4x4 patch starts one pixel up-left of the tile's 2x2 block.
+    // One byte offset per patch pixel, fixed for the whole K loop (out-of-image pixels: an out-of-range offset, which
+    // the buffer load answers with zeros); the channel block comes in through the scalar offset.
+    const int ltile = tid >> 2, quad = tid & 3;
+    unsigned aoff[16];
+    {
+        const int t = t0 + ltile;
+        const int tpi = p.th * p.tw;
+        const int img = t / tpi, rem = t - img * tpi;
+        const int ty = rem / p.tw, tx = rem - ty * p.tw;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < p.H && x0 + s >= 0 && x0 + s < p.W;
+                aoff[r * 4 + s] = ok ? ((unsigned)((img * p.H + y0 + r) * p.W + x0 + s) * (unsigned)p.C + 4u * quad) * 4u
+                                     : p.xbytes;
+            }
+    }
+    // ---- B loader: position j's slab row (n, channel quad) of this thread; rows past N read as zeros
+    const unsigned boff = n0 + (tid >> 2) < p.N ? (unsigned)((n0 + (tid >> 2)) * KC + 4 * (tid & 3)) * 4u : p.ubytes;
+    const unsigned bstride = (unsigned)p.N * KC * 4u;  // bytes between positions (and 16 x that between channel blocks)
+
+    float4 pa[16], pb[8];
+    // `live` false (past the last channel block) turns the loads into out-of-range ones (zeros, no traffic).  The
+    // loads are issued UNCONDITIONALLY: around a branch hipcc can no longer count them and makes every later wait
+    // on the filter loads wait for these patch loads too (HBM latency exposed in every second half step).
+    auto load_a = [&](int cb, bool live) {
+        const unsigned so = live ? (unsigned)cb * KC * 4u : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            pa[i] = __builtin_bit_cast(float4,
+                                       __builtin_amdgcn_raw_buffer_load_b128(rx, live ? aoff[i] : p.xbytes, so, 0));
+    };
+    // filters of 4 positions (half a group) of channel block cb: always L2 hits (U is a few MB shared by every
+    // workgroup), so they are fetched only half a group of MFMAs before their store, into 8 float4 in all
+    auto load_b4 = [&](int cb, int pos0, int slot0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pb[slot0 + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           ru, boff, ((unsigned)cb * 16u + (unsigned)(pos0 + j)) * bstride, 0));
+    };
+    // rows of the input transform: t = B^T d, kept between the two halves of a step
+    F4 t[4][4];
+    auto row_transform = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const F4 d0 = ld4(pa[s]), d1 = ld4(pa[4 + s]), d2 = ld4(pa[8 + s]), d3 = ld4(pa[12 + s]);
+            t[0][s] = d0 - d2;
+            t[1][s] = d1 + d2;
+            t[2][s] = d2 - d1;
+            t[3][s] = d1 - d3;
+        }
+    };
+    float *arow = As + ltile * ROW + 4 * quad;
+    float *brow = Bs + (tid >> 2) * ROW + 4 * (tid & 3);
+    // piece i (0..15) of the stores of group g: pieces 0-7 the A rows of the group's positions, 8-15 the B rows
+    auto store_piece = [&](auto group_c, int i) {
+        constexpr int g = decltype(group_c)::value;
+        if (i < 8) {
+            const int pos = 8 * g + i, xi = pos >> 2, nu = pos & 3;
+            const F4 v = nu == 0 ? t[xi][0] - t[xi][2] : nu == 1 ? t[xi][1] + t[xi][2]
+                         : nu == 2 ? t[xi][2] - t[xi][1] : t[xi][1] - t[xi][3];
+            st4(arow + pos * MT * ROW, v);
+        } else {
+            const int pos = 8 * g + (i - 8);
+            *reinterpret_cast<float4 *>(brow + pos * NT * ROW) = pb[i - 8];
+        }
+    };
+
+    // 15 accumulator tiles live in the 256-entry accumulator file, the 16th in ordinary vector registers: with all
+    // 256 entries taken hipcc shuffles one tile through VGPRs inside the loop (read-after-MFMA stalls, +40 % on every
+    // second half step)
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    asm volatile("" : "+v"(acc[15]));
+
+    const float *Aw = As + (wm * 32 + (lane & 31)) * ROW + (lane >> 5) * 4;
+    const float *Bw = Bs + (wn * 32 + (lane & 31)) * ROW + (lane >> 5) * 4;
+    // One group = 8 positions x 2 k-halves = 8 "pair steps": two positions (two independent accumulators) at one k
+    // half, 4 fragment reads + 8 MFMAs issued alternately on the two accumulators.  Between MFMAs on DIFFERENT
+    // accumulators another instruction costs ~6 cycles; between two dependent ones ~43 (MI355X_MICROARCH.md), so the
+    // store pieces go only where the neighbours differ.  The fragments of pair step s+1 are read before the MFMAs of
+    // pair step s are issued (one wave per SIMD: nobody else hides the LDS latency).
+    auto compute = [&](auto group_c, auto store_c, auto sgroup_c, int scb) {
+        constexpr int g = decltype(group_c)::value;
+        constexpr bool STORE = decltype(store_c)::value;
+        constexpr int PS = 8;  // pair steps: (position pair pp = s >> 1, k half kq = s & 1)
+        float4 fa[2][2], fb[2][2];
+        auto read_frags = [&](int s, int set) {
+            const int q0 = 8 * g + 2 * (s >> 1), kq = s & 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                fa[set][u] = *reinterpret_cast<const float4 *>(Aw + (q0 + u) * MT * ROW + kq * 8);
+                fb[set][u] = *reinterpret_cast<const float4 *>(Bw + (q0 + u) * NT * ROW + kq * 8);
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < PS; ++s) {
+            if (s + 1 < PS) read_frags(s + 1, (s + 1) & 1);
+            // pin the reads ahead of this pair step's MFMAs: left free, hipcc sinks them to just before their use
+            // (same registers, no prefetch) and every pair step waits out the LDS latency
+            __builtin_amdgcn_sched_barrier(0);
+            const int q0 = 8 * g + 2 * (s >> 1), q1 = q0 + 1;
+            const float4 a0 = fa[s & 1][0], b0 = fb[s & 1][0], a1 = fa[s & 1][1], b1 = fb[s & 1][1];
+            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[q0], 0, 0, 0);
+            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[q1], 0, 0, 0);
+            if constexpr (STORE) store_piece(sgroup_c, 2 * s);
+            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[q0], 0, 0, 0);
+            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[q1], 0, 0, 0);
+            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[q0], 0, 0, 0);
+            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[q1], 0, 0, 0);
+            if constexpr (STORE) store_piece(sgroup_c, 2 * s + 1);
+            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[q0], 0, 0, 0);
+            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[q1], 0, 0, 0);
+        }
+    };
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+    using Yes = std::true_type;
+    using No = std::false_type;
+    static_assert(KC == 16, "16 store pieces ride on the 16 half steps of a position group");
+
+    // prologue: step 0 complete in LDS
+    load_a(0, true);
+    load_b4(0, 0, 0);
+    load_b4(0, 4, 4);
+    row_transform();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) store_piece(G0{}, i);
+    load_b4(0, 8, 0);
+    load_b4(0, 12, 4);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) store_piece(G1{}, i);
+    __syncthreads();
+    WINO_STAMP();  // 1: prologue done
+    // The 256 accumulators fill the accumulator file exactly, so the loop must not give the compiler a reason to
+    // copy them (a branch that selects between two multiply blocks does: it then spills accumulators to scratch).
+    // Hence the rotation: first half of step 0 before the loop, one straight-line trip = [second half of step k,
+    // first half of step k+1], second half of the last step after it.
+    const int nsteps = p.cblocks;
+    load_a(1, nsteps > 1);
+    compute(G0{}, No{}, G1{}, 0);
+    __syncthreads();
+    WINO_STAMP();  // 2: first half of step 0 done
+    for (int k = 0; k + 1 < nsteps; ++k) {
+        // second half of step k: g1(k) x, g0(k+1) stored.  Load order matters: vmcnt retires in order, so the
+        // filter rows this half stores are requested BEFORE the next step's patches (a full step ahead of their
+        // transform), and the wait for them leaves the 16 patch loads in flight.
+        row_transform();  // consumes pa(k+1)
+        load_b4(k + 1, 0, 0);
+        load_b4(k + 1, 4, 4);
+        load_a(k + 2, k + 2 < nsteps);
+        compute(G1{}, Yes{}, G0{}, k + 1);
+        __syncthreads();
+        if (k == 0) WINO_STAMP();  // 3: second half of step 0 (with stores) done
+        // first half of step k+1: g0(k+1) x, g1(k+1) stored
+        load_b4(k + 1, 8, 0);
+        load_b4(k + 1, 12, 4);
+        compute(G0{}, Yes{}, G1{}, k + 1);
+        __syncthreads();
+        if (k == 0) WINO_STAMP();  // 4: first half of step 1 (with stores) done
+    }
+    WINO_STAMP();  // 5: loop done
+    compute(G1{}, No{}, G0{}, 0);
+    // (the 16-pass MFMA needs 18 wait states before its result is read; made explicit as in conv_mfma.hip)
+#pragma unroll
+    for (int q = 0; q < 15; ++q) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[q]));
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[15]));
+
+    WINO_STAMP();  // 6: last half done
+    // ---- output transform + bias + ReLU + store.  Accumulator element e of a lane: tile row (e&3) + 8(e>>2) + 4(lane>>5)
+    // of the wave's 32, output channel n0 + 32 wn + (lane & 31).
+    const int n = n0 + wn * 32 + (lane & 31);
+    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    const int tpi = p.th * p.tw;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int tt = t0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            s0[nu] = acc[0 * 4 + nu][e] + acc[1 * 4 + nu][e] + acc[2 * 4 + nu][e];
+            s1[nu] = acc[1 * 4 + nu][e] - acc[2 * 4 + nu][e] - acc[3 * 4 + nu][e];
+        }
+        float y00 = s0[0] + s0[1] + s0[2] + bias, y01 = s0[1] - s0[2] - s0[3] + bias;
+        float y10 = s1[0] + s1[1] + s1[2] + bias, y11 = s1[1] - s1[2] - s1[3] + bias;
+        if (p.relu) {
+            y00 = fmaxf(y00, 0.f);
+            y01 = fmaxf(y01, 0.f);
+            y10 = fmaxf(y10, 0.f);
+            y11 = fmaxf(y11, 0.f);
+        }
+        if (tt < p.T && n < p.N) {
+            const int img = tt / tpi, rem = tt - img * tpi;
+            const int ty = rem / p.tw, tx = rem - ty * p.tw;
+            float *o = p.y + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.N + n;
+            o[0] = y00;
+            o[p.N] = y01;
+            o[(size_t)p.W * p.N] = y10;
+            o[(size_t)p.W * p.N + p.N] = y11;
+        }
+    }
+#ifdef WINO_TRACE
+    WINO_STAMP();  // 7: epilogue issued
+    if (p.trace && tid == 0)
+        for (int i = 0; i < 8; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = i < nts ? ts[i] : 0;
+#endif
+}
+
+}  // namespace
+
+static unsigned long long *g_wino_trace = nullptr;
+extern "C" void mpsr_debug_set_wino_trace(void *buf) { g_wino_trace = static_cast<unsigned long long *>(buf); }
+
+namespace mpsr {
+
+// floats of scratch conv3x3_winograd needs behind `ws` (the transformed filters)
+size_t winograd_scratch_floats(int C, int N) { return (size_t)16 * N * C; }
+
+bool winograd_applies(int H, int W, int C, int N) { return H % 2 == 0 && W % 2 == 0 && C % KC == 0 && C >= KC && N >= 1; }
+
+int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
+                     int N, float *ws, size_t ws_floats, hipStream_t s)
+{
+    MPSR_REQUIRE(winograd_applies(H, W, C, N), "conv3x3_winograd: needs even H, W and C %% %d == 0", KC);
+    if (ws_floats < winograd_scratch_floats(C, N) || !ws)
+        return fail(MPSR_ERR_WORKSPACE, "conv3x3_winograd: scratch holds %zu floats, needs %zu", ws_floats,
+                    winograd_scratch_floats(C, N));
+    static std::once_flag once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(once, [] {
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float)));
+    });
+    MPSR_CHECK_HIP(attr_status);
+    {
+        const long long total = (long long)N * C;
+        hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
+        MPSR_CHECK_LAUNCH("wino_filter_kernel");
+    }
+    WinoParams p;
+    p.x = x; p.u = ws; p.bias = bias; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.N = N;
+    p.th = H / 2; p.tw = W / 2;
+    p.T = B * p.th * p.tw;
+    p.cblocks = C / KC;
+    p.nblocks = ceil_div(N, NT);
+    p.mblocks = ceil_div(p.T, MT);
+    p.relu = relu;
+    p.xbytes = (unsigned)((long long)B * H * W * C * 4);
+    p.ubytes = (unsigned)(winograd_scratch_floats(C, N) * 4);
+    p.trace = g_wino_trace;
+    const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
+    if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd: grid too large");
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), kLdsFloats * sizeof(float), s, p);
+    MPSR_CHECK_LAUNCH("wino_conv_kernel");
+    return MPSR_OK;
+}
+
+}  // namespace mpsr

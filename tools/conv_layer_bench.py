@@ -47,6 +47,7 @@ def main():
                     "per workgroup, 1 stream-K; 1:G or 1:-N pins the workgroups per CU / the workgroup count")
     ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
                     "kernel: -1 heuristic, 1, 2")
+    ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0, 1")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
                     "median over rounds is reported (boxes and power states drift: compare within one run only)")
     ap.add_argument("--reps", type=int, default=5)
@@ -65,7 +66,9 @@ def main():
     for sp in args.sched.split(","):
         a, _, b = sp.partition(":")
         scheds.append((int(a), int(b) if b else 0))
-    combos = [(t, sc, d) for t in tiles for sc in scheds for d in depths]
+    winos = [int(v) for v in args.wino.split(",")]
+    combos = [(t, sc, d if len(winos) == 1 and winos[0] == -1 else 100 + wv) for t in tiles for sc in scheds
+              for d in depths for wv in winos]
     print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("t%d s%d:%d d%d TF/s (us)" % (t, a, b, d)
                                                                    for t, (a, b), d in combos)))
     total = {c: 0.0 for c in combos}
@@ -96,7 +99,8 @@ def main():
                     continue
                 lib.mpsr_debug_set_conv_tile(t)
                 lib.mpsr_debug_set_conv_sched(sc[0], sc[1])
-                lib.mpsr_debug_set_conv_depth(d)
+                lib.mpsr_debug_set_conv_depth(d if d < 50 else -1)
+                lib.mpsr_debug_set_conv_winograd(d - 100 if d >= 50 else -1)
 
                 def run():
                     _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
@@ -121,6 +125,7 @@ def main():
         lib.mpsr_debug_set_conv_tile(-1)
         lib.mpsr_debug_set_conv_sched(-1, 0)
         lib.mpsr_debug_set_conv_depth(-1)
+        lib.mpsr_debug_set_conv_winograd(-1)
         print("%-28s %3d %9.2f | %s" % (name, count, flop / 1e9, "  ".join(cells)))
     print("per-step conv time (ms): " + "  ".join("t%d s%d:%d d%d %.2f" % (t, sc[0], sc[1], d, total[(t, sc, d)] / 1e3)
                                                     for t, sc, d in combos))
