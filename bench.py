@@ -198,10 +198,20 @@ def conv_replay(net, B):
                                                 bias, None, y.data_ptr(), r["cout"], r["kh"], r["kw"], r["dilation"],
                                                 r["relu"], 0, ws.data_ptr(), nws, s))
     flops = sum(2.0 * Bq * H * W * cin * r["kh"] * r["kw"] * r["cout"] for _, _, _, r, Bq, H, W, cin in jobs)
+    # multiply-add FLOPs the library's kernels really issue for these launches: the Winograd kernel (decoder 3x3
+    # layers) 16/36 of the direct count, the atrous layers only their in-image taps
+    import ctypes
+    executed, kinds = 0.0, {0: 0, 1: 0, 2: 0}
+    for _, _, _, r, Bq, H, W, _ in jobs:
+        kind, ex = ctypes.c_int(0), ctypes.c_double(0.0)
+        _lib.check(lib.mpsr_conv2d_plan(Bq, H, W, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"],
+                                        ctypes.byref(kind), ctypes.byref(ex)))
+        executed += ex.value
+        kinds[kind.value] += 1
     # algorithmic HBM bytes of a launch: its input, weights and output once each
     alg_bytes = sum(4.0 * (Bq * H * W * (r["cin"] + r["cout"]) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
                     for _, _, _, r, Bq, H, W, _ in jobs)
-    return run, len(jobs), flops, alg_bytes
+    return run, len(jobs), flops, alg_bytes, executed, kinds
 
 
 def mfma_box_peak(device):
@@ -456,7 +466,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel alone: every conv/FC launch of one step, timed with events on the launch stream
-        run, launches, flops, alg_bytes = conv_replay(net, args.batch)
+        run, launches, flops, alg_bytes, executed, kinds = conv_replay(net, args.batch)
         run()
         torch.cuda.synchronize()
         reps = max(3, min(10, args.steps))
@@ -485,7 +495,8 @@ def main():
             except Exception:
                 pass
         peak = PEAK_F32_MFMA_TFLOPS if args.math == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        kname = "conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM)" if args.math == "fp32" else \
+        kname = "conv_igemm_kernel + wino_conv_kernel (fp32 MFMA 32x32x2: implicit GEMM; Winograd F(2x2,3x3) for the " \
+                "decoder's 3x3 layers)" if args.math == "fp32" else \
             "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
         result["roofline"] = {"bound": "mfma", "kernel": kname,
                               "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -494,6 +505,14 @@ def main():
                               "flops_per_launch": round(flops / launches),
                               "algorithmic_bytes": round(alg_bytes / launches)}
         if args.math == "fp32":
+            # `achieved` counts the ALGORITHMIC multiply-adds of the direct convolution (the contract's definition);
+            # the decoder's 3x3 layers run as Winograd F(2x2,3x3) (16 products where the direct form has 36) and the
+            # atrous layers skip their out-of-image taps, so the matrix pipes issue fewer: `executed` is what they do
+            result["roofline"]["executed"] = round(executed / launches / avg_s / 1e12, 2)
+            result["roofline"]["executed_frac"] = round(executed / launches / avg_s / 1e12 / peak, 4)
+            result["roofline"]["executed_flops_per_launch"] = round(executed / launches)
+            result["roofline"]["launch_kinds"] = {"implicit_gemm": kinds[0], "winograd_f2x2_3x3": kinds[1],
+                                                  "direct_narrow": kinds[2]}
             if traffic:
                 result["roofline"]["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
                 result["roofline"]["mfma_busy"] = busy

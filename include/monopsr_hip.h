@@ -149,8 +149,17 @@ int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int
  *            number of K steps of the launch's tile sequence; partial tiles meet in `ws`) when `ws` holds
  *            mpsr_conv2d_scratch_floats(B,H,W,N) floats, otherwise as split_k = 1.  Results are deterministic for
  *            a given shape and device, and equal to split_k = 1 up to fp32 summation order on the split tiles.
- * A fully-connected layer is H=W=KH=KW=1. */
+ *            With split_k = 0 and that scratch, large dense 3x3 layers (dilation 1, no residual, even H and W,
+ *            C % 16 == 0, C and N >= 64, B*H*W >= 65536: the map decoder) run as Winograd F(2x2,3x3) -- 16
+ *            products per 2x2 output tile where the direct form has 36; fp32 results agree with the direct form to
+ *            ~1e-6 relative (tests/test_net_gpu.py checks 1e-5 against fp64).
+ * A fully-connected layer is H=W=KH=KW=1.
+ * mpsr_conv2d_plan reports, for a layer left to the library (split_k = 0, scratch given), which kernel serves it
+ * (*kind: 0 implicit GEMM, 1 Winograd, 2 direct narrow-N kernel) and the multiply-add FLOPs that kernel issues --
+ * for throughput accounting (bench.py's roofline.executed), not needed to run anything. */
 size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N);
+int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
+                     double *executed_flops);
 int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
                          const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                          int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream);

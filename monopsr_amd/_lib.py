@@ -70,6 +70,7 @@ SIGNATURES = {
     "mpsr_conv2d_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                    c_sz, c_f]),
     "mpsr_conv2d_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "mpsr_conv2d_plan": (c_i, [c_i] * 8 + [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
     "mpsr_conv2d_wgrad_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
     "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -1169,6 +1169,38 @@ extern "C" int mpsr_set_conv_math(int mode)
 }
 extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
+// What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
+// kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel; and
+// the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernel 16/36 of the direct count,
+// the implicit GEMM with border classes only the in-image taps.  For reporting (bench.py), not part of the compute path.
+extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
+                                double *executed_flops)
+{
+    MPSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && kind && executed_flops, "conv2d_plan: bad arguments");
+    const double M = (double)B * H * W;
+    const bool wino = KH == 3 && KW == 3 && dilation == 1 && mpsr::winograd_applies(H, W, C, N) && M >= 65536 &&
+                      C >= 64 && N >= 64 && g_math.load() == MATH_FP32;
+    if (wino) {
+        *kind = 1;
+        *executed_flops = 2.0 * (double)B * (H / 2) * (W / 2) * 16.0 * C * N;
+        return MPSR_OK;
+    }
+    if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0) {
+        *kind = 2;
+        *executed_flops = 2.0 * M * 9.0 * C * N;
+        return MPSR_OK;
+    }
+    *kind = 0;
+    double taps = (double)KH * KW * H * W;  // tap evaluations per image and channel pair
+    if (KH == 3 && KW == 3 && dilation > 1 && H >= 2 * dilation && W >= 2 * dilation) {
+        // border classes: rows / columns within `dilation` of an edge lose one row / column of taps
+        const double ty = 3.0 * H - 2.0 * dilation, tx = 3.0 * W - 2.0 * dilation;
+        taps = ty * tx;
+    }
+    *executed_flops = 2.0 * (double)B * taps * C * N;
+    return MPSR_OK;
+}
+
 extern "C" size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N)
 {
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0) return 0;

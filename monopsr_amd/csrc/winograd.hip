@@ -151,55 +151,39 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
     const unsigned bstride = (unsigned)p.N * KC * 4u;  // bytes between positions (and 16 x that between channel blocks)
 
     float4 pa[16], pb[8];
-    // `live` false (past the last channel block) turns the loads into out-of-range ones (zeros, no traffic).  The
-    // loads are issued UNCONDITIONALLY: around a branch hipcc can no longer count them and makes every later wait
-    // on the filter loads wait for these patch loads too (HBM latency exposed in every second half step).
-    auto load_a = [&](int cb, bool live) {
-        const unsigned so = live ? (unsigned)cb * KC * 4u : 0u;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            pa[i] = __builtin_bit_cast(float4,
-                                       __builtin_amdgcn_raw_buffer_load_b128(rx, live ? aoff[i] : p.xbytes, so, 0));
+    // One patch pixel.  `live` false (past the last channel block) turns the load into an out-of-range one (zeros, no
+    // traffic); the loads are issued UNCONDITIONALLY: around a branch hipcc can no longer count them and makes every
+    // later wait on the filter loads wait for these patch loads too.
+    auto load_a1 = [&](int cb, bool live, int i) {
+        pa[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rx, live ? aoff[i] : p.xbytes, live ? (unsigned)cb * KC * 4u : 0u, 0));
     };
-    // filters of 4 positions (half a group) of channel block cb: always L2 hits (U is a few MB shared by every
-    // workgroup), so they are fetched only half a group of MFMAs before their store, into 8 float4 in all
-    auto load_b4 = [&](int cb, int pos0, int slot0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            pb[slot0 + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                           ru, boff, ((unsigned)cb * 16u + (unsigned)(pos0 + j)) * bstride, 0));
+    // One filter row (position pos of channel block cb) into staging slot `slot`: always an L2 hit (U is a few MB
+    // shared by every workgroup), so it is fetched only about a third of a half step before its store.
+    auto load_b1 = [&](int cb, int pos, int slot) {
+        pb[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  ru, boff, ((unsigned)cb * 16u + (unsigned)pos) * bstride, 0));
     };
     // rows of the input transform: t = B^T d, kept between the two halves of a step
     F4 t[4][4];
-    auto row_transform = [&]() {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const F4 d0 = ld4(pa[s]), d1 = ld4(pa[4 + s]), d2 = ld4(pa[8 + s]), d3 = ld4(pa[12 + s]);
-            t[0][s] = d0 - d2;
-            t[1][s] = d1 + d2;
-            t[2][s] = d2 - d1;
-            t[3][s] = d1 - d3;
-        }
+    auto row_transform_col = [&](int c) {
+        const F4 d0 = ld4(pa[c]), d1 = ld4(pa[4 + c]), d2 = ld4(pa[8 + c]), d3 = ld4(pa[12 + c]);
+        t[0][c] = d0 - d2;
+        t[1][c] = d1 + d2;
+        t[2][c] = d2 - d1;
+        t[3][c] = d1 - d3;
     };
     float *arow = As + ltile * ROW + 4 * quad;
     float *brow = Bs + (tid >> 2) * ROW + 4 * (tid & 3);
-    // piece i (0..15) of the stores of group g: pieces 0-7 the A rows of the group's positions, 8-15 the B rows
-    auto store_piece = [&](auto group_c, int i) {
-        constexpr int g = decltype(group_c)::value;
-        if (i < 8) {
-            const int pos = 8 * g + i, xi = pos >> 2, nu = pos & 3;
-            const F4 v = nu == 0 ? t[xi][0] - t[xi][2] : nu == 1 ? t[xi][1] + t[xi][2]
-                         : nu == 2 ? t[xi][2] - t[xi][1] : t[xi][1] - t[xi][3];
-            st4(arow + pos * MT * ROW, v);
-        } else {
-            const int pos = 8 * g + (i - 8);
-            *reinterpret_cast<float4 *>(brow + pos * NT * ROW) = pb[i - 8];
-        }
+    // the A row of position pos (from the row-transformed patch) / the B row of position pos (from staging slot)
+    auto store_a = [&](int pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const F4 v = nu == 0 ? t[xi][0] - t[xi][2] : nu == 1 ? t[xi][1] + t[xi][2]
+                     : nu == 2 ? t[xi][2] - t[xi][1] : t[xi][1] - t[xi][3];
+        st4(arow + pos * MT * ROW, v);
     };
+    auto store_b = [&](int pos, int slot) { *reinterpret_cast<float4 *>(brow + pos * NT * ROW) = pb[slot]; };
 
-    // 15 accumulator tiles live in the 256-entry accumulator file, the 16th in ordinary vector registers: with all
-    // 256 entries taken hipcc shuffles one tile through VGPRs inside the loop (read-after-MFMA stalls, +40 % on every
-    // second half step)
     f32x16 acc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
@@ -210,13 +194,14 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
     const float *Aw = As + (wm * 32 + (lane & 31)) * ROW + (lane >> 5) * 4;
     const float *Bw = Bs + (wn * 32 + (lane & 31)) * ROW + (lane >> 5) * 4;
     // One group = 8 positions x 2 k-halves = 8 "pair steps": two positions (two independent accumulators) at one k
-    // half, 4 fragment reads + 8 MFMAs issued alternately on the two accumulators.  Between MFMAs on DIFFERENT
-    // accumulators another instruction costs ~6 cycles; between two dependent ones ~43 (MI355X_MICROARCH.md), so the
-    // store pieces go only where the neighbours differ.  The fragments of pair step s+1 are read before the MFMAs of
-    // pair step s are issued (one wave per SIMD: nobody else hides the LDS latency).
-    auto compute = [&](auto group_c, auto store_c, auto sgroup_c, int scb) {
+    // half, 4 fragment reads + 8 MFMAs issued alternately on the two accumulators.  After every MFMA comes a "filler
+    // slot" (64 per group) that the caller fills with pieces of the NEXT data's preparation: between MFMAs on
+    // DIFFERENT accumulators an extra instruction costs ~6 cycles, between two dependent ones ~43
+    // (MI355X_MICROARCH.md), and consecutive MFMAs here always differ.  The fragments of pair step s+1 are read before
+    // the MFMAs of pair step s are issued and pinned there (one wave per SIMD: nobody else hides the LDS latency, and
+    // left free hipcc sinks the reads to just before their use).
+    auto compute = [&](auto group_c, auto &&filler) {
         constexpr int g = decltype(group_c)::value;
-        constexpr bool STORE = decltype(store_c)::value;
         constexpr int PS = 8;  // pair steps: (position pair pp = s >> 1, k half kq = s & 1)
         float4 fa[2][2], fb[2][2];
         auto read_frags = [&](int s, int set) {
@@ -231,75 +216,114 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
 #pragma unroll
         for (int s = 0; s < PS; ++s) {
             if (s + 1 < PS) read_frags(s + 1, (s + 1) & 1);
-            // pin the reads ahead of this pair step's MFMAs: left free, hipcc sinks them to just before their use
-            // (same registers, no prefetch) and every pair step waits out the LDS latency
             __builtin_amdgcn_sched_barrier(0);
             const int q0 = 8 * g + 2 * (s >> 1), q1 = q0 + 1;
             const float4 a0 = fa[s & 1][0], b0 = fb[s & 1][0], a1 = fa[s & 1][1], b1 = fb[s & 1][1];
             acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[q0], 0, 0, 0);
+            filler(8 * s + 0);
             acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[q1], 0, 0, 0);
-            if constexpr (STORE) store_piece(sgroup_c, 2 * s);
+            filler(8 * s + 1);
             acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[q0], 0, 0, 0);
+            filler(8 * s + 2);
             acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[q1], 0, 0, 0);
+            filler(8 * s + 3);
             acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[q0], 0, 0, 0);
+            filler(8 * s + 4);
             acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[q1], 0, 0, 0);
-            if constexpr (STORE) store_piece(sgroup_c, 2 * s + 1);
+            filler(8 * s + 5);
             acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[q0], 0, 0, 0);
+            filler(8 * s + 6);
             acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[q1], 0, 0, 0);
+            filler(8 * s + 7);
         }
     };
     using G0 = std::integral_constant<int, 0>;
     using G1 = std::integral_constant<int, 1>;
-    using Yes = std::true_type;
-    using No = std::false_type;
-    static_assert(KC == 16, "16 store pieces ride on the 16 half steps of a position group");
+    static_assert(KC == 16, "the filler plans below are laid out for 16 channels per K step");
 
     // prologue: step 0 complete in LDS
-    load_a(0, true);
-    load_b4(0, 0, 0);
-    load_b4(0, 4, 4);
-    row_transform();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) store_piece(G0{}, i);
-    load_b4(0, 8, 0);
-    load_b4(0, 12, 4);
+    for (int i = 0; i < 16; ++i) load_a1(0, true, i);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) store_piece(G1{}, i);
+    for (int c = 0; c < 4; ++c) row_transform_col(c);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_b1(0, 8 * h + j, j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            store_a(8 * h + j);
+            store_b(8 * h + j, j);
+        }
+    }
     __syncthreads();
     WINO_STAMP();  // 1: prologue done
-    // The 256 accumulators fill the accumulator file exactly, so the loop must not give the compiler a reason to
-    // copy them (a branch that selects between two multiply blocks does: it then spills accumulators to scratch).
-    // Hence the rotation: first half of step 0 before the loop, one straight-line trip = [second half of step k,
-    // first half of step k+1], second half of the last step after it.
+    // The 256 accumulators fill the accumulator file, so the loop must not give the compiler a reason to copy them (a
+    // branch that selects between two multiply blocks does: it then spills accumulators to scratch).  Hence the
+    // rotation: first half of step 0 before the loop, one straight-line trip = [second half of step k, first half of
+    // step k+1], second half of the last step after it.
+    //
+    // Filler plans (slot = position in the stream of 64 MFMAs of a half):
+    //   second half of step k (multiplies g1(k)):       first half of step k+1 (multiplies g0(k+1)):
+    //     0-3   row transform of patch(k+1)               0-7   request filter rows of g1(k+1)
+    //     8-15  request filter rows of g0(k+1)            12-19 store A rows of g1(k+1)
+    //     16-23 store A rows of g0(k+1)                   40-47 store filter rows of g1(k+1)
+    //     24-39 request patch(k+2)
+    //     48-55 store filter rows of g0(k+1)
+    // vmcnt retires in order, so filter rows are requested BEFORE the patches that follow them in the same half, and
+    // the waits in front of their stores leave those 16 patch loads in flight.
     const int nsteps = p.cblocks;
-    load_a(1, nsteps > 1);
-    compute(G0{}, No{}, G1{}, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_a1(1, nsteps > 1, i);
+    compute(G0{}, [](int) {});
     __syncthreads();
     WINO_STAMP();  // 2: first half of step 0 done
+#ifdef WINO_TRACE
+    unsigned long long sum_g1 = 0, sum_g0 = 0;
+#endif
     for (int k = 0; k + 1 < nsteps; ++k) {
-        // second half of step k: g1(k) x, g0(k+1) stored.  Load order matters: vmcnt retires in order, so the
-        // filter rows this half stores are requested BEFORE the next step's patches (a full step ahead of their
-        // transform), and the wait for them leaves the 16 patch loads in flight.
-        row_transform();  // consumes pa(k+1)
-        load_b4(k + 1, 0, 0);
-        load_b4(k + 1, 4, 4);
-        load_a(k + 2, k + 2 < nsteps);
-        compute(G1{}, Yes{}, G0{}, k + 1);
+        const bool more2 = k + 2 < nsteps;
+#ifdef WINO_TRACE
+        const unsigned long long h0 = __builtin_readcyclecounter();
+#endif
+        compute(G1{}, [&](int slot) {
+            if (slot < 4) row_transform_col(slot);
+            else if (slot >= 8 && slot < 16) load_b1(k + 1, slot - 8, slot - 8);
+            else if (slot >= 16 && slot < 24) store_a(slot - 16);
+            else if (slot >= 24 && slot < 40) load_a1(k + 2, more2, slot - 24);
+            else if (slot >= 48 && slot < 56) store_b(slot - 48, slot - 48);
+        });
         __syncthreads();
-        if (k == 0) WINO_STAMP();  // 3: second half of step 0 (with stores) done
-        // first half of step k+1: g0(k+1) x, g1(k+1) stored
-        load_b4(k + 1, 8, 0);
-        load_b4(k + 1, 12, 4);
-        compute(G0{}, Yes{}, G1{}, k + 1);
+        if (k == 0) WINO_STAMP();  // 3: second half of step 0 (with fillers) done
+#ifdef WINO_TRACE
+        const unsigned long long h1 = __builtin_readcyclecounter();
+        sum_g1 += h1 - h0;
+#endif
+        compute(G0{}, [&](int slot) {
+            if (slot < 8) load_b1(k + 1, 8 + slot, slot);
+            else if (slot >= 12 && slot < 20) store_a(8 + slot - 12);
+            else if (slot >= 40 && slot < 48) store_b(8 + slot - 40, slot - 40);
+        });
         __syncthreads();
-        if (k == 0) WINO_STAMP();  // 4: first half of step 1 (with stores) done
+        if (k == 0) WINO_STAMP();  // 4: first half of step 1 (with fillers) done
+#ifdef WINO_TRACE
+        sum_g0 += __builtin_readcyclecounter() - h1;
+#endif
     }
+#ifdef WINO_TRACE
+    if (p.trace && threadIdx.x == 0) {
+        p.trace[(size_t)(gridDim.x + blockIdx.x) * 8] = sum_g1;
+        p.trace[(size_t)(gridDim.x + blockIdx.x) * 8 + 1] = sum_g0;
+    }
+#endif
     WINO_STAMP();  // 5: loop done
-    compute(G1{}, No{}, G0{}, 0);
-    // (the 16-pass MFMA needs 18 wait states before its result is read; made explicit as in conv_mfma.hip)
-#pragma unroll
-    for (int q = 0; q < 15; ++q) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[q]));
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[15]));
+    compute(G1{}, [](int) {});
+    // (the 16-pass MFMA needs 18 wait states before its result is read; made explicit as in conv_mfma.hip -- one
+    // wait, tied to every accumulator so that no read is scheduled above it)
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]),
+                   "+a"(acc[7]), "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]),
+                   "+a"(acc[13]), "+a"(acc[14]), "+v"(acc[15]));
 
     WINO_STAMP();  // 6: last half done
     // ---- output transform + bias + ReLU + store.  Accumulator element e of a lane: tile row (e&3) + 8(e>>2) + 4(lane>>5)

@@ -31,8 +31,17 @@ for _ in range(3):
     _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), None, None, y.data_ptr(), N, 3, 3, 1, 1,
                                         0, ws.data_ptr(), nws, _lib.stream()))
 torch.cuda.synchronize()
-t = trace.cpu().numpy()
+t_all = trace.cpu().numpy()
+nwg = int((t_all[:, 0] != 0).sum()) // 2 if (t_all[:, 2] != 0).sum() < (t_all[:, 0] != 0).sum() else int((t_all[:, 0] != 0).sum())
+grid = ((B * (H // 2) * (W // 2) + 63) // 64 + 7) // 8 * 8 * ((N + 63) // 64)
+sums = t_all[grid:2 * grid]
+sums = sums[sums[:, 0] != 0]
+t = t_all[:grid]
 t = t[t[:, 0] != 0]
+if len(sums):
+    it = C // 16 - 1
+    print("steady state per half (median over workgroups): second halves (g1) %.0f  first halves (g0) %.0f cycles"
+          % (np.median(sums[:, 0]) / it, np.median(sums[:, 1]) / it))
 d = np.diff(t, axis=1).astype(np.float64)
 names = ["prologue", "half0 (no stores)", "half1(0)+stores", "half0(1)+stores", "rest of loop", "last half", "epilogue"]
 print("%d workgroups; cycles (s_memtime units), median over workgroups; K steps = %d" % (len(t), C // 16))
