@@ -10,12 +10,12 @@ _REGISTRY = {
     'smooth_l1_nonzero': losses_custom.WeightedNonZeroSmoothL1LocalizationLoss,
     'softmax': losses.WeightedSoftmaxClassificationLoss,
     'softmax_temp': lambda: losses.WeightedSoftmaxClassificationLoss(0.5),
+    'focal': losses.SigmoidFocalClassificationLoss,
     'sigmoid_ce': losses_custom.SigmoidClassificationLoss,
     'berHu': losses_custom.WeightedBerHu,
     'chamfer_dist': losses_custom.ChamferDistance,
     'emd': losses_custom.EarthMoversDistance,
 }
-_NOT_BUILT = {'focal': 'the sigmoid focal loss is selectable in the reference but used by no MonoPSR config'}
 
 
 def get_loss_type_and_weight(loss_config, output_rep):
@@ -27,8 +27,6 @@ def get_loss_type_and_weight(loss_config, output_rep):
 
 
 def build_loss(loss_type):
-    if loss_type in _NOT_BUILT:
-        raise ValueError('Loss type not built: ' + _NOT_BUILT[loss_type], loss_type)
     if loss_type not in _REGISTRY:
         raise ValueError('Invalid loss type', loss_type)
     return _REGISTRY[loss_type]()

@@ -1,5 +1,5 @@
-"""The two object-detection-API losses MonoPSR's loss builder instantiates (object_detection/core/losses.py:40-157,
-283-317), with the same class names and call convention: loss(prediction_tensor, target_tensor, weights=...).
+"""The object-detection-API losses MonoPSR's loss builder instantiates (object_detection/core/losses.py:40-157,
+223-317), with the same class names and call convention: loss(prediction_tensor, target_tensor, weights=...).
 Inputs here are the heads' (1, num_boxes, k) tensors -- a few KB -- so these are plain torch expressions on the
 device (autograd supplies the gradients); the map-sized terms go through the HIP kernels in losses_custom.
 """
@@ -49,3 +49,31 @@ class WeightedSoftmaxClassificationLoss(Loss):
         logits = (prediction_tensor / self._logit_scale).reshape(-1, num_classes)
         ce = -(target_tensor.reshape(-1, num_classes) * F.log_softmax(logits, dim=1)).sum(1)
         return ce.reshape(weights.shape) * weights
+
+
+class SigmoidFocalClassificationLoss(Loss):
+    """losses.py:223-280 (loss type 'focal'): sigmoid cross entropy per entry, down-weighted by (1 - p_t)^gamma and
+    balanced by alpha, times weights (batch, anchors) broadcast over the class axis.  As in the reference a gamma of
+    0 / None and an alpha of None switch the respective factor off; `class_indices` restricts the loss to some
+    classes."""
+
+    def __init__(self, gamma=2.0, alpha=0.25):
+        self._alpha = alpha
+        self._gamma = gamma
+
+    def _compute_loss(self, prediction_tensor, target_tensor, weights, class_indices=None):
+        weights = weights.unsqueeze(2)
+        if class_indices is not None:
+            dense = torch.zeros(prediction_tensor.shape[2], dtype=prediction_tensor.dtype,
+                                device=prediction_tensor.device)
+            dense[torch.as_tensor(class_indices, dtype=torch.int64, device=prediction_tensor.device)] = 1.0
+            weights = weights * dense.reshape(1, 1, -1)
+        per_entry_cross_ent = F.binary_cross_entropy_with_logits(prediction_tensor, target_tensor, reduction='none')
+        prediction_probabilities = torch.sigmoid(prediction_tensor)
+        p_t = target_tensor * prediction_probabilities + (1 - target_tensor) * (1 - prediction_probabilities)
+        loss = per_entry_cross_ent
+        if self._gamma:
+            loss = torch.pow(1.0 - p_t, self._gamma) * loss
+        if self._alpha is not None:
+            loss = (target_tensor * self._alpha + (1 - target_tensor) * (1 - self._alpha)) * loss
+        return loss * weights

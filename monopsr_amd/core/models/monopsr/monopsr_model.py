@@ -114,11 +114,13 @@ class MonoPSRModel:
         output_dict = builder.get_output_dict()
         if constants.KEY_INST_XYZ_MAP_LOCAL in self.output_types:
             builder.add_inst_xyz_maps_local(gt_inst_xyz_maps_local=sample.get('gt_inst_xyz_maps_local'))
-        # :308-318 valid mask maps: model 000 predicts none, the ground-truth masks stand in
-        if constants.KEY_VALID_MASK_MAPS in self.output_types:
-            raise ValueError('predicted valid_mask_maps are not part of the built output set')
+        # :308-318 valid mask maps: predicted by their own head when configured (model 000 predicts none), else the
+        # ground-truth masks stand in
         if gt_valid_mask_maps is not None:
             builder._gt_dict.add_unique_to_dict({constants.KEY_VALID_MASK_MAPS: gt_valid_mask_maps})
+        if constants.KEY_VALID_MASK_MAPS in self.output_types:
+            builder.add_valid_mask_maps_output()
+        elif gt_valid_mask_maps is not None:
             output_dict.add_unique_to_dict({constants.KEY_VALID_MASK_MAPS: gt_valid_mask_maps})
         builder.add_proposal_fc_features(boxes_2d=boxes_2d, view_angs=est_view_angs,
                                          class_indices=sample['class_indices'], image_shape=self.image_input_shape)
@@ -126,7 +128,8 @@ class MonoPSRModel:
         if constants.KEY_LWH in self.output_types:
             builder.add_lwh_output(features_to_use=init_est_fc_features, est_lwh=sample['mean_lwh'], gt_lwh=gt_lwh)
         if constants.KEY_ALPHA in self.output_types:
-            builder.add_alpha_output(features_to_use=init_est_fc_features, gt_alpha=None, gt_alpha_dc=gt_alpha_dc)
+            builder.add_alpha_output(features_to_use=init_est_fc_features, gt_alpha=sample.get('gt_alpha'),
+                                     gt_alpha_dc=gt_alpha_dc)
         if constants.KEY_VIEW_ANG in self.output_types:
             builder.add_view_ang_output(output_key=constants.KEY_VIEW_ANG, features_in=init_est_fc_features,
                                         est_view_angs=est_view_angs, gt_view_angs=gt_view_angs)
@@ -198,24 +201,45 @@ class MonoPSRModel:
                 gt_dict[constants.KEY_INST_XYZ_MAP_LOCAL], mask=gt_dict[constants.KEY_VALID_MASK_MAPS]) / num_boxes
             losses_dict[constants.KEY_INST_XYZ_MAP_LOCAL] = v
             total_loss = total_loss + v
+        if constants.KEY_VALID_MASK_MAPS in self.output_types:
+            # :597-620 label-smoothed targets, every pixel weighted 1, mean over the pixels, summed over the instances
+            gt_mask = gt_dict[constants.KEY_VALID_MASK_MAPS]
+            mask_map_loss = loss_builder.add_loss_tensor(
+                loss_config, constants.KEY_VALID_MASK_MAPS, output_dict[constants.KEY_VALID_MASK_MAPS],
+                gt_mask * 0.998 + 0.001, torch.ones_like(gt_mask))
+            v = (mask_map_loss.sum(dim=(1, 2)) / float(self.map_roi_size[0] * self.map_roi_size[1])).sum()
+            losses_dict[constants.KEY_VALID_MASK_MAPS] = v
+            total_loss = total_loss + v
         if constants.KEY_LWH in self.output_types:
             k = constants.KEY_LWH + '_offs'
             losses_dict[k] = box_term(output_dict[k], gt_dict[k], constants.KEY_LWH)
             total_loss = total_loss + losses_dict[k]
         if constants.KEY_ALPHA in self.output_types:
-            if self.output_config.alpha != 'dc':
-                raise ValueError('Invalid output_type', self.output_config.alpha)
-            eps = getattr(loss_config, constants.KEY_ALPHA + '_cls')[2]
+            alpha_type = self.output_config.alpha
             gt_bins = gt_dict[constants.KEY_ALPHA_BINS].reshape(-1).long()
-            one_hot = torch.full((self.num_boxes, self.num_alpha_bins), eps / self.dataset_config.num_alpha_bins,
-                                 dtype=torch.float32, device=dev)
-            one_hot[torch.arange(self.num_boxes, device=dev), gt_bins] = 1.0 - eps
-            bins_loss = box_term(output_dict[constants.KEY_ALPHA_BINS], one_hot, constants.KEY_ALPHA + '_cls')
-            reg_loss = box_term(output_dict[constants.KEY_ALPHA_REGS], gt_dict[constants.KEY_ALPHA_REGS],
-                                constants.KEY_ALPHA + '_reg', mask=gt_alpha_valid_bins.unsqueeze(0).float())
-            losses_dict[constants.KEY_ALPHA_BINS] = bins_loss
-            losses_dict[constants.KEY_ALPHA_REGS] = reg_loss
-            total_loss = total_loss + (bins_loss + reg_loss)
+            rows = torch.arange(self.num_boxes, device=dev)
+            if alpha_type in ('dc', 'dc_rotation'):  # :655-710
+                eps = getattr(loss_config, constants.KEY_ALPHA + '_cls')[2]
+                one_hot = torch.full((self.num_boxes, self.num_alpha_bins), eps / self.dataset_config.num_alpha_bins,
+                                     dtype=torch.float32, device=dev)
+                one_hot[rows, gt_bins] = 1.0 - eps
+                bins_loss = box_term(output_dict[constants.KEY_ALPHA_BINS], one_hot, constants.KEY_ALPHA + '_cls')
+                reg_loss = box_term(output_dict[constants.KEY_ALPHA_REGS], gt_dict[constants.KEY_ALPHA_REGS],
+                                    constants.KEY_ALPHA + '_reg', mask=gt_alpha_valid_bins.unsqueeze(0).float())
+                losses_dict[constants.KEY_ALPHA_BINS] = bins_loss
+                losses_dict[constants.KEY_ALPHA_REGS] = reg_loss
+                total_loss = total_loss + (bins_loss + reg_loss)
+            elif alpha_type == 'prob':  # :712-752: hard one-hot targets, the temperature softmax, alpha itself regressed
+                one_hot = torch.zeros((self.num_boxes, self.num_alpha_bins), dtype=torch.float32, device=dev)
+                one_hot[rows, gt_bins] = 1.0
+                bins_loss = box_term(output_dict[constants.KEY_ALPHA_BINS], one_hot, constants.KEY_ALPHA + '_cls_temp')
+                reg_loss = box_term(output_dict[constants.KEY_ALPHA], gt_dict[constants.KEY_ALPHA],
+                                    constants.KEY_ALPHA + '_reg')
+                losses_dict[constants.KEY_ALPHA_BINS] = bins_loss
+                losses_dict[constants.KEY_ALPHA] = reg_loss
+                total_loss = total_loss + (bins_loss + reg_loss)
+            elif alpha_type != 'gt':  # 'gt': nothing to learn
+                raise ValueError('Invalid output_type', alpha_type)
         for key in (constants.KEY_CEN_Z, constants.KEY_VIEW_ANG, constants.KEY_CEN_Y):
             if key in self.output_types and getattr(self.output_config, key) == 'offset':
                 k = key + '_offs'

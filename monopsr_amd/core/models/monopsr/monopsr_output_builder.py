@@ -4,10 +4,14 @@ Method names, arguments, output_dict keys and the order of operations are the re
 layer runs through the HIP fp32-MFMA GEMM (DeviceNet.fully_connected), the per-box scalar algebra (a few flops
 per box) is plain tensor arithmetic on the GPU.  The fused native fast path for the same graph is
 mpsr_heads_fwd (DeviceNet.heads_fwd); tests check that both agree.
-Only the output types of monopsr_model_000.yaml plus their 'est' variants are implemented ('gt' variants are
-not).  The global maps (:663-772) run through the geometry kernels (datasets/kitti/instance_utils.py); box
+Every output type the reference's methods accept is implemented ('offset' / 'est' / 'gt' / 'direct', alpha
+'dc' / 'dc_rotation' / 'prob' / 'gt', the predicted valid-mask head); monopsr_model_000.yaml uses the first of
+each.  The global maps (:663-772) run through the geometry kernels (datasets/kitti/instance_utils.py); box
 rescoring (:805-860) is fused into mpsr_format_boxes (MonoPSRModel.format_predictions).
 """
+import math
+
+import numpy as np
 import torch
 
 from monopsr_amd.core import constants
@@ -98,6 +102,25 @@ class MonoPSROutputBuilder:
         if self.is_train_or_val:
             self._gt_dict.add_unique_to_dict({output_key: gt_inst_xyz_maps_local})
 
+    # ------------------------------------------------------------------ predicted valid mask (:110-120)
+    def add_valid_mask_maps_output(self):
+        """3x3 convolution of the map features to one logit per pixel (no activation), variables
+        output/valid_mask_maps/valid_mask_maps/{weights,biases}; through the narrow-N 3x3 HIP kernel."""
+        from monopsr_amd.core import device_net
+        output_key = constants.KEY_VALID_MASK_MAPS
+        name = 'output/' + output_key + '/' + output_key
+        if self.net is None or name + '/weights' not in self.net._weights:
+            raise ValueError('no weights for the predicted valid-mask head', name)
+        if name not in self.net._fc_cache:
+            w = np.asarray(self.net._weights[name + '/weights'], np.float32)  # HWIO (3, 3, cin, 1)
+            w_ok = np.ascontiguousarray(w.transpose(3, 0, 1, 2).reshape(w.shape[3], -1))
+            self.net._fc_cache[name] = (torch.from_numpy(w_ok).to(self.net.device),
+                                        torch.from_numpy(np.asarray(self.net._weights[name + '/biases'],
+                                                                    np.float32)).to(self.net.device))
+        w_ok, bias = self.net._fc_cache[name]
+        output = device_net.conv2d(self.features_for_map, w_ok, bias, None, 3, 3, 1, False)
+        self._output_dict.add_unique_to_dict({output_key: output})
+
     # ------------------------------------------------------------------ shared scalar features
     def _box_features(self, boxes_2d, class_indices, image_shape):
         box_2d_coords = tf_boxes_2d_ij_fmt(boxes_2d, self.cam_p)
@@ -153,18 +176,44 @@ class MonoPSROutputBuilder:
 
     # ------------------------------------------------------------------ outputs
     def add_alpha_output(self, features_to_use, gt_alpha, gt_alpha_dc):
-        output_type = self.output_config[constants.KEY_ALPHA]
-        if output_type != 'dc':
-            raise ValueError('Invalid output_type', output_type)
+        """:276-393.  'dc': bins + one regression per bin; 'dc_rotation': bins + a (cos, sin) pair per bin,
+        L2-normalised, regression = atan2; 'prob': bins only, alpha = angle of the softmax-weighted bin centres;
+        'gt': ground truth passed through."""
+        output_key = constants.KEY_ALPHA
+        output_type = self.output_config[output_key]
         num_alpha_bins = self.dataset_config.num_alpha_bins
-        orientation_outputs = self.net.fully_connected(features_to_use, 'output/alpha', False)
-        self._output_dict.add_unique_to_dict({
-            constants.KEY_ALPHA_BINS: orientation_outputs[:, 0:num_alpha_bins],
-            constants.KEY_ALPHA_REGS: orientation_outputs[:, num_alpha_bins:num_alpha_bins * 2],
-        })
+        if output_type == 'dc':
+            orientation_outputs = self.net.fully_connected(features_to_use, 'output/alpha', False)
+            outputs = {constants.KEY_ALPHA_BINS: orientation_outputs[:, 0:num_alpha_bins],
+                       constants.KEY_ALPHA_REGS: orientation_outputs[:, num_alpha_bins:num_alpha_bins * 2]}
+        elif output_type == 'dc_rotation':
+            orientation_outputs = self.net.fully_connected(features_to_use, 'output/alpha', False)
+            comp = orientation_outputs[:, num_alpha_bins:num_alpha_bins * 3].reshape(self.num_boxes, num_alpha_bins, 2)
+            # tf.nn.l2_normalize(axis=2, epsilon=1e-12): x * rsqrt(max(sum x^2, eps))
+            comp = comp * torch.rsqrt(torch.clamp((comp * comp).sum(2, keepdim=True), min=1e-12))
+            outputs = {constants.KEY_ALPHA_BINS: orientation_outputs[:, 0:num_alpha_bins],
+                       constants.KEY_ALPHA_REGS: torch.atan2(comp[:, :, 1], comp[:, :, 0])}
+        elif output_type == 'prob':
+            pred_alpha_bins = self.net.fully_connected(features_to_use, 'output/alpha', False)
+            angle_per_half_bin = 2 * math.pi / num_alpha_bins / 2
+            centres = np.linspace(angle_per_half_bin, 2 * math.pi - angle_per_half_bin, num_alpha_bins)
+            bin_centers_comp = torch.tensor(np.stack((np.cos(centres), np.sin(centres)), axis=1), dtype=torch.float32,
+                                            device=pred_alpha_bins.device)
+            comp = torch.softmax(pred_alpha_bins, dim=1) @ bin_centers_comp
+            outputs = {constants.KEY_ALPHA_BINS: pred_alpha_bins,
+                       constants.KEY_ALPHA: torch.atan2(comp[:, 1], comp[:, 0]).unsqueeze(1)}
+        elif output_type == 'gt':
+            outputs = {constants.KEY_ALPHA_BINS: gt_alpha_dc[0], constants.KEY_ALPHA_REGS: gt_alpha_dc[1]}
+        else:
+            raise ValueError('Invalid output_type', output_type)
+        self._output_dict.add_unique_to_dict(outputs)
         if self.is_train_or_val and gt_alpha_dc is not None:
-            self._gt_dict.add_unique_to_dict({constants.KEY_ALPHA_BINS: gt_alpha_dc[0],
-                                              constants.KEY_ALPHA_REGS: gt_alpha_dc[1]})
+            if output_type == 'prob':
+                self._gt_dict.add_unique_to_dict({constants.KEY_ALPHA_BINS: gt_alpha_dc[0],
+                                                  constants.KEY_ALPHA: gt_alpha})
+            else:
+                self._gt_dict.add_unique_to_dict({constants.KEY_ALPHA_BINS: gt_alpha_dc[0],
+                                                  constants.KEY_ALPHA_REGS: gt_alpha_dc[1]})
 
     def add_lwh_output(self, features_to_use, est_lwh, gt_lwh):
         output_key = constants.KEY_LWH
@@ -175,6 +224,9 @@ class MonoPSROutputBuilder:
         elif output_type == 'est':
             pred_dim_offsets = est_lwh
             pred_lwh = est_lwh
+        elif output_type == 'gt':
+            pred_dim_offsets = gt_lwh - est_lwh
+            pred_lwh = gt_lwh
         else:
             raise ValueError('Invalid output_type', output_type)
         self._output_dict.add_unique_to_dict({output_key + '_offs': pred_dim_offsets, output_key: pred_lwh})
@@ -183,13 +235,23 @@ class MonoPSROutputBuilder:
         return pred_lwh
 
     def add_view_ang_output(self, output_key, features_in, est_view_angs, gt_view_angs):
+        """:509-549.  'offset': one FC output added to the 2-D viewing angle (variables
+        output/<key>/<key>); 'est': the 2-D viewing angle itself; 'gt': ground truth."""
         output_type = self.output_config[output_key]
-        if output_type != 'est':
+        if output_type == 'offset':
+            pred_view_ang_offsets = self.net.fully_connected(features_in, 'output/%s/%s' % (output_key, output_key),
+                                                             False)
+            pred_view_angs = est_view_angs + pred_view_ang_offsets
+        elif output_type == 'est':
+            pred_view_angs = est_view_angs
+            pred_view_ang_offsets = torch.zeros((), dtype=torch.float32, device=est_view_angs.device)
+        elif output_type == 'gt':
+            pred_view_ang_offsets = gt_view_angs - est_view_angs
+            pred_view_angs = gt_view_angs
+        else:
             raise ValueError('Invalid output_type', output_type)
-        self._output_dict.add_unique_to_dict({
-            output_key + '_offs': torch.zeros((), dtype=torch.float32, device=est_view_angs.device),
-            output_key: est_view_angs,
-        })
+        self._output_dict.add_unique_to_dict({output_key + '_offs': pred_view_ang_offsets,
+                                              output_key: pred_view_angs})
         if self.is_train_or_val and gt_view_angs is not None:
             self._gt_dict.add_unique_to_dict({output_key + '_offs': gt_view_angs - est_view_angs,
                                               output_key: gt_view_angs})
@@ -206,21 +268,36 @@ class MonoPSROutputBuilder:
         return tf_est_y_from_box_2d_and_depth(self.cam_p, boxes_2d, depth, class_name, trend_data='kitti')
 
     def add_cen_z_output(self, output_key, features_in, prop_cen_z, gt_cen_z):
+        """:441-507.  'offset': FC output added to the proposal depth (scope cen_z_offs); 'direct': the FC output
+        is the depth (scope cen_z_direct, no offset entry)."""
         output_type = self.output_config[output_key]
         assert prop_cen_z.shape[1] == 1
-        if output_type != 'offset':
+        if output_type == 'offset':
+            pred_cen_z_offsets = self.net.fully_connected(features_in, 'output/cen_z_offs/' + output_key, False)
+            pred_cen_z = prop_cen_z + pred_cen_z_offsets
+            self._output_dict.add_unique_to_dict({output_key + '_offs': pred_cen_z_offsets, output_key: pred_cen_z})
+            if self.is_train_or_val and gt_cen_z is not None:
+                self._gt_dict.add_unique_to_dict({output_key: gt_cen_z, output_key + '_offs': gt_cen_z - prop_cen_z})
+        elif output_type == 'direct':
+            pred_cen_z = self.net.fully_connected(features_in, 'output/cen_z_direct/' + output_key, False)
+            self._output_dict.add_unique_to_dict({output_key: pred_cen_z})
+            if self.is_train_or_val and gt_cen_z is not None:
+                self._gt_dict.add_unique_to_dict({output_key: gt_cen_z})
+        else:
             raise ValueError('Invalid output_type', output_type)
-        pred_cen_z_offsets = self.net.fully_connected(features_in, 'output/cen_z_offs/' + output_key, False)
-        pred_cen_z = prop_cen_z + pred_cen_z_offsets
-        self._output_dict.add_unique_to_dict({output_key + '_offs': pred_cen_z_offsets, output_key: pred_cen_z})
-        if self.is_train_or_val and gt_cen_z is not None:
-            self._gt_dict.add_unique_to_dict({output_key: gt_cen_z, output_key + '_offs': gt_cen_z - prop_cen_z})
 
     def add_cen_y_output(self, output_key, features_in, prop_cen_y, gt_cen_y):
+        """:573-609.  'offset' / 'gt'; the reference's 'est' branch leaves the offset undefined and fails with a
+        NameError when the outputs are collected -- same here."""
         output_type = self.output_config[output_key]
         if output_type == 'offset':
             pred_cen_y_offsets = self.net.fully_connected(features_in, 'output/cen_y/' + output_key, False)
             pred_cen_y = prop_cen_y + pred_cen_y_offsets
+        elif output_type == 'est':
+            raise NameError("name 'pred_cen_y_offsets' is not defined")  # monopsr_output_builder.py:587-598
+        elif output_type == 'gt':
+            pred_cen_y_offsets = gt_cen_y - prop_cen_y
+            pred_cen_y = gt_cen_y
         else:
             raise ValueError('Invalid output_type', output_type)
         self._output_dict.add_unique_to_dict({output_key + '_offs': pred_cen_y_offsets, output_key: pred_cen_y})
@@ -266,3 +343,29 @@ class MonoPSROutputBuilder:
         self._output_dict.add_unique_to_dict({output_key: pred})
         if self.is_train_or_val:
             self._gt_dict.add_unique_to_dict({output_key: gt_inst_depth_maps_global})
+
+    def add_inst_xyz_maps_global_from_depth(self, pred_inst_depth_map_global, boxes_2d, gt_inst_xyz_maps_global):
+        """:774-803: back-project each instance's global depth map (N,h,w,1) through the pixel-centre grid of its
+        2-D box (datasets/kitti/depth_map_utils.py:161-236, tf_depth_patch_to_pc_map: x = (u - cu) d / f,
+        y = (v - cv) d / f, z = d).  The reference turns each (3, h, w) result into (1, h, w, 3) with a RESHAPE, not
+        a transpose, and no caller in the reference reaches this method; the reshape is kept as written."""
+        output_key = constants.KEY_INST_XYZ_MAP_GLOBAL_FROM_DEPTH
+        h, w = self.map_roi_size
+        d = pred_inst_depth_map_global.reshape(-1, h, w)
+        n = d.shape[0]
+        y1, x1, y2, x2 = [boxes_2d[:n, i].reshape(n, 1) for i in range(4)]
+        # roi_size[0] counts the x pixels and roi_size[1] the y pixels in the reference (square maps in practice)
+        nx, ny = self.map_roi_size[0], self.map_roi_size[1]
+        half_w, half_h = (x2 - x1) / nx / 2.0, (y2 - y1) / ny / 2.0
+        tx = torch.linspace(0.0, 1.0, nx, device=d.device).reshape(1, nx)
+        ty = torch.linspace(0.0, 1.0, ny, device=d.device).reshape(1, ny)
+        xs = (x1 + half_w) + ((x2 - half_w) - (x1 + half_w)) * tx  # (n, nx)
+        ys = (y1 + half_h) + ((y2 - half_h) - (y1 + half_h)) * ty  # (n, ny)
+        ratio = d / self.cam_p[0, 0]
+        x = (xs.reshape(n, 1, nx) - self.cam_p[0, 2]) * ratio
+        y = (ys.reshape(n, ny, 1) - self.cam_p[1, 2]) * ratio
+        pc_map = torch.stack((x, y, d), dim=1)  # (n, 3, h, w)
+        output = pc_map.reshape(n, h, w, 3)
+        self._output_dict.add_unique_to_dict({output_key: output})
+        if self.is_train_or_val:
+            self._gt_dict.add_unique_to_dict({output_key: gt_inst_xyz_maps_global})

@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE ONLY: imported by tests/; never by the product path.
 
 Pinning: the smooth-L1 and softmax classes are vendored OD-API code whose own tests hold known answers
 (object_detection/core/losses_test.py:87-107 -> 7.695; :490-544 -> -1.5*log(.5) and the anchor-wise matrix);
-tests/test_oracle_losses.py re-expresses them.  tf.losses.huber_loss and the SUM_BY_NONZERO_WEIGHTS reduction live in
+tests/test_oracle_geometry.py re-expresses them; the sigmoid focal loss (losses.py:223-280) is pinned by the nine
+known answers of losses_test.py:223-487.  tf.losses.huber_loss and the SUM_BY_NONZERO_WEIGHTS reduction live in
 TensorFlow 1.8 (not vendored): restated from its documented definition.  BerHu / sigmoid-CE / the model's loss
 wiring have no reference test: PARITY UNPINNED for those.
 """
@@ -54,6 +55,19 @@ def sigmoid_ce(logits, target):
     """losses_custom.py:201-232 SigmoidClassificationLoss: tf.nn.sigmoid_cross_entropy_with_logits, unweighted."""
     x, z = np.asarray(logits, np.float64), np.asarray(target, np.float64)
     return np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))
+
+
+def sigmoid_focal(logits, target, weights, gamma=2.0, alpha=0.25):
+    """object_detection/core/losses.py:223-280 SigmoidFocalClassificationLoss: sigmoid cross-entropy per entry times
+    (1 - p_t)^gamma and the alpha balance, times weights (batch, anchors) broadcast over classes.  gamma = 0 / None
+    and alpha = None switch the factors off as in the reference (`if self._gamma`, `if self._alpha is not None`)."""
+    x, z = np.asarray(logits, np.float64), np.asarray(target, np.float64)
+    ce = sigmoid_ce(x, z)
+    p = 1.0 / (1.0 + np.exp(-x))
+    p_t = z * p + (1 - z) * (1 - p)
+    mod = np.power(1.0 - p_t, gamma) if gamma else 1.0
+    bal = (z * alpha + (1 - z) * (1 - alpha)) if alpha is not None else 1.0
+    return mod * bal * ce * np.asarray(weights, np.float64)[..., None]
 
 
 def weighted_berhu(pred, target, weights):

@@ -210,3 +210,76 @@ def test_nonzero_smooth_l1_and_berhu_definitions():
     x, z = rng.standard_normal(50) * 5, rng.random(50)
     s = 1 / (1 + np.exp(-x))
     np.testing.assert_allclose(L.sigmoid_ce(x, z), -(z * np.log(s) + (1 - z) * np.log(1 - s)), rtol=1e-9)
+
+
+def _logit(p):
+    return math.log(p / (1 - p))
+
+
+def _order(ratio):
+    """10^floor(log10(ratio)); the reference evaluates this in float32, where 1 / (1 - 0.9)^2 lands on 100 and not
+    just below it: nudge by 1e-6 decades."""
+    return np.power(10, np.floor(np.log10(ratio) + 1e-6))
+
+
+def _focal_both(pred, tgt, w, **kw):
+    """oracle value, and the product class on the same numbers (plain torch, runs on CPU tensors too)."""
+    import torch
+    from monopsr_amd.core import losses as product
+    ref = L.sigmoid_focal(pred, tgt, w, **kw)
+    got = product.SigmoidFocalClassificationLoss(**kw)(torch.tensor(pred, dtype=torch.float32),
+                                                       torch.tensor(tgt, dtype=torch.float32),
+                                                       weights=torch.tensor(w, dtype=torch.float32)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7)
+    return ref
+
+
+def test_sigmoid_focal_known_answers():
+    """losses_test.py:223-487 (SigmoidFocalClassificationLossTest) on the oracle and on the product class."""
+    # easy examples: orders of magnitude below the plain sigmoid loss (:225-252)
+    pred = np.array([[[_logit(0.97)], [_logit(0.90)], [_logit(0.73)], [_logit(0.27)], [_logit(0.09)], [_logit(0.03)]]])
+    tgt = np.array([[[1.], [1.], [1.], [0.], [0.], [0.]]])
+    w = np.ones((1, 6))
+    focal = _focal_both(pred, tgt, w, gamma=2.0, alpha=None).sum(2)
+    sig = (L.sigmoid_ce(pred, tgt) * w[..., None]).sum(2)
+    np.testing.assert_allclose(_order(sig / focal), [[1000, 100, 10, 10, 100, 1000]])
+    # hard examples: same order (:254-280); alpha = 1 ignores negatives, alpha = 0 positives (:282-367)
+    pred = np.array([[[_logit(0.55)], [_logit(0.52)], [_logit(0.50)], [_logit(0.48)], [_logit(0.45)]]])
+    tgt = np.array([[[1.], [1.], [1.], [0.], [0.]]])
+    w = np.ones((1, 5))
+    sig = (L.sigmoid_ce(pred, tgt) * w[..., None]).sum(2)
+    focal = _focal_both(pred, tgt, w, gamma=2.0, alpha=None).sum(2)
+    np.testing.assert_allclose(_order(sig / focal), [[1., 1., 1., 1., 1.]])
+    focal = _focal_both(pred, tgt, w, gamma=2.0, alpha=1.0).sum(2)
+    np.testing.assert_allclose(focal[0][3:], [0., 0.])
+    np.testing.assert_allclose(_order(sig[0][:3] / focal[0][:3]), [1., 1., 1.])
+    focal = _focal_both(pred, tgt, w, gamma=2.0, alpha=0.0).sum(2)
+    np.testing.assert_allclose(focal[0][:3], [0., 0., 0.])
+    np.testing.assert_allclose(_order(sig[0][3:] / focal[0][3:]), [1., 1.])
+    # gamma = 0: alpha 0.5 halves the sigmoid loss, alpha None reproduces it (:369-420)
+    pred = np.array([[[-100, 100, -100], [100, -100, -100], [100, 0, -100], [-100, -100, 100]],
+                     [[-100, 0, 100], [-100, 100, -100], [100, 100, 100], [0, 0, -1]]], np.float64)
+    tgt = np.array([[[0, 1, 0], [1, 0, 0], [1, 0, 0], [0, 0, 1]], [[0, 0, 1], [0, 1, 0], [1, 1, 1], [1, 0, 0]]], np.float64)
+    w = np.array([[1, 1, 1, 1], [1, 1, 1, 0]], np.float64)
+    sig = L.sigmoid_ce(pred, tgt) * w[..., None]
+    np.testing.assert_allclose(sig, _focal_both(pred, tgt, w, alpha=0.5, gamma=0.0) * 2, atol=1e-9)
+    np.testing.assert_allclose(sig, _focal_both(pred, tgt, w, alpha=None, gamma=0.0), atol=1e-9)
+    # all-zero logits = probability 0.5: closed forms (:422-487)
+    pred = np.zeros((2, 4, 3))
+    tgt = np.array([[[0, 1, 0], [1, 0, 0], [1, 0, 0], [0, 0, 1]], [[0, 0, 1], [0, 1, 0], [1, 0, 0], [1, 0, 0]]], np.float64)
+    w = np.ones((2, 4))
+    np.testing.assert_allclose(_focal_both(pred, tgt, w, alpha=1.0, gamma=0.0).sum(), -math.log(.5) * 1.0 * 8, rtol=1e-9)
+    np.testing.assert_allclose(_focal_both(pred, tgt, w, alpha=0.75, gamma=0.0).sum(),
+                               -math.log(.5) * (0.75 * 8 + 0.25 * 8 * 2), rtol=1e-9)
+
+
+def test_focal_is_a_buildable_loss_type():
+    """builders/loss_builder.py:47: 'focal' -> SigmoidFocalClassificationLoss() with the default gamma / alpha."""
+    import torch
+    from monopsr_amd.builders import loss_builder
+    loss = loss_builder.build_loss('focal')
+    rng = np.random.default_rng(3)
+    x, z, w = rng.standard_normal((1, 7, 4)), (rng.random((1, 7, 4)) > 0.6).astype(np.float64), rng.random((1, 7))
+    got = loss(torch.tensor(x, dtype=torch.float32), torch.tensor(z, dtype=torch.float32),
+               weights=torch.tensor(w, dtype=torch.float32)).numpy()
+    np.testing.assert_allclose(got, L.sigmoid_focal(x, z, w, gamma=2.0, alpha=0.25), rtol=2e-5, atol=1e-7)
