@@ -12,6 +12,11 @@ from monopsr_amd import _lib
 from monopsr_amd.core import device_net as dn
 
 
+# split_k argument of every forward / data-gradient convolution: 0 = the library schedules the launch (Winograd for
+# the decoder's dense 3x3 layers and their data gradients, stream-K for the long-K FC layers): 88 -> 81 ms per step
+_SCHED = 0
+
+
 class LayerRef:
     """One conv / FC layer: views into the flat parameter and gradient buffers (BatchNorm already folded)."""
 
@@ -47,7 +52,7 @@ class Conv2dFn(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         bn = layer.batch_norm is not None
         y = dn.conv2d(x, layer.w, None if bn else layer.b, res, layer.kh, layer.kw, layer.dilation,
-                      layer.relu and not bn)
+                      layer.relu and not bn, split_k=_SCHED)
         ctx.layer = layer
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if (layer.relu and not bn) else None)
@@ -93,7 +98,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=x.device)
             _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd), s))
-            dx = dn.conv2d(g4, wd, None, None, L.kh, L.kw, L.dilation, False)
+            dx = dn.conv2d(g4, wd, None, None, L.kh, L.kw, L.dilation, False, split_k=_SCHED)
         return dx, (g if ctx.has_res else None), None, None
 
 

@@ -176,16 +176,27 @@ class DeviceNet:
 
 # ---------------------------------------------------------------------- single-layer helpers (tests, tools)
 
+_SCHED_SCRATCH = {}
+
+
 def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1):
     """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C)."""
     x, w_ok = x.contiguous(), w_ok.contiguous()
     B, H, Wd, C = x.shape
     N = w_ok.shape[0]
     y = torch.empty((B, H, Wd, N), dtype=torch.float32, device=x.device)
-    # split_k == 0: the library schedules the launch itself (stream-K) inside this scratch
-    nws = split_k * B * H * Wd * N if split_k > 1 else (
-        _lib.lib().mpsr_conv2d_scratch_floats(B, H, Wd, N) if split_k == 0 else 0)
-    ws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
+    # split_k == 0: the library schedules the launch itself (stream-K / Winograd) inside a scratch that is kept per
+    # (device, stream) -- launches on one stream are ordered, so they can share it, and a training step issues
+    # hundreds of these calls from Python
+    if split_k == 0:
+        nws = _lib.lib().mpsr_conv2d_scratch_floats(B, H, Wd, N)
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _SCHED_SCRATCH.get(key)
+        if ws is None or ws.numel() < nws:
+            ws = _SCHED_SCRATCH[key] = torch.empty((nws,), dtype=torch.float32, device=x.device)
+    else:
+        nws = split_k * B * H * Wd * N if split_k > 1 else 0
+        ws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
     _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32(
         _lib.ptr(x), B, H, Wd, C, _lib.ptr(w_ok), _lib.ptr(bias.contiguous()) if bias is not None else None,
         _lib.ptr(residual.contiguous()) if residual is not None else None, _lib.ptr(y), N, kh, kw, dilation,
