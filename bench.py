@@ -305,6 +305,34 @@ def cpu_baseline(weights, host, sample, npts):
                       (sample, torch.get_num_threads(), dt)}, ref
 
 
+def training_step_object(device, batch, inp, steps=3, warmup=2):
+    """ms per training step of `batch` instances on this GPU (crop trunk + decoder + heads trainable, 72.8 M
+    parameters in one flat buffer)."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    cfg = config_utils.default_config()
+    net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0)
+    sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
+                  cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"], mean_lwh=inp["mean_lwh"],
+                  prop_cen_z_offset=inp["z_off"])
+    sample.update(trainer.synthetic_ground_truth(sample, seed=7))
+    losses = [float(tr.step(sample)) for _ in range(warmup)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timed = [tr.step(sample) for _ in range(steps)]  # device scalars: no host sync inside the timed region
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    losses += [float(v) for v in timed]
+    return {"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch / dt, 1), "steps": steps,
+            "params": int(net.params.numel()), "grad_bytes": int(net.grads.numel() * 4),
+            "what": "fwd + configured losses (incl. global-map projection) + bwd + clip + Adam + EMA, fp32, "
+                    "decoder BatchNorm on batch statistics; single rank (no all-reduce)",
+            "loss_per_step": [round(v, 1) for v in losses],
+            "note": "random-initialised weights and synthetic targets: the first Adam steps are a transient (the same "
+                    "run reaches 40 % of the initial loss after 10 steps, tools/train_bench.py)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +346,7 @@ def main():
                     help="also all-reduce a 100,204,832-float buffer per step (size of the model's gradient)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-emd", action="store_true", help="skip the extra EMD (BASELINE config 5) object")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the extra training_step object")
     ap.add_argument("--streams", type=int, default=1,
                     help="split each GPU's batch into this many instance shards on separate HIP streams")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
@@ -589,6 +618,14 @@ def main():
             result["bf16x3_mode"] = {"error": repr(e)}
         finally:
             _lib.set_conv_math("fp32")
+    if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_train_step and not args.no_roofline:
+        # one data-parallel TRAINING step of the same 256 instances (forward, the reference's configured
+        # loss set, backward, per-variable clip, Adam + moving average; map-decoder BatchNorm on batch statistics),
+        # timed like tools/train_bench.py.  A side measurement: never part of `value`.
+        try:
+            result["training_step"] = training_step_object(device, args.batch, inp)
+        except Exception as e:
+            result["training_step"] = {"error": repr(e)}
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
         result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
 
