@@ -54,12 +54,36 @@ constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats per LDS row
 constexpr int MAX_CLS = 9;
 
+// Division of a non-negative int (< 2^31) by a launch constant as multiply-high + shift (Granlund-Montgomery,
+// m = ceil(2^(31+l) / d), l = ceil(log2 d)).  On this hardware every vector-ALU instruction of a resident wave takes
+// ~4 cycles away from the SIMD's matrix pipe (tools/mfma_peak.py --valu), and hipcc's integer division is a ~35
+// instruction sequence: the row -> (image, y, x) decodes alone cost the K = 256 layers a fifth of their MFMA time.
+struct FastDiv {
+    unsigned m;  // 0: divisor 1
+    int s;
+};
+inline FastDiv make_fastdiv(int d)
+{
+    FastDiv f{0u, 0};
+    if (d <= 1) return f;
+    int l = 0;
+    while ((1LL << l) < d) ++l;
+    f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)d - 1) / (unsigned)d);
+    f.s = l - 1;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv &f)
+{
+    return f.m == 0 ? n : (int)(__umulhi((unsigned)n, f.m) >> f.s);
+}
+
 // A rectangle of output pixels [y0, y0+h) x [x0, x0+w) of every image whose in-image taps are ky0..ky1 x kx0..kx1.
 struct PixelClass {
     int y0, h, x0, w;
     int ky0, ky1, kx0, kx1;
     int tiles;  // M tiles of this class
     int rows;   // B * h * w
+    FastDiv fd_ppi, fd_w;  // by h * w and by w
 };
 
 struct ConvParams {
@@ -72,13 +96,17 @@ struct ConvParams {
     int M, H, W, C, N, KH, KW, dil, relu;
     int ksteps_total, ksteps_per_split, cblocks;
     int mtiles_xcd, ntiles, splits;  // mtiles_xcd: M tiles per XCD (max over XCDs)
+    FastDiv fd_ntiles, fd_mtiles;
     unsigned xbytes, wbytes;
     size_t ws_floats;
     int ncls;
     PixelClass cls[MAX_CLS];
 };
 
-template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1>
+// PLAIN: a 1x1 layer (convolution or fully connected) over whole images with C a multiple of 32 -- row r of the GEMM
+// is pixel r, a K step is the next 128 bytes of every row: no decode, and the K loop's loads take their per-step
+// offset in a scalar register (no vector-ALU work at all between the MFMAs).
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -96,18 +124,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     // them heaviest class first, the N tiles of one M tile back to back so its activation panel stays in that
     // XCD's L2.  Workgroups past an XCD's share (classes whose tile count is not a multiple of 8) exit at once.
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int ni = l % p.ntiles;
-    int lm = (l / p.ntiles) % p.mtiles_xcd;
-    const int si = l / (p.ntiles * p.mtiles_xcd);
+    const int lq = fdiv(l, p.fd_ntiles);
+    const int ni = l - lq * p.ntiles;
+    const int si = fdiv(lq, p.fd_mtiles);
+    int lm = lq - si * p.mtiles_xcd;
     const int n0 = ni * BN;
     int ci = -1;
-    for (int c = 0; c < p.ncls; ++c) {
-        const int cnt = p.cls[c].tiles > xcd ? (p.cls[c].tiles - xcd + 7) >> 3 : 0;
-        if (lm < cnt) {
-            ci = c;
-            break;
+    if constexpr (PLAIN) {
+        if (xcd + 8 * lm < p.cls[0].tiles) ci = 0;
+    } else {
+        for (int c = 0; c < p.ncls; ++c) {
+            const int cnt = p.cls[c].tiles > xcd ? (p.cls[c].tiles - xcd + 7) >> 3 : 0;
+            if (lm < cnt) {
+                ci = c;
+                break;
+            }
+            lm -= cnt;
         }
-        lm -= cnt;
     }
     if (ci < 0) return;  // block-uniform
     const PixelClass pc = p.cls[ci];
@@ -131,13 +164,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 
     // class row -> (y, x, linear NHWC pixel index); -1 for rows past the end of the class
     auto decode = [&](int row, int &yy, int &xx) -> int {
+        if constexpr (PLAIN) {
+            yy = xx = 0;
+            return row < pc.rows ? row : -1;
+        }
         if (row >= pc.rows) {
             yy = -(1 << 20);  // fails every bounds test
             xx = 0;
             return -1;
         }
-        const int img = row / ppi, pp = row - img * ppi;
-        const int py = pp / pc.w;
+        const int img = fdiv(row, pc.fd_ppi), pp = row - img * ppi;
+        const int py = fdiv(pp, pc.fd_w);
         yy = pc.y0 + py;
         xx = pc.x0 + (pp - py * pc.w);
         return (img * p.H + yy) * p.W + xx;
@@ -150,6 +187,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     for (int j = 0; j < AV; ++j) {
         const int pix = decode(r0 + lrow + 32 * j, ay[j], ax[j]);
         abase[j] = (unsigned)(pix < 0 ? 0 : pix) * (unsigned)p.C * 4u;
+        if constexpr (PLAIN) abase[j] = pix < 0 ? p.xbytes : abase[j] + (unsigned)lcol * 4u;  // the whole voffset
     }
     const int Ktot = p.KH * p.KW * p.C;
     unsigned bbase[BV];
@@ -157,6 +195,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     for (int j = 0; j < BV; ++j) {
         const int n = n0 + lrow + 32 * j;
         bbase[j] = n < p.N ? (unsigned)n * (unsigned)Ktot * 4u : p.wbytes;  // past the end -> zeros
+        if constexpr (PLAIN) bbase[j] = n < p.N ? bbase[j] + (unsigned)lcol * 4u : p.wbytes;
     }
 
     // K-step state, advanced incrementally: taps fastest (kx, then ky over the class's taps), channel block slowest.
@@ -164,7 +203,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     // with the channel block fastest a pixel came back after a whole channel sweep (1/9 of the K loop, far more than
     // the XCD's L2 holds across its resident tiles) and the 3x3 layers fetched their input ~4.7x from HBM.
     int st_cb, st_kx, st_ky;
-    {
+    if (PLAIN || ks_begin == 0) {  // block-uniform; PLAIN has one tap, so st_cb counts K steps
+        st_cb = ks_begin;
+        st_ky = pc.ky0;
+        st_kx = pc.kx0;
+    } else {
         const int ntaps = (pc.ky1 - pc.ky0 + 1) * ntx;
         st_cb = ks_begin / ntaps;
         const int tap = ks_begin - st_cb * ntaps;
@@ -180,6 +223,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     // the state; `live` false (past the last K step) turns every load into an out-of-range one (no traffic)
     auto load_tile = [&](auto set_c, bool live) {
         constexpr int set = decltype(set_c)::value;
+        if constexpr (PLAIN) {
+            const int soff = st_cb * (BK * 4);
+            // a dead load (DEPTH 2 runs past the last K step) goes through a zero-length descriptor: a scalar
+            // select instead of a per-lane one
+            const __amdgpu_buffer_rsrc_t rxl =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, live ? (int)p.xbytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rwl =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, live ? (int)p.wbytes : 0, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < AV; ++j)
+                ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxl, abase[j], soff, 0));
+#pragma unroll
+            for (int j = 0; j < BV; ++j)
+                rb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwl, bbase[j], soff, 0));
+            ++st_cb;
+            return;
+        }
         const int dy = (st_ky - (p.KH >> 1)) * p.dil, dx = (st_kx - (p.KW >> 1)) * p.dil;
         const int c = st_cb * BK + lcol;
         const bool cok = (c < p.C) & live;
@@ -538,8 +598,8 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvParams p, const 
                 xx = 0;
                 return -1;
             }
-            const int img = row / ppi, pp = row - img * ppi;
-            const int py = pp / pc.w;
+            const int img = fdiv(row, pc.fd_ppi), pp = row - img * ppi;
+            const int py = fdiv(pp, pc.fd_w);
             yy = pc.y0 + py;
             xx = pc.x0 + (pp - py * pc.w);
             return (img * p.H + yy) * p.W + xx;
@@ -852,6 +912,8 @@ void build_classes(ConvParams &p, int B, int BM, bool use_classes)
             c.y0 = ys[a].o; c.h = ys[a].len; c.ky0 = ys[a].k0; c.ky1 = ys[a].k1;
             c.x0 = xs[b].o; c.w = xs[b].len; c.kx0 = xs[b].k0; c.kx1 = xs[b].k1;
             c.rows = B * c.h * c.w;
+            c.fd_ppi = make_fastdiv(c.h * c.w);
+            c.fd_w = make_fastdiv(c.w);
             c.tiles = mpsr::ceil_div(c.rows, BM);
         }
     auto taps = [](const PixelClass &c) { return (c.ky1 - c.ky0 + 1) * (c.kx1 - c.kx0 + 1); };
@@ -866,13 +928,28 @@ void build_classes(ConvParams &p, int B, int BM, bool use_classes)
     for (int i = 0; i < p.ncls; ++i) p.mtiles_xcd += mpsr::ceil_div(p.cls[i].tiles, 8);
 }
 
+std::atomic<int> g_plain_override{-1};  // 0: never use the PLAIN instantiation (tests / A-B), else whenever it applies
+
 template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1>
 int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
 {
     build_classes(p, B, BM, use_classes);
     p.ntiles = mpsr::ceil_div(p.N, BN);
+    p.fd_ntiles = make_fastdiv(p.ntiles);
+    p.fd_mtiles = make_fastdiv(p.mtiles_xcd);
     const long long blocks = 8LL * p.mtiles_xcd * p.ntiles * p.splits;
     if (blocks > 0x7fffffffLL) return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv2d: grid too large");
+    // 1x1 layers over whole images with whole 32-channel K steps take the instantiation without decode / tap logic
+    const bool plain = MATH == MATH_FP32 && p.KH == 1 && p.KW == 1 && p.C % BK == 0 && p.ncls == 1 &&
+                       g_plain_override.load() != 0;
+    if constexpr (MATH == MATH_FP32) {
+        if (plain) {
+            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH, true>), dim3((unsigned)blocks), dim3(256),
+                               0, s, p);
+            MPSR_CHECK_LAUNCH("conv_igemm_kernel");
+            return MPSR_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     MPSR_CHECK_LAUNCH("conv_igemm_kernel");
     return MPSR_OK;
@@ -1122,7 +1199,10 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // two staging register sets (loads two K steps ahead) pay on the atrous 3x3 layers of the trunk (block3 conv2:
     // 228 -> 213 us) and with the 96x128 tile at N = 256; elsewhere the lost occupancy costs as much as it buys
     int depth = g_depth_override.load();
-    if (depth < 0) depth = ((sel == 3 && use_classes) || (sel == 5 && N <= 256)) ? 2 : 1;
+    // 1x1 layers on the 64x64 tile: the decode-free instantiation has registers to spare, two staging sets keep its
+    // 7 workgroups per CU (measured +2 % on block2 / block3 conv3 and conv1)
+    const bool plain64 = sel == 3 && KH == 1 && KW == 1 && C % BK == 0 && p.ksteps_total >= 8 && math == MATH_FP32;
+    if (depth < 0) depth = ((sel == 3 && use_classes) || (sel == 5 && N <= 256) || plain64) ? 2 : 1;
 #define MPSR_TILE(BM_, BN_, WM_, WN_)                                                                        \
     rc = math == MATH_BF16X3 ? launch<BM_, BN_, WM_, WN_, MATH_BF16X3>(p, B, use_classes, stream)           \
          : depth == 2        ? launch<BM_, BN_, WM_, WN_, MATH_FP32, 2>(p, B, use_classes, stream)          \
@@ -1154,6 +1234,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
 extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
 extern "C" void mpsr_debug_set_conv_depth(int depth) { g_depth_override = depth; }
+extern "C" void mpsr_debug_set_conv_plain(int mode) { g_plain_override = mode; }
 extern "C" void mpsr_debug_set_conv_winograd(int mode) { g_wino_override = mode; }
 extern "C" void mpsr_debug_set_conv_sched(int mode, int per_cu)
 {
@@ -1283,6 +1364,85 @@ __global__ __launch_bounds__(256) void mfma_lds_kernel(float *out, int iters)
     if (s == 12345.678f) out[0] = s;
 }
 }  // namespace
+
+namespace {
+// One dependent MFMA chain per wave with NV independent vector-ALU instructions issued after every MFMA: does ordinary
+// VALU work of the resident waves take time away from the matrix pipe?  (tools/mfma_peak.py --valu)
+template <int NV, int KIND = 0>
+__global__ __launch_bounds__(256) void mfma_valu_kernel(float *out, int iters, float av, float bv)
+{
+    __shared__ __attribute__((aligned(16))) float buf[256 * 4 + 64];
+    buf[threadIdx.x * 4] = av;
+    __syncthreads();
+    const float *lp = buf + (threadIdx.x & 63) * 4;
+    int sreg = iters;
+    f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = av * (float)(threadIdx.x + e);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(u * NV + q) & 15]) : "v"(bv));
+                if (KIND == 1) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
+                if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(lv) : "v"((unsigned)(size_t)lp) : "memory");
+                if (KIND == 3) asm volatile("s_nop 0");
+            }
+            if (KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[e] + v[e];
+    s += lv.x + (float)sreg;
+    if (s == 12345.678f) out[0] = s;
+}
+}  // namespace
+
+// kind 0: vector ALU, 1: scalar ALU, 2: LDS reads (ds_read_b128), 3: s_nop
+extern "C" int mpsr_debug_mfma_mix(float *out, int cus, int waves_per_simd, int nv, int kind, int iters,
+                                   mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 && (nv == 4 || nv == 8),
+                 "mfma_mix: bad arguments");
+    const dim3 grid((unsigned)(cus * waves_per_simd));
+    hipStream_t s = mpsr::as_stream(stream);
+#define MIX(NV_, K_) hipLaunchKernelGGL((mfma_valu_kernel<NV_, K_>), grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f)
+    if (nv == 4) {
+        if (kind == 0) MIX(4, 0); else if (kind == 1) MIX(4, 1); else if (kind == 2) MIX(4, 2); else MIX(4, 3);
+    } else {
+        if (kind == 0) MIX(8, 0); else if (kind == 1) MIX(8, 1); else if (kind == 2) MIX(8, 2); else MIX(8, 3);
+    }
+#undef MIX
+    MPSR_CHECK_LAUNCH("mfma_valu_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_debug_mfma_valu(float *out, int cus, int waves_per_simd, int nv, int iters, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0, "mfma_valu: bad arguments");
+    const dim3 grid((unsigned)(cus * waves_per_simd));
+    hipStream_t s = mpsr::as_stream(stream);
+    switch (nv) {
+    case 0: hipLaunchKernelGGL(mfma_valu_kernel<0>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 1: hipLaunchKernelGGL(mfma_valu_kernel<1>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 2: hipLaunchKernelGGL(mfma_valu_kernel<2>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 4: hipLaunchKernelGGL(mfma_valu_kernel<4>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 6: hipLaunchKernelGGL(mfma_valu_kernel<6>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 8: hipLaunchKernelGGL(mfma_valu_kernel<8>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 12: hipLaunchKernelGGL(mfma_valu_kernel<12>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    case 16: hipLaunchKernelGGL(mfma_valu_kernel<16>, grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f); break;
+    default: return mpsr::fail(MPSR_ERR_INVALID_ARG, "mfma_valu: nv must be 0, 1, 2, 4, 6, 8, 12 or 16");
+    }
+    MPSR_CHECK_LAUNCH("mfma_valu_kernel");
+    return MPSR_OK;
+}
 
 extern "C" int mpsr_debug_mfma_lds(float *out, int cus, int waves_per_simd, int mode, int iters, mpsr_stream_t stream)
 {

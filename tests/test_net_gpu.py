@@ -246,6 +246,38 @@ def test_border_class_tiling_is_bit_identical():
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("tile,depth", [(-1, -1), (3, 1), (3, 2), (5, 1), (5, 2), (0, 1)])
+def test_plain_1x1_instantiation_is_bit_identical(tile, depth):
+    """1x1 layers with C % 32 == 0 run an instantiation without row decode / tap logic (scalar K-step offsets);
+    same products in the same order as the general kernel: not a bit may differ, ragged M and N tails, bias,
+    residual, ReLU and split-K included."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(123)
+    lib = _lib.lib()
+    for (B, H, Wd, C, N, split) in ((3, 12, 12, 256, 96, 1), (2, 7, 5, 64, 130, 1), (37, 1, 1, 512, 24, 1),
+                                    (2, 12, 12, 128, 64, 2), (1, 3, 3, 32, 4, 1)):
+        x = _dev(rng.standard_normal((B, H, Wd, C)).astype(np.float32))
+        w = _dev((rng.standard_normal((N, C)) / np.sqrt(C)).astype(np.float32))
+        bias = _dev(rng.standard_normal(N).astype(np.float32))
+        res = _dev(rng.standard_normal((B, H, Wd, N)).astype(np.float32))
+        outs = []
+        lib.mpsr_debug_set_conv_tile(tile)
+        lib.mpsr_debug_set_conv_depth(depth)
+        try:
+            for mode in (0, -1):
+                lib.mpsr_debug_set_conv_plain(mode)
+                outs.append(dn.conv2d(x, w, bias, res, 1, 1, 1, True, split_k=split).cpu().numpy())
+        finally:
+            lib.mpsr_debug_set_conv_plain(-1)
+            lib.mpsr_debug_set_conv_tile(-1)
+            lib.mpsr_debug_set_conv_depth(-1)
+        np.testing.assert_array_equal(outs[0], outs[1])
+        ref = np.maximum(x.cpu().numpy().reshape(-1, C).astype(np.float64) @ w.cpu().numpy().T.astype(np.float64)
+                         + bias.cpu().numpy() + res.cpu().numpy().reshape(-1, N), 0)
+        np.testing.assert_allclose(outs[1].reshape(-1, N), ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("split", [2, 3, 8, 16])
 def test_fc_split_k(split):
     from monopsr_amd.core import device_net as dn

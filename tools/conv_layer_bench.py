@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
                     "kernel: -1 heuristic, 1, 2")
     ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0, 1")
+    ap.add_argument("--plain", default="-1", help="comma list: the decode-free 1x1 instantiation: -1 whenever it "
+                    "applies, 0 never")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
                     "median over rounds is reported (boxes and power states drift: compare within one run only)")
     ap.add_argument("--reps", type=int, default=5)
@@ -67,10 +69,13 @@ def main():
         a, _, b = sp.partition(":")
         scheds.append((int(a), int(b) if b else 0))
     winos = [int(v) for v in args.wino.split(",")]
-    combos = [(t, sc, d if len(winos) == 1 and winos[0] == -1 else 100 + wv) for t in tiles for sc in scheds
-              for d in depths for wv in winos]
-    print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join("t%d s%d:%d d%d TF/s (us)" % (t, a, b, d)
-                                                                   for t, (a, b), d in combos)))
+    plains = [int(v) for v in args.plain.split(",")]
+    combos = [(t, sc, d, wv, pl) for t in tiles for sc in scheds for d in depths for wv in winos for pl in plains]
+
+    def label(c):
+        t, (a, b), d, wv, pl = c
+        return "t%d s%d:%d d%d w%d p%d" % (t, a, b, d, wv, pl)
+    print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join(label(c) + " TF/s (us)" for c in combos)))
     total = {c: 0.0 for c in combos}
     shapes = SHAPES
     if args.shape:
@@ -94,13 +99,14 @@ def main():
         samples = {c: [] for c in combos}
         for rnd in range(args.rounds):
             for c in combos:
-                t, sc, d = c
+                t, sc, d, wv, pl = c
                 if t == 4 and N > 32:
                     continue
                 lib.mpsr_debug_set_conv_tile(t)
                 lib.mpsr_debug_set_conv_sched(sc[0], sc[1])
-                lib.mpsr_debug_set_conv_depth(d if d < 50 else -1)
-                lib.mpsr_debug_set_conv_winograd(d - 100 if d >= 50 else -1)
+                lib.mpsr_debug_set_conv_depth(d)
+                lib.mpsr_debug_set_conv_winograd(wv)
+                lib.mpsr_debug_set_conv_plain(pl)
 
                 def run():
                     _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
@@ -126,9 +132,9 @@ def main():
         lib.mpsr_debug_set_conv_sched(-1, 0)
         lib.mpsr_debug_set_conv_depth(-1)
         lib.mpsr_debug_set_conv_winograd(-1)
+        lib.mpsr_debug_set_conv_plain(-1)
         print("%-28s %3d %9.2f | %s" % (name, count, flop / 1e9, "  ".join(cells)))
-    print("per-step conv time (ms): " + "  ".join("t%d s%d:%d d%d %.2f" % (t, sc[0], sc[1], d, total[(t, sc, d)] / 1e3)
-                                                    for t, sc, d in combos))
+    print("per-step conv time (ms): " + "  ".join("%s %.2f" % (label(c), total[c] / 1e3) for c in combos))
 
 
 if __name__ == "__main__":

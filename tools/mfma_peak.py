@@ -45,7 +45,52 @@ def measure_lds(waves, mode, iters=4000, cus=None, reps=3):
     return cus * 4 * waves * iters * 16 * 4096.0 / s / 1e12
 
 
+def measure_valu(waves, nv, iters=4000, cus=None, reps=3):
+    """MFMA rate with `nv` independent VALU instructions issued after every MFMA of every wave."""
+    lib = _lib.lib()
+    cus = cus or torch.cuda.get_device_properties(0).multi_processor_count
+    out = torch.zeros(4, device="cuda")
+    lib.mpsr_debug_mfma_valu.argtypes = [_lib.c_f, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_f]
+    _lib.check(lib.mpsr_debug_mfma_valu(out.data_ptr(), cus, waves, nv, 100, _lib.stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.mpsr_debug_mfma_valu(out.data_ptr(), cus, waves, nv, iters, _lib.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    s = e0.elapsed_time(e1) * 1e-3 / reps
+    return cus * 4 * waves * iters * 16 * 4096.0 / s / 1e12
+
+
+def measure_mix(waves, nv, kind, iters=4000, cus=None, reps=3):
+    lib = _lib.lib()
+    cus = cus or torch.cuda.get_device_properties(0).multi_processor_count
+    out = torch.zeros(4, device="cuda")
+    lib.mpsr_debug_mfma_mix.argtypes = [_lib.c_f, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_f]
+    _lib.check(lib.mpsr_debug_mfma_mix(out.data_ptr(), cus, waves, nv, kind, 100, _lib.stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.mpsr_debug_mfma_mix(out.data_ptr(), cus, waves, nv, kind, iters, _lib.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    s = e0.elapsed_time(e1) * 1e-3 / reps
+    return cus * 4 * waves * iters * 16 * 4096.0 / s / 1e12
+
+
 if __name__ == "__main__":
+    if "--mix" in sys.argv:
+        for kind, name in ((0, "v_fma_f32"), (1, "s_add_u32"), (2, "ds_read_b128"), (3, "s_nop")):
+            print("%-13s " % name + "  ".join("%dw x%d: %.1f" % (w, nv, measure_mix(w, nv, kind, iters=4000 // w))
+                                              for w in (1, 4, 7) for nv in (4, 8)))
+        sys.exit(0)
+    if "--valu" in sys.argv:
+        for w in (1, 2, 4, 7):
+            print("%d waves/SIMD, VALU per MFMA -> TFLOP/s: " % w + "  ".join(
+                "%d: %.1f" % (nv, measure_valu(w, nv, iters=4000 // w)) for nv in (0, 1, 2, 4, 6, 8, 12, 16)))
+        sys.exit(0)
     for mode in (0, 1):
         print("lds mode %d: " % mode + "  ".join("%dw %.1f" % (w, measure_lds(w, mode, iters=8000 // w))
                                                  for w in (1, 2, 3, 4, 6, 7, 8)))
