@@ -106,9 +106,14 @@ struct ConvParams {
 // PLAIN: a 1x1 layer (convolution or fully connected) over whole images with C a multiple of 32 -- row r of the GEMM
 // is pixel r, a K step is the next 128 bytes of every row: no decode, and the K loop's loads take their per-step
 // offset in a scalar register (no vector-ALU work at all between the MFMAs).
-template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1, bool PLAIN = false>
+// KIND 2 (CLS): a 3x3 layer tiled by border classes with C a multiple of 32 -- every tap a class visits is inside the
+// image for every row of the class, so the per-load bounds tests go too: a row's offset is fixed, the tap / channel
+// block offset of a K step is one scalar (the descriptor's base is moved back by the most negative tap offset so that
+// the scalar stays non-negative; the hardware range-checks the vector offset only).
+template <int BM, int BN, int WM, int WN, int MATH = MATH_FP32, int DEPTH = 1, int KIND = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
 {
+    constexpr bool PLAIN = KIND == 1, CLS = KIND == 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AV = BM / 32, BV = BN / 32;  // float4 loads per thread per tile
@@ -187,7 +192,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     for (int j = 0; j < AV; ++j) {
         const int pix = decode(r0 + lrow + 32 * j, ay[j], ax[j]);
         abase[j] = (unsigned)(pix < 0 ? 0 : pix) * (unsigned)p.C * 4u;
-        if constexpr (PLAIN) abase[j] = pix < 0 ? p.xbytes : abase[j] + (unsigned)lcol * 4u;  // the whole voffset
+        // the whole voffset; rows past the end get one that is out of range for the (CLS: enlarged) descriptor
+        if constexpr (PLAIN || CLS)
+            abase[j] = pix < 0 ? p.xbytes + (CLS ? (unsigned)(p.dil * (p.W + 1) * p.C * 4) : 0u)
+                               : abase[j] + (unsigned)lcol * 4u;
     }
     const int Ktot = p.KH * p.KW * p.C;
     unsigned bbase[BV];
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
     for (int j = 0; j < BV; ++j) {
         const int n = n0 + lrow + 32 * j;
         bbase[j] = n < p.N ? (unsigned)n * (unsigned)Ktot * 4u : p.wbytes;  // past the end -> zeros
-        if constexpr (PLAIN) bbase[j] = n < p.N ? bbase[j] + (unsigned)lcol * 4u : p.wbytes;
+        if constexpr (PLAIN || CLS) bbase[j] = n < p.N ? bbase[j] + (unsigned)lcol * 4u : p.wbytes;
     }
 
     // K-step state, advanced incrementally: taps fastest (kx, then ky over the class's taps), channel block slowest.
@@ -238,6 +246,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p)
             for (int j = 0; j < BV; ++j)
                 rb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwl, bbase[j], soff, 0));
             ++st_cb;
+            return;
+        }
+        if constexpr (CLS) {
+            const int dy = (st_ky - (p.KH >> 1)) * p.dil, dx = (st_kx - (p.KW >> 1)) * p.dil;
+            const int bias = p.dil * (p.W + 1) * p.C * 4;  // -(most negative tap offset)
+            const int soffa = ((dy * p.W + dx) * p.C + st_cb * BK) * 4 + bias;
+            const int soffb = ((st_ky * p.KW + st_kx) * p.C + st_cb * BK) * 4;
+            // the window starts `bias` bytes before the tensor, so it is `bias` bytes longer: a valid row + tap lands
+            // in [bias, bias + xbytes) whether the hardware range-checks the scalar offset or not
+            const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(p.x)) - bias, 0, live ? (int)p.xbytes + bias : 0,
+                0x00020000);
+            const __amdgpu_buffer_rsrc_t rwl =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, live ? (int)p.wbytes : 0, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < AV; ++j)
+                ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxl, abase[j], soffa, 0));
+#pragma unroll
+            for (int j = 0; j < BV; ++j)
+                rb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwl, bbase[j], soffb, 0));
+            if (++st_kx > pc.kx1) {
+                st_kx = pc.kx0;
+                if (++st_ky > pc.ky1) {
+                    st_ky = pc.ky0;
+                    ++st_cb;
+                }
+            }
             return;
         }
         const int dy = (st_ky - (p.KH >> 1)) * p.dil, dx = (st_kx - (p.KW >> 1)) * p.dil;
@@ -942,9 +977,20 @@ int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
     // 1x1 layers over whole images with whole 32-channel K steps take the instantiation without decode / tap logic
     const bool plain = MATH == MATH_FP32 && p.KH == 1 && p.KW == 1 && p.C % BK == 0 && p.ncls == 1 &&
                        g_plain_override.load() != 0;
+    // 3x3 layers whose classes cover both axes (every visited tap in-image for every row of its class); the moved
+    // descriptor base must stay a valid 32-bit offset range
+    const bool cls = MATH == MATH_FP32 && use_classes && p.KH == 3 && p.KW == 3 && p.C % BK == 0 &&
+                     p.H >= 2 * p.dil && p.W >= 2 * p.dil && g_plain_override.load() != 0 &&
+                     (long long)p.xbytes + (long long)p.dil * (p.W + 1) * p.C * 4 < 0x7ffffff0LL;
     if constexpr (MATH == MATH_FP32) {
         if (plain) {
-            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH, true>), dim3((unsigned)blocks), dim3(256),
+            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH, 1>), dim3((unsigned)blocks), dim3(256),
+                               0, s, p);
+            MPSR_CHECK_LAUNCH("conv_igemm_kernel");
+            return MPSR_OK;
+        }
+        if (cls) {
+            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH, 2>), dim3((unsigned)blocks), dim3(256),
                                0, s, p);
             MPSR_CHECK_LAUNCH("conv_igemm_kernel");
             return MPSR_OK;

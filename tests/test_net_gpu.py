@@ -246,6 +246,39 @@ def test_border_class_tiling_is_bit_identical():
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("tile,depth", [(-1, -1), (3, 1), (3, 2), (0, 1), (5, 2)])
+def test_class_tap_instantiation_is_bit_identical(tile, depth):
+    """3x3 layers tiled by border classes with C % 32 == 0 run an instantiation whose loads carry the tap offset in a
+    scalar register and no per-load bounds test (every tap of a class is in-image for all its rows): same products,
+    same order as the general kernel."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(321)
+    lib = _lib.lib()
+    for (B, H, Wd, C, N, d) in ((5, 12, 12, 64, 96, 4), (3, 12, 12, 32, 64, 2), (2, 9, 11, 32, 36, 4),
+                                (2, 8, 8, 64, 32, 4), (3, 24, 10, 32, 32, 1), (1, 2, 2, 32, 8, 1)):
+        x = _dev(rng.standard_normal((B, H, Wd, C)).astype(np.float32))
+        w = _dev((rng.standard_normal((N, 9 * C)) / np.sqrt(9 * C)).astype(np.float32))
+        bias = _dev(rng.standard_normal(N).astype(np.float32))
+        outs = []
+        lib.mpsr_debug_set_conv_tile(tile)
+        lib.mpsr_debug_set_conv_depth(depth)
+        lib.mpsr_debug_set_conv_classes(1)
+        try:
+            for mode in (0, -1):
+                lib.mpsr_debug_set_conv_plain(mode)
+                outs.append(dn.conv2d(x, w, bias, None, 3, 3, d, True).cpu().numpy())
+        finally:
+            lib.mpsr_debug_set_conv_plain(-1)
+            lib.mpsr_debug_set_conv_classes(-1)
+            lib.mpsr_debug_set_conv_tile(-1)
+            lib.mpsr_debug_set_conv_depth(-1)
+        np.testing.assert_array_equal(outs[0], outs[1])
+        ref = _conv_ref(x.cpu().numpy(), w.cpu().numpy().reshape(N, 3, 3, C).transpose(1, 2, 3, 0), bias.cpu().numpy(),
+                        None, d, True)
+        np.testing.assert_allclose(outs[1], ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("tile,depth", [(-1, -1), (3, 1), (3, 2), (5, 1), (5, 2), (0, 1)])
 def test_plain_1x1_instantiation_is_bit_identical(tile, depth):
     """1x1 layers with C % 32 == 0 run an instantiation without row decode / tap logic (scalar K-step offsets);
