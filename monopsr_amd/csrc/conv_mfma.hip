@@ -1451,6 +1451,26 @@ __global__ __launch_bounds__(256) void mfma_valu_kernel(float *out, int iters, f
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void empty_kernel(float *out, int spin)
+{
+    extern __shared__ float dyn[];
+    float v = 0.f;
+    for (int i = 0; i < spin; ++i) asm volatile("s_sleep 1");
+    if (out && threadIdx.x == 1000) out[0] = v + dyn[0];
+}
+}  // namespace
+
+// Workgroup dispatch rate: `blocks` workgroups of 256 threads with `lds_bytes` of LDS that do nothing (spin = 0) or
+// sleep for spin * 64 cycles.
+extern "C" int mpsr_debug_dispatch(float *out, int blocks, int lds_bytes, int spin, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(blocks > 0 && lds_bytes >= 0 && lds_bytes <= 64 * 1024, "dispatch: bad arguments");
+    hipLaunchKernelGGL(empty_kernel, dim3((unsigned)blocks), dim3(256), (size_t)lds_bytes, mpsr::as_stream(stream), out, spin);
+    MPSR_CHECK_LAUNCH("empty_kernel");
+    return MPSR_OK;
+}
+
 // kind 0: vector ALU, 1: scalar ALU, 2: LDS reads (ds_read_b128), 3: s_nop
 extern "C" int mpsr_debug_mfma_mix(float *out, int cus, int waves_per_simd, int nv, int kind, int iters,
                                    mpsr_stream_t stream)

@@ -80,7 +80,30 @@ def measure_mix(waves, nv, kind, iters=4000, cus=None, reps=3):
     return cus * 4 * waves * iters * 16 * 4096.0 / s / 1e12
 
 
+def dispatch_rate():
+    lib = _lib.lib()
+    lib.mpsr_debug_dispatch.argtypes = [_lib.c_f, _lib.c_i, _lib.c_i, _lib.c_i, _lib.c_f]
+    for blocks in (2304, 9216, 36864):
+        for lds in (0, 18432, 40960):
+            for spin in (0, 16, 256):
+                for _ in range(2):
+                    _lib.check(lib.mpsr_debug_dispatch(None, blocks, lds, spin, _lib.stream()))
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    _lib.check(lib.mpsr_debug_dispatch(None, blocks, lds, spin, _lib.stream()))
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 100.0
+                print("%6d workgroups, %5d B LDS, sleep %5d cycles: %7.1f us  (%.1f ns per workgroup)"
+                      % (blocks, lds, spin * 64, us, us * 1e3 / blocks))
+
+
 if __name__ == "__main__":
+    if "--dispatch" in sys.argv:
+        dispatch_rate()
+        sys.exit(0)
     if "--mix" in sys.argv:
         for kind, name in ((0, "v_fma_f32"), (1, "s_add_u32"), (2, "ds_read_b128"), (3, "s_nop")):
             print("%-13s " % name + "  ".join("%dw x%d: %.1f" % (w, nv, measure_mix(w, nv, kind, iters=4000 // w))
