@@ -9,7 +9,7 @@
 TAG=${1:-r02}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fast-mode > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err || echo "stats pass failed"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fast-mode --no-train-step > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err || echo "stats pass failed"
 cp $OUT/stats/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" \
