@@ -559,6 +559,105 @@ __global__ __launch_bounds__(256) void emd_loss_kernel(int n, int m, const float
     }
 }
 
+// DEVICE semantics, two own points per thread in the halves of 2-wide vectors: the ~45 full-rate instructions a pair
+// costs (distance, fourth powers, the ten level terms, gradient) issue as packed fp32, which leaves the five
+// transcendentals per pair (3 exp2, rsqrt; sqrt(d2) is taken as d2 * rsqrt) as the larger share.  Same terms in the
+// same order as pair_match<false> / emd_loss_kernel<false, ROLE>.  grid (ceil(own / 512), b).
+template <int ROLE>
+__global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, void *temp,
+                                                         float *__restrict__ cost, float *__restrict__ grad)
+{
+    constexpr int L = Sem<false>::levels;
+    __shared__ float4 tp[kLossTile];
+    __shared__ float tr[kLossTile][L + 2];
+    __shared__ double part[4];
+    const int cloud = blockIdx.y, tid = threadIdx.x;
+    const int nown = ROLE == 0 ? n : m, nother = ROLE == 0 ? m : n;
+    const float *own = (ROLE == 0 ? xyz1 : xyz2) + (size_t)cloud * nown * 3;
+    const float *other = (ROLE == 0 ? xyz2 : xyz1) + (size_t)cloud * nother * 3;
+    const State<false> st(temp, cloud, n, m, L);
+    const float *ratOwn = ROLE == 0 ? st.ratL : st.ratR, *ratOther = ROLE == 0 ? st.ratR : st.ratL;
+    const int i0 = blockIdx.x * 512 + tid, i1 = i0 + 256;
+    const bool live0 = i0 < nown, live1 = i1 < nown;
+    const f32x2 vx = {live0 ? own[3 * i0] : 0.f, live1 ? own[3 * i1] : 0.f};
+    const f32x2 vy = {live0 ? own[3 * i0 + 1] : 0.f, live1 ? own[3 * i1 + 1] : 0.f};
+    const f32x2 vz = {live0 ? own[3 * i0 + 2] : 0.f, live1 ? own[3 * i1 + 2] : 0.f};
+    f32x2 ro[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q)
+        ro[q] = f32x2{live0 ? ratOwn[(size_t)q * nown + i0] : 0.f, live1 ? ratOwn[(size_t)q * nown + i1] : 0.f};
+    f32x2 gx = {0.f, 0.f}, gy = {0.f, 0.f}, gz = {0.f, 0.f}, csum = {0.f, 0.f};
+    for (int o0 = 0; o0 < nother; o0 += kLossTile) {
+        const int cnt = min(kLossTile, nother - o0);
+        __syncthreads();
+        if (tid < cnt) {
+            const float *sp = other + (size_t)(o0 + tid) * 3;
+            tp[tid] = make_float4(sp[0], sp[1], sp[2], 0.f);
+        }
+        for (int q = tid; q < cnt * L; q += 256) tr[q % cnt][q / cnt] = ratOther[(size_t)(q / cnt) * nother + o0 + q % cnt];
+        __syncthreads();
+        if (!live0) continue;  // a whole wave at a time (own points are taken in blocks of 256)
+        for (int o = 0; o < cnt; ++o) {
+            const float4 t = tp[o];
+            const f32x2 dx = vx - t.x, dy = vy - t.y, dz = vz - t.z;  // own - other
+            const f32x2 d2 = dx * dx + dy * dy + dz * dz;
+            f32x2 e[9];
+            const f32x2 a8 = (-0.25f * kLog2e) * d2, a5 = (-16.f * kLog2e) * d2, a2 = (-1024.f * kLog2e) * d2;
+            e[8] = f32x2{__builtin_amdgcn_exp2f(a8[0]), __builtin_amdgcn_exp2f(a8[1])};
+            e[5] = f32x2{__builtin_amdgcn_exp2f(a5[0]), __builtin_amdgcn_exp2f(a5[1])};
+            e[2] = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+            auto p4 = [](f32x2 v) {
+                v = v * v;
+                return v * v;
+            };
+            e[7] = p4(e[8]);
+            e[6] = p4(e[7]);
+            e[4] = p4(e[5]);
+            e[3] = p4(e[4]);
+            e[1] = p4(e[2]);
+            e[0] = p4(e[1]);
+            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                // e * (giver ratio) * (receiver ratio), as pair_match
+                if (ROLE == 0) acc += e[q] * ro[q] * tr[o][q];
+                else acc += e[q] * tr[o][q] * ro[q];
+            }
+            const f32x2 mv = acc + (ROLE == 0 ? ro[9] * tr[o][9] : tr[o][9] * ro[9]);
+            f32x2 rs;
+            rs[0] = __builtin_amdgcn_rsqf(fmaxf(d2[0], 1e-20f));
+            rs[1] = __builtin_amdgcn_rsqf(fmaxf(d2[1], 1e-20f));
+            const f32x2 sc = mv * rs;
+            gx += dx * sc;
+            gy += dy * sc;
+            gz += dz * sc;
+            if (ROLE == 0) csum += d2 * sc;  // |d| * match with |d| = d2 * rsqrt(d2)
+        }
+    }
+    if (grad) {
+        if (live0) {
+            float *g = grad + ((size_t)cloud * nown + i0) * 3;
+            g[0] = gx[0];
+            g[1] = gy[0];
+            g[2] = gz[0];
+        }
+        if (live1) {
+            float *g = grad + ((size_t)cloud * nown + i1) * 3;
+            g[0] = gx[1];
+            g[1] = gy[1];
+            g[2] = gz[1];
+        }
+    }
+    if (ROLE == 0) {
+        double v = wave_sum_d((double)csum[0] + (double)csum[1]);
+        __syncthreads();
+        if ((tid & 63) == 0) part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) atomicAdd(&cost[cloud], (float)(part[0] + part[1] + part[2] + part[3]));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- cost / grad of
 // a materialised match (DEVICE layout [m][n]; a HOST-layout match is the DEVICE layout of the swapped clouds)
 
@@ -808,10 +907,10 @@ extern "C" int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float
     } else {
         if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
             return rc;
-        hipLaunchKernelGGL((emd_loss_kernel<false, 0>), g1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1);
+        const dim3 p1(mpsr::ceil_div(n, 512), b), p2(mpsr::ceil_div(m, 512), b);
+        hipLaunchKernelGGL(emd_loss_pk_kernel<0>, p1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1);
         if (grad2)
-            hipLaunchKernelGGL((emd_loss_kernel<false, 1>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost,
-                               grad2);
+            hipLaunchKernelGGL(emd_loss_pk_kernel<1>, p2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad2);
     }
     MPSR_CHECK_LAUNCH("emd_loss_kernel");
     return MPSR_OK;
