@@ -37,6 +37,8 @@
 //   * Scratch: (n+m) * (1 + levels) state words per cloud.  With only the reference shell's (n+m)*2 floats
 //     (tf_approxmatch.cpp:168) the DEVICE path still works: ratios of one level at a time, match accumulated level by
 //     level (the reference's own traffic pattern; bit-identical result, ~2x slower).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -172,6 +174,12 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
         s1[u] = (S)1e-9;
         s3[u] = 0;
     }
+    // DEVICE: the exponent of the smaller level in magnitude; the other one is its fourth power.  When the current
+    // level is the zero level (e = 1) the exponential belongs to the previous level instead.  (Folding the level
+    // constant into the coordinates -- exp2(-|s p - s q|^2) -- would save a packed multiply per pair, but the products
+    // s p round before the subtraction: 50x the error in the steep levels' exponents, visible in the gradients.)
+    const bool cur_zero = kDo1 && lv_cur == 0.f;
+    const float c_small = (kDo1 && !cur_zero ? lv_cur : lv_prev) * kLog2e;
     f32x2 vx[kPV], vy[kPV], vz[kPV], a1[kPV], a3[kPV];
 #pragma unroll
     for (int v = 0; v < kPV; ++v) {
@@ -181,10 +189,6 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
         a1[v] = f32x2{1e-9f, 1e-9f};
         a3[v] = f32x2{0.f, 0.f};
     }
-    // DEVICE: the exponent of the smaller level in magnitude; the other one is its fourth power.  When the current
-    // level is the zero level (e = 1) the exponential belongs to the previous level instead.
-    const bool cur_zero = kDo1 && lv_cur == 0.f;
-    const float c_small = (kDo1 && !cur_zero ? lv_cur : lv_prev) * kLog2e;
 
     for (int o0 = 0; o0 < m; o0 += kTile) {
         const int cnt = min(kTile, m - o0);
@@ -209,35 +213,40 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
                 }
             }
         } else {
+            // the zero level (e_cur = 1, the exponential is e_prev) is block-uniform: two copies of the loop, not a
+            // select per pair (hipcc does not unswitch it: 5 of 17 instructions per pair pair were selects and moves)
+            auto sweep = [&](auto zero_c) {
+                constexpr bool kZero = decltype(zero_c)::value;
 #pragma unroll 4
-            for (int o = 0; o < cnt; ++o) {
-                const float4 t = tile[o];
-                const float w1 = kDo1 ? w1s[o] : 0.f;
+                for (int o = 0; o < cnt; ++o) {
+                    const float4 t = tile[o];
+                    const float w1 = kDo1 ? w1s[o] : 0.f;
 #pragma unroll
-                for (int v = 0; v < kPV; ++v) {
-                    const f32x2 dx = t.x - vx[v], dy = t.y - vy[v], dz = t.z - vz[v];  // the reference's order (x2 - x1)
-                    const f32x2 d2 = dx * dx + dy * dy + dz * dz;
-                    const f32x2 a = c_small * d2;
-                    f32x2 es, eb;  // e of the smaller / of the 4x larger level
-                    es[0] = __builtin_amdgcn_exp2f(a[0]);
-                    es[1] = __builtin_amdgcn_exp2f(a[1]);
-                    if (MODE == 1 && !cur_zero) {
-                        eb = es * es;
-                        eb = eb * eb;
-                    }
-                    if (MODE == 0) a1[v] += es * w1;
-                    if (MODE == 2) a3[v] += es * t.w;
-                    if (MODE == 1) {
-                        if (cur_zero) {  // block-uniform: e_cur = 1, the exponential is e_prev
-                            a1[v] += w1;
-                            a3[v] += es * t.w;
-                        } else {
-                            a1[v] += es * w1;
-                            a3[v] += eb * t.w;
+                    for (int v = 0; v < kPV; ++v) {
+                        const f32x2 dx = t.x - vx[v], dy = t.y - vy[v], dz = t.z - vz[v];  // the reference's order (x2 - x1)
+                        const f32x2 d2 = dx * dx + dy * dy + dz * dz;
+                        const f32x2 a = c_small * d2;
+                        f32x2 es;  // e of the smaller level; its fourth power is e of the 4x larger one
+                        es[0] = __builtin_amdgcn_exp2f(a[0]);
+                        es[1] = __builtin_amdgcn_exp2f(a[1]);
+                        if (MODE == 0) a1[v] += es * w1;
+                        if (MODE == 2) a3[v] += es * t.w;
+                        if (MODE == 1) {
+                            if (kZero) {
+                                a1[v] += w1;
+                                a3[v] += es * t.w;
+                            } else {
+                                f32x2 eb = es * es;
+                                eb = eb * eb;
+                                a1[v] += es * w1;
+                                a3[v] += eb * t.w;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (MODE == 1 && cur_zero) sweep(std::true_type{});
+            else sweep(std::false_type{});
         }
     }
     if constexpr (!HOST) {
