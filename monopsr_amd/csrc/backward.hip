@@ -100,18 +100,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             const bool mok = mv < Mv;
             // two divisions per load, four loads per K step: float reciprocal + one-step fix-up instead of the
             // ~40-instruction integer division sequence (operands < 2^24; the fix-up absorbs the rounding)
+            // (every product below has operands < 2^24 -- the host checks M, N, C -- so they are the full-rate
+            // 24-bit multiplies, not the quarter-rate 32-bit ones: vector instructions take matrix-pipe time)
             int img = (int)((float)mv * inv_HWv);
-            img -= (img * HWv > mv);
-            img += ((img + 1) * HWv <= mv);
-            const int r = mv - img * HWv;
+            img -= (__mul24(img, HWv) > mv);
+            img += (__mul24(img + 1, HWv) <= mv);
+            const int r = mv - __mul24(img, HWv);
             int ry = (int)((float)r * inv_wv);
-            ry -= (ry * wv > r);
-            ry += ((ry + 1) * wv <= r);
-            const int m = img * HW + (ylo + ry) * p.W + xlo + (r - ry * wv);  // the pixel itself
-            const unsigned offa = (mok && nok) ? ((unsigned)m * (unsigned)p.N + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
+            ry -= (__mul24(ry, wv) > r);
+            ry += (__mul24(ry + 1, wv) <= r);
+            const int m = __mul24(img, HW) + __mul24(ylo + ry, p.W) + xlo + (r - __mul24(ry, wv));  // the pixel itself
+            const unsigned offa = (mok && nok) ? (__umul24((unsigned)m, (unsigned)p.N) + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
             ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa, 0, 0));
             const unsigned offb = (mok && cok)
-                ? ((unsigned)(m + dyo * p.W + dxo) * (unsigned)p.C + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
+                ? (__umul24((unsigned)(m + dyo * p.W + dxo), (unsigned)p.C) + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
             rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb, 0, 0));
         }
     };
@@ -415,6 +417,9 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     MPSR_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const long long M = (long long)B * H * W;
     MPSR_REQUIRE(M * C * 4 < 0xfffffff0LL && M * N * 4 < 0xfffffff0LL, "conv2d_wgrad: tensor exceeds 4 GiB");
+    // the kernel decodes pixel indices with 24-bit multiplies and a float reciprocal
+    MPSR_REQUIRE(M < (1LL << 24) && N < (1 << 24) && C < (1 << 24),
+                 "conv2d_wgrad: more than 2^24 pixels (or channels) in one call; split the batch");
     WgradParams p;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.M = (int)M; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation;

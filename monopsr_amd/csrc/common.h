@@ -45,4 +45,28 @@ inline hipStream_t as_stream(mpsr_stream_t s) { return reinterpret_cast<hipStrea
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+
+// Division of a non-negative int (< 2^31) by a launch constant as multiply-high + shift (Granlund-Montgomery,
+// m = ceil(2^(31+l) / d), l = ceil(log2 d)).  On this hardware every vector-ALU instruction of a resident wave takes
+// ~4 cycles away from the SIMD's matrix pipe (tools/mfma_peak.py --valu), and hipcc's integer division is a ~35
+// instruction sequence: the row -> (image, y, x) decodes alone cost the K = 256 layers a fifth of their MFMA time.
+struct FastDiv {
+    unsigned m;  // 0: divisor 1
+    int s;
+};
+__host__ __device__ inline FastDiv make_fastdiv(int d)
+{
+    FastDiv f{0u, 0};
+    if (d <= 1) return f;
+    int l = 0;
+    while ((1LL << l) < d) ++l;
+    f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)d - 1) / (unsigned)d);
+    f.s = l - 1;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv &f)
+{
+    return f.m == 0 ? n : (int)(__umulhi((unsigned)n, f.m) >> f.s);
+}
+
 }  // namespace mpsr

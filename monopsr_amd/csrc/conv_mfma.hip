@@ -54,28 +54,9 @@ constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats per LDS row
 constexpr int MAX_CLS = 9;
 
-// Division of a non-negative int (< 2^31) by a launch constant as multiply-high + shift (Granlund-Montgomery,
-// m = ceil(2^(31+l) / d), l = ceil(log2 d)).  On this hardware every vector-ALU instruction of a resident wave takes
-// ~4 cycles away from the SIMD's matrix pipe (tools/mfma_peak.py --valu), and hipcc's integer division is a ~35
-// instruction sequence: the row -> (image, y, x) decodes alone cost the K = 256 layers a fifth of their MFMA time.
-struct FastDiv {
-    unsigned m;  // 0: divisor 1
-    int s;
-};
-inline FastDiv make_fastdiv(int d)
-{
-    FastDiv f{0u, 0};
-    if (d <= 1) return f;
-    int l = 0;
-    while ((1LL << l) < d) ++l;
-    f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)d - 1) / (unsigned)d);
-    f.s = l - 1;
-    return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv &f)
-{
-    return f.m == 0 ? n : (int)(__umulhi((unsigned)n, f.m) >> f.s);
-}
+using mpsr::FastDiv;
+using mpsr::fdiv;
+using mpsr::make_fastdiv;
 
 // A rectangle of output pixels [y0, y0+h) x [x0, x0+w) of every image whose in-image taps are ky0..ky1 x kx0..kx1.
 struct PixelClass {
