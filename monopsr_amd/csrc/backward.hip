@@ -93,15 +93,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[4], rb[4];
-    auto load_tile = [&](int ms) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int mv = ms * WG_K + lrow + 8 * j;  // index into the tap's valid pixels
+    // Row decode through LDS.  A K step stages 32 pixel rows; which pixel a row is -- (image, y, x) inside the tap's
+    // valid rectangle -- and the byte offsets that follow are the same for the 32 threads that share the row.  The 32
+    // decodes of a step are done ONCE, by the first half of wave 0, one step ahead, into a two-entry LDS table; every
+    // thread then reads its row's pair of offsets and adds its column.  Vector instructions take matrix-pipe time on
+    // this hardware (conv_mfma.hip / DESIGN.md 4.1): decoding per thread and per load was ~200 of them per step and
+    // wave against 64 MFMAs; this is ~16, plus ~45 on one wave.
+    __shared__ uint2 offs[2][WG_K];  // (dy byte offset, x byte offset) of a row, or out-of-range ones past the end
+    auto decode_rows = [&](int ms) {
+        if (tid < WG_K) {
+            const int mv = ms * WG_K + tid;  // index into the tap's valid pixels
             const bool mok = mv < Mv;
-            // two divisions per load, four loads per K step: float reciprocal + one-step fix-up instead of the
-            // ~40-instruction integer division sequence (operands < 2^24; the fix-up absorbs the rounding)
-            // (every product below has operands < 2^24 -- the host checks M, N, C -- so they are the full-rate
-            // 24-bit multiplies, not the quarter-rate 32-bit ones: vector instructions take matrix-pipe time)
+            // float reciprocal + one-step fix-up (operands < 2^24, checked on the host; 24-bit multiplies)
             int img = (int)((float)mv * inv_HWv);
             img -= (__mul24(img, HWv) > mv);
             img += (__mul24(img + 1, HWv) <= mv);
@@ -110,10 +113,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             ry -= (__mul24(ry, wv) > r);
             ry += (__mul24(ry + 1, wv) <= r);
             const int m = __mul24(img, HW) + __mul24(ylo + ry, p.W) + xlo + (r - __mul24(ry, wv));  // the pixel itself
-            const unsigned offa = (mok && nok) ? (__umul24((unsigned)m, (unsigned)p.N) + (unsigned)(n0 + lcol)) * 4u : p.dybytes;
+            offs[ms & 1][tid] = make_uint2(
+                mok ? (__umul24((unsigned)m, (unsigned)p.N) + (unsigned)n0) * 4u : p.dybytes,
+                mok ? (__umul24((unsigned)(m + dyo * p.W + dxo), (unsigned)p.C) + (unsigned)c0) * 4u : p.xbytes);
+        }
+    };
+    const unsigned lcol4 = (unsigned)lcol * 4u;
+    auto load_tile = [&](int ms) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint2 o = offs[ms & 1][lrow + 8 * j];
+            // a row past the end keeps an out-of-range offset after the column is added (the host keeps the tensors
+            // 4 KiB below 4 GiB)
+            const unsigned offa = nok ? o.x + lcol4 : p.dybytes;
             ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa, 0, 0));
-            const unsigned offb = (mok && cok)
-                ? (__umul24((unsigned)(m + dyo * p.W + dxo), (unsigned)p.C) + (unsigned)(c0 + lcol)) * 4u : p.xbytes;
+            const unsigned offb = cok ? o.y + lcol4 : p.xbytes;
             rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb, 0, 0));
         }
     };
@@ -149,11 +163,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     };
 
     if (ms_begin >= ms_end) return;  // uniform over the workgroup
+    decode_rows(ms_begin);
+    decode_rows(ms_begin + 1);
+    __syncthreads();
     load_tile(ms_begin);
     store_tile();
     __syncthreads();
     for (int ms = ms_begin; ms < ms_end - 1; ++ms) {
         load_tile(ms + 1);
+        decode_rows(ms + 2);  // into the table entry load_tile(ms) read before the barriers of the previous trip
         compute_tile();
         __syncthreads();
         store_tile();
@@ -416,7 +434,7 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     if (B == 0) return MPSR_OK;
     MPSR_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const long long M = (long long)B * H * W;
-    MPSR_REQUIRE(M * C * 4 < 0xfffffff0LL && M * N * 4 < 0xfffffff0LL, "conv2d_wgrad: tensor exceeds 4 GiB");
+    MPSR_REQUIRE(M * C * 4 < 0xfffff000LL && M * N * 4 < 0xfffff000LL, "conv2d_wgrad: tensor exceeds 4 GiB");
     // the kernel decodes pixel indices with 24-bit multiplies and a float reciprocal
     MPSR_REQUIRE(M < (1LL << 24) && N < (1 << 24) && C < (1 << 24),
                  "conv2d_wgrad: more than 2^24 pixels (or channels) in one call; split the batch");
