@@ -956,14 +956,13 @@ int launch(ConvParams &p, int B, bool use_classes, hipStream_t s)
     const long long blocks = 8LL * p.mtiles_xcd * p.ntiles * p.splits;
     if (blocks > 0x7fffffffLL) return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv2d: grid too large");
     // 1x1 layers over whole images with whole 32-channel K steps take the instantiation without decode / tap logic
-    const bool plain = MATH == MATH_FP32 && p.KH == 1 && p.KW == 1 && p.C % BK == 0 && p.ncls == 1 &&
-                       g_plain_override.load() != 0;
+    const bool plain = p.KH == 1 && p.KW == 1 && p.C % BK == 0 && p.ncls == 1 && g_plain_override.load() != 0;
     // 3x3 layers whose classes cover both axes (every visited tap in-image for every row of its class); the moved
     // descriptor base must stay a valid 32-bit offset range
-    const bool cls = MATH == MATH_FP32 && use_classes && p.KH == 3 && p.KW == 3 && p.C % BK == 0 &&
+    const bool cls = use_classes && p.KH == 3 && p.KW == 3 && p.C % BK == 0 &&
                      p.H >= 2 * p.dil && p.W >= 2 * p.dil && g_plain_override.load() != 0 &&
                      (long long)p.xbytes + (long long)p.dil * (p.W + 1) * p.C * 4 < 0x7ffffff0LL;
-    if constexpr (MATH == MATH_FP32) {
+    {
         if (plain) {
             hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MATH, DEPTH, 1>), dim3((unsigned)blocks), dim3(256),
                                0, s, p);
