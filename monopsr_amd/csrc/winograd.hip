@@ -21,6 +21,7 @@
 //     so A^T M A is 24 adds per element; bias + ReLU fused; each store instruction writes two 128-byte rows.
 // Numerics: fp32 throughout; transform constants are 0, +-1, +-1/2 (exact); measured error against float64
 // ~1e-6 of the tensor scale (direct fp32 MFMA path: ~5e-7), three orders inside the path's 1e-3 budget.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -365,10 +366,245 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Eight-wave variant: the same workgroup tile, LDS layout and K-step schedule, but 512 threads -- two waves per SIMD.
+// One wave per SIMD means every LDS / memory instruction of the fill costs the wave its issue time (tools/
+// mfma_peak.py --mix: 4 ds_read_b128 per MFMA run at 75 TFLOP/s with one wave per SIMD and 124 with four); with a
+// second wave on the SIMD those issue slots overlap the other wave's MFMAs.  To fit two waves into the register file
+// a wave keeps HALF the positions (4 of the 8 of each group: 128 accumulator registers); the fill is split the same
+// way -- a thread loads / transforms / stores 2 of its slot's 4 channels and 4 of a group's 8 filter rows -- and the
+// output transform, being linear, is done as two partial sums that the wave pair exchanges through LDS once.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv8_kernel(const WinoParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                   // [16][MT][ROW]
+    float *Bs = lds + 16 * MT * ROW;   // [16][NT][ROW]
+    const int xcd = blockIdx.x & 7, l_ = blockIdx.x >> 3;
+    const int nb = l_ % p.nblocks;
+    const int mb = (l_ / p.nblocks) * 8 + xcd;
+    if (mb >= p.mblocks) return;  // block-uniform
+    const int n0 = nb * NT, t0 = mb * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 2 x 2 wave grid, position half: wave-uniform by construction -- said so, or every load whose scalar offset
+    // depends on them becomes a waterfall loop
+    const int wq = __builtin_amdgcn_readfirstlane(wave & 3), ph = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int wm = wq >> 1, wn = wq & 1;
+    const int slot_id = tid & 255;            // loader slot (tile or filter row, channel quad); ph doubles as its half
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, (int)p.ubytes, 0x00020000);
+
+    // ---- A loader: thread = (tile, channel quad, channel pair of the quad)
+    const int ltile = slot_id >> 2, quad = slot_id & 3;
+    unsigned aoff[16];
+    {
+        const int t = t0 + ltile;
+        const int tpi = p.th * p.tw;
+        const int img = t / tpi, rem = t - img * tpi;
+        const int ty = rem / p.tw, tx = rem - ty * p.tw;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < p.H && x0 + sx >= 0 && x0 + sx < p.W;
+                aoff[r * 4 + sx] = ok ? ((unsigned)((img * p.H + y0 + r) * p.W + x0 + sx) * (unsigned)p.C + 4u * quad + 2u * ph) * 4u
+                                      : p.xbytes;
+            }
+    }
+    // ---- B loader: thread = (filter row n, channel quad); it handles positions 4 ph .. 4 ph + 3 of a group
+    const unsigned bstride = (unsigned)p.N * KC * 4u;
+    const unsigned boff = n0 + (slot_id >> 2) < p.N
+        ? (unsigned)((n0 + (slot_id >> 2)) * KC + 4 * (slot_id & 3)) * 4u + 4u * (unsigned)ph * bstride : p.ubytes;
+
+    f32x2 pa[16];
+    float4 pb[4];
+    auto load_a1 = [&](int cb, bool live, int i) {
+        pa[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, live ? aoff[i] : p.xbytes,
+                                                                               live ? (unsigned)cb * KC * 4u : 0u, 0));
+    };
+    auto load_b1 = [&](int cb, int pos, int slot) {
+        pb[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  ru, boff, ((unsigned)cb * 16u + (unsigned)pos) * bstride, 0));
+    };
+    f32x2 t[4][4];
+    auto row_transform_col = [&](int c) {
+        const f32x2 d0 = pa[c], d1 = pa[4 + c], d2 = pa[8 + c], d3 = pa[12 + c];
+        t[0][c] = d0 - d2;
+        t[1][c] = d1 + d2;
+        t[2][c] = d2 - d1;
+        t[3][c] = d1 - d3;
+    };
+    float *arow = As + ltile * ROW + 4 * quad + 2 * ph;
+    float *brow = Bs + (slot_id >> 2) * ROW + 4 * (slot_id & 3) + 4 * ph * NT * ROW;  // + this thread's position half
+    auto store_a = [&](int pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const f32x2 v = nu == 0 ? t[xi][0] - t[xi][2] : nu == 1 ? t[xi][1] + t[xi][2]
+                        : nu == 2 ? t[xi][2] - t[xi][1] : t[xi][1] - t[xi][3];
+        *reinterpret_cast<f32x2 *>(arow + pos * MT * ROW) = v;
+    };
+    auto store_b = [&](int pos, int slot) { *reinterpret_cast<float4 *>(brow + pos * NT * ROW) = pb[slot]; };
+
+    // accumulators: position 8 g + 4 ph + r  ->  acc[4 g + r]
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+    // (the wave's position half is folded into the base addresses: every fragment offset below is a literal)
+    const float *Aw = As + (wm * 32 + (lane & 31)) * ROW + (lane >> 5) * 4 + 4 * ph * MT * ROW;
+    const float *Bw = Bs + (wn * 32 + (lane & 31)) * ROW + (lane >> 5) * 4 + 4 * ph * NT * ROW;
+    // one group for this wave = 4 positions x 2 k-halves = 4 pair steps of 8 MFMAs, a filler slot after every MFMA
+    auto compute = [&](auto group_c, auto &&filler) {
+        constexpr int g = decltype(group_c)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r0 = 2 * (s >> 1), kq = s & 1;
+            const int q0 = 8 * g + r0;  // LDS position of the pair, relative to the wave's half
+            __builtin_amdgcn_sched_barrier(0);
+            float4 a0 = *reinterpret_cast<const float4 *>(Aw + q0 * MT * ROW + kq * 8);
+            float4 b0 = *reinterpret_cast<const float4 *>(Bw + q0 * NT * ROW + kq * 8);
+            float4 a1 = *reinterpret_cast<const float4 *>(Aw + (q0 + 1) * MT * ROW + kq * 8);
+            float4 b1 = *reinterpret_cast<const float4 *>(Bw + (q0 + 1) * NT * ROW + kq * 8);
+            f32x16 &c0 = acc[4 * g + r0], &c1 = acc[4 * g + r0 + 1];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c0, 0, 0, 0);
+            filler(8 * s + 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c1, 0, 0, 0);
+            filler(8 * s + 1);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c0, 0, 0, 0);
+            filler(8 * s + 2);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c1, 0, 0, 0);
+            filler(8 * s + 3);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c0, 0, 0, 0);
+            filler(8 * s + 4);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c1, 0, 0, 0);
+            filler(8 * s + 5);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c0, 0, 0, 0);
+            filler(8 * s + 6);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c1, 0, 0, 0);
+            filler(8 * s + 7);
+        }
+    };
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+
+    // prologue: step 0 complete in LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_a1(0, true, i);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row_transform_col(c);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_b1(0, 8 * h + j, j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store_a(8 * h + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_b(8 * h + j, j);
+    }
+    __syncthreads();
+    // Rotated loop as in the four-wave kernel.  Filler plans (32 slots per half):
+    //   second half of step k (multiplies g1(k)):        first half of step k+1 (multiplies g0(k+1)):
+    //     0-3   request this thread's filter rows of g0     0-3   request this thread's filter rows of g1(k+1)
+    //     4-7   row transform of patch(k+1)                 6-13  store A rows of g1(k+1)
+    //     8-15  store A rows of g0(k+1)                     20-23 store filter rows of g1(k+1)
+    //     16-19 store filter rows of g0(k+1)
+    //     20-31 request patch(k+2) (vmcnt retires in order: the filter rows' stores must not sit behind these)
+    const int nsteps = p.cblocks;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_a1(1, nsteps > 1, i);
+    compute(G0{}, [](int) {});
+    __syncthreads();
+    for (int k = 0; k + 1 < nsteps; ++k) {
+        const bool more2 = k + 2 < nsteps;
+        compute(G1{}, [&](int slot) {
+            if (slot < 4) load_b1(k + 1, slot, slot);
+            else if (slot < 8) row_transform_col(slot - 4);
+            else if (slot < 16) store_a(slot - 8);
+            else if (slot < 20) store_b(slot - 16, slot - 16);
+            else if (slot < 28) load_a1(k + 2, more2, slot - 20);
+            else {
+                load_a1(k + 2, more2, 8 + 2 * (slot - 28));
+                load_a1(k + 2, more2, 9 + 2 * (slot - 28));
+            }
+        });
+        __syncthreads();
+        compute(G0{}, [&](int slot) {
+            if (slot < 4) load_b1(k + 1, 8 + slot, slot);
+            else if (slot >= 6 && slot < 14) store_a(8 + slot - 6);
+            else if (slot >= 20 && slot < 24) store_b(8 + slot - 20, slot - 20);
+        });
+        __syncthreads();
+    }
+    compute(G1{}, [](int) {});
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]),
+                   "+a"(acc[7]));
+
+    // ---- output transform, split over the wave pair.  This wave holds the transformed-domain rows xi = ph and ph + 2
+    // (positions 4 xi + nu): acc[nu] = M[ph][nu], acc[4 + nu] = M[ph + 2][nu].  With s0 = M0 + M1 + M2 and
+    // s1 = M1 - M2 - M3 per column nu, the wave's partial sums are
+    //     ph 0 (rows 0, 2):  s0' = M0 + M2,  s1' = -M2          ph 1 (rows 1, 3):  s0' = M1,  s1' = M1 - M3
+    // Output row 0 (y00, y01 from s0) is finished by the ph = 0 wave, row 1 (y10, y11 from s1) by the ph = 1 wave; each
+    // hands the other its partial of the row it does not finish (2 values per element) through LDS.
+    __syncthreads();  // every wave is done reading the A / B tiles
+    float *xch = lds + (size_t)wq * (2 * 2 * 16 * 64);  // [target ph][value][element][lane]
+    const int n = n0 + wn * 32 + (lane & 31);
+    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    float mine[16][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const float ma = acc[nu][e], mb2 = acc[4 + nu][e];  // rows ph and ph + 2
+            if (ph == 0) {
+                s0[nu] = ma + mb2;
+                s1[nu] = -mb2;
+            } else {
+                s0[nu] = ma;
+                s1[nu] = ma - mb2;
+            }
+        }
+        const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+        const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+        // keep the row this wave finishes, hand over the other one
+        mine[e][0] = ph == 0 ? y00 : y10;
+        mine[e][1] = ph == 0 ? y01 : y11;
+        float *dst = xch + (size_t)((1 - ph) * 2) * 16 * 64 + e * 64 + lane;
+        dst[0] = ph == 0 ? y10 : y00;
+        dst[16 * 64] = ph == 0 ? y11 : y01;
+    }
+    __syncthreads();
+    const int tpi = p.th * p.tw;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int tt = t0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const float *src = xch + (size_t)(ph * 2) * 16 * 64 + e * 64 + lane;
+        float ya = mine[e][0] + src[0] + bias, yb = mine[e][1] + src[16 * 64] + bias;
+        if (p.relu) {
+            ya = fmaxf(ya, 0.f);
+            yb = fmaxf(yb, 0.f);
+        }
+        if (tt < p.T && n < p.N) {
+            const int img = tt / tpi, rem = tt - img * tpi;
+            const int ty = rem / p.tw, tx = rem - ty * p.tw;
+            float *o = p.y + ((size_t)(img * p.H + 2 * ty + ph) * p.W + 2 * tx) * p.N + n;
+            o[0] = ya;
+            o[p.N] = yb;
+        }
+    }
+}
+
 }  // namespace
 
 static unsigned long long *g_wino_trace = nullptr;
 extern "C" void mpsr_debug_set_wino_trace(void *buf) { g_wino_trace = static_cast<unsigned long long *>(buf); }
+namespace mpsr { extern std::atomic<int> g_wino_waves; }
+extern "C" void mpsr_debug_set_wino_waves(int waves) { mpsr::g_wino_waves = waves; }
 
 namespace mpsr {
 
@@ -376,6 +612,8 @@ namespace mpsr {
 size_t winograd_scratch_floats(int C, int N) { return (size_t)16 * N * C; }
 
 bool winograd_applies(int H, int W, int C, int N) { return H % 2 == 0 && W % 2 == 0 && C % KC == 0 && C >= KC && N >= 1; }
+
+std::atomic<int> g_wino_waves{8};  // 4: the one-wave-per-SIMD kernel, 8: the two-waves-per-SIMD variant
 
 int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                      int N, float *ws, size_t ws_floats, hipStream_t s)
@@ -389,6 +627,10 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
     std::call_once(once, [] {
         attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float)));
+        if (attr_status == hipSuccess)
+            attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv8_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(kLdsFloats * sizeof(float)));
     });
     MPSR_CHECK_HIP(attr_status);
     {
@@ -410,7 +652,10 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
     p.trace = g_wino_trace;
     const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd: grid too large");
-    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), kLdsFloats * sizeof(float), s, p);
+    if (g_wino_waves.load() == 8)
+        hipLaunchKernelGGL(wino_conv8_kernel, dim3((unsigned)blocks), dim3(512), kLdsFloats * sizeof(float), s, p);
+    else
+        hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), kLdsFloats * sizeof(float), s, p);
     MPSR_CHECK_LAUNCH("wino_conv_kernel");
     return MPSR_OK;
 }
