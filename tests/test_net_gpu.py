@@ -198,10 +198,11 @@ def test_stream_k_against_one_tile_per_workgroup(shape):
     (2, 24, 24, 64, 64, True, True), (1, 48, 48, 32, 128, True, True), (3, 10, 6, 16, 40, False, False),
     (1, 2, 2, 16, 4, True, False), (5, 12, 12, 48, 200, True, True), (4, 48, 48, 256, 128, True, True),
     (2, 24, 24, 512, 256, True, True), (7, 4, 8, 16, 65, True, True)])
-def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu):
-    """The Winograd F(2x2,3x3) kernel (3x3, stride 1, SAME, even maps): ragged tile / channel counts, borders,
-    the decoder's real layer shapes.  Tolerance 1e-5 of the tensor scale (the transforms add a few roundings to the
-    direct path's 2e-6)."""
+@pytest.mark.parametrize("waves", [8, 4])
+def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu, waves):
+    """The Winograd F(2x2,3x3) kernels (3x3, stride 1, SAME, even maps) -- the two-waves-per-SIMD one the library
+    uses and the one-wave-per-SIMD one it keeps: ragged tile / channel counts, borders, the decoder's real layer
+    shapes.  Tolerance 1e-5 of the tensor scale (the transforms add a few roundings to the direct path's 2e-6)."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
@@ -213,11 +214,13 @@ def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu):
     w_ok, _ = W.fold_conv(w)
     lib = _lib.lib()
     lib.mpsr_debug_set_conv_winograd(1)
+    lib.mpsr_debug_set_wino_waves(waves)
     try:
         got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, 1, relu, split_k=0)
     finally:
         lib.mpsr_debug_set_conv_winograd(-1)
-    _close(got, ref, 1e-5, "winograd %s" % ((B, H, Wd, C, N),))
+        lib.mpsr_debug_set_wino_waves(8)
+    _close(got, ref, 1e-5, "winograd %s, %d waves" % ((B, H, Wd, C, N), waves))
     lib.mpsr_debug_set_conv_winograd(0)
     try:
         direct = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, 1, relu, split_k=0)
