@@ -87,6 +87,45 @@ def test_conv_layer_gradients(case):
         _close(rt.grad, rr.grad, 1e-6, "dresidual")
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_conv_layer_gradients_random(chunk):
+    """Seeded random sweep of the layer backward (weight gradient kernel with its per-tap valid rectangles and LDS row
+    table, bias gradient, data gradient through the scheduled forward kernels) on small ragged shapes."""
+    from monopsr_amd.core import autograd_ops as ops
+    rng = np.random.default_rng(4000 + chunk)
+    for case in range(12):
+        k = int(rng.choice([1, 3]))
+        dil = int(rng.choice([1, 2, 4])) if k == 3 else 1
+        B, H, Wd = int(rng.integers(1, 6)), int(rng.integers(1, 14)), int(rng.integers(1, 14))
+        C, N = int(rng.choice([4, 16, 32, 36, 64, 132])), int(rng.choice([3, 4, 20, 32, 64, 130]))
+        has_b, has_res, relu = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+        w = (rng.standard_normal((N, k * k * C)) / np.sqrt(k * k * C)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32) if has_b else None
+        res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+        up = rng.standard_normal((B, H, Wd, N)).astype(np.float32)
+        xr = torch.from_numpy(x).double().requires_grad_(True)
+        wr = torch.from_numpy(w).double().requires_grad_(True)
+        br = torch.from_numpy(b).double().requires_grad_(True) if has_b else None
+        rr = torch.from_numpy(res).double().requires_grad_(True) if has_res else None
+        yr = _ref_conv(xr, wr, br, rr, k, k, dil, relu)
+        (yr * torch.from_numpy(up).double()).sum().backward()
+        wt, dwt = _dev(w), torch.zeros((N, k * k * C), device="cuda")
+        bt, dbt = (_dev(b), torch.zeros((N,), device="cuda")) if has_b else (None, None)
+        layer = ops.LayerRef(wt, bt, dwt, dbt, C, N, k, k, dil, relu)
+        xt = _dev(x).requires_grad_(True)
+        rt = _dev(res).requires_grad_(True) if has_res else None
+        y = ops.conv2d(xt, layer, rt)
+        tag = "chunk %d case %d: B%d H%d W%d C%d N%d k%d d%d b%d res%d relu%d" % (chunk, case, B, H, Wd, C, N, k, dil,
+                                                                           has_b, has_res, relu)
+        _close(y, yr, 5e-6, tag + " forward")
+        (y * _dev(up)).sum().backward()
+        _close(xt.grad, xr.grad, 2e-5, tag + " dx")
+        _close(dwt, wr.grad, 1e-4, tag + " dw")
+        if has_b:
+            _close(dbt, br.grad, 1e-4, tag + " db")
+
+
 @pytest.mark.parametrize("shape,k,s,pad", [((2, 24, 24, 16), 3, 2, "SAME"), ((2, 12, 12, 8), 2, 2, "VALID"),
                                            ((1, 7, 9, 4), 3, 2, "SAME")])
 def test_max_pool_gradient(shape, k, s, pad):
