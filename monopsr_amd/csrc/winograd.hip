@@ -464,6 +464,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < 4; ++s) {
             const int r0 = 2 * (s >> 1), kq = s & 1;
             const int q0 = 8 * g + r0;  // LDS position of the pair, relative to the wave's half
+            // (measured: reading the next pair step's fragments ahead, or letting hipcc move these reads, both cost 4 %:
+            // the other wave of the SIMD covers the latency, extra live registers and reordered waits do not pay)
             __builtin_amdgcn_sched_barrier(0);
             float4 a0 = *reinterpret_cast<const float4 *>(Aw + q0 * MT * ROW + kq * 8);
             float4 b0 = *reinterpret_cast<const float4 *>(Bw + q0 * NT * ROW + kq * 8);
@@ -508,34 +510,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     // Rotated loop as in the four-wave kernel.  Filler plans (32 slots per half):
     //   second half of step k (multiplies g1(k)):        first half of step k+1 (multiplies g0(k+1)):
-    //     0-3   request this thread's filter rows of g0     0-3   request this thread's filter rows of g1(k+1)
-    //     4-7   row transform of patch(k+1)                 6-13  store A rows of g1(k+1)
-    //     8-15  store A rows of g0(k+1)                     20-23 store filter rows of g1(k+1)
-    //     16-19 store filter rows of g0(k+1)
-    //     20-31 request patch(k+2) (vmcnt retires in order: the filter rows' stores must not sit behind these)
+    //     4-7   row transform of patch(k+1)                 0-3   request this thread's filter rows of g1(k+1)
+    //     8-15  store A rows of g0(k+1)                     6-13  store A rows of g1(k+1)
+    //     16-19 store filter rows of g0(k+1)                14-19 request patch(k+2), pixels 8-13
+    //     20-27 request patch(k+2), pixels 0-7              20-23 store filter rows of g1(k+1)
+    //                                                       24-25 request patch(k+2), pixels 14-15
+    //                                                       26-29 request filter rows of g0(k+2)
+    // (measured: spreading the requests over both halves is worth 4 % of the kernel; vmcnt retires in order, so a
+    // store is never placed behind younger requests than the ones it needs)
     const int nsteps = p.cblocks;
 #pragma unroll
     for (int i = 0; i < 16; ++i) load_a1(1, nsteps > 1, i);
-    compute(G0{}, [](int) {});
+    compute(G0{}, [&](int slot) {
+        if (slot >= 26 && slot < 30) load_b1(1, slot - 26, slot - 26);  // g0's filter rows of step 1 (zeros past the end)
+    });
     __syncthreads();
     for (int k = 0; k + 1 < nsteps; ++k) {
         const bool more2 = k + 2 < nsteps;
         compute(G1{}, [&](int slot) {
-            if (slot < 4) load_b1(k + 1, slot, slot);
-            else if (slot < 8) row_transform_col(slot - 4);
-            else if (slot < 16) store_a(slot - 8);
-            else if (slot < 20) store_b(slot - 16, slot - 16);
-            else if (slot < 28) load_a1(k + 2, more2, slot - 20);
-            else {
-                load_a1(k + 2, more2, 8 + 2 * (slot - 28));
-                load_a1(k + 2, more2, 9 + 2 * (slot - 28));
-            }
+            if (slot >= 4 && slot < 8) row_transform_col(slot - 4);
+            else if (slot >= 8 && slot < 16) store_a(slot - 8);
+            else if (slot >= 16 && slot < 20) store_b(slot - 16, slot - 16);
+            else if (slot >= 20 && slot < 28) load_a1(k + 2, more2, slot - 20);  // pixels 0-7
         });
         __syncthreads();
         compute(G0{}, [&](int slot) {
             if (slot < 4) load_b1(k + 1, 8 + slot, slot);
             else if (slot >= 6 && slot < 14) store_a(8 + slot - 6);
+            else if (slot >= 14 && slot < 20) load_a1(k + 2, more2, 8 + slot - 14);  // pixels 8-13
             else if (slot >= 20 && slot < 24) store_b(8 + slot - 20, slot - 20);
+            else if (slot >= 24 && slot < 26) load_a1(k + 2, more2, 14 + slot - 24);  // pixels 14-15
+            else if (slot >= 26 && slot < 30) load_b1(k + 2, slot - 26, slot - 26);  // g0's rows of the step after
         });
         __syncthreads();
     }
