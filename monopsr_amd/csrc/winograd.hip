@@ -391,8 +391,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wq = __builtin_amdgcn_readfirstlane(wave & 3), ph = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int wm = wq >> 1, wn = wq & 1;
     const int slot_id = tid & 255;            // loader slot (tile or filter row, channel quad); ph doubles as its half
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, (int)p.ubytes, 0x00020000);
 
@@ -421,28 +419,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     f32x2 pa[16];
     float4 pb[4];
+    // (a request past the last channel block goes through a zero-length descriptor: a scalar select, where a select
+    // on the offset would be one vector instruction per request)
     auto load_a1 = [&](int cb, bool live, int i) {
-        pa[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, live ? aoff[i] : p.xbytes,
-                                                                               live ? (unsigned)cb * KC * 4u : 0u, 0));
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, live ? (int)p.xbytes : 0, 0x00020000);
+        pa[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, aoff[i], live ? (unsigned)cb * KC * 4u : 0u, 0));
     };
     auto load_b1 = [&](int cb, int pos, int slot) {
         pb[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   ru, boff, ((unsigned)cb * 16u + (unsigned)pos) * bstride, 0));
     };
+    // (the packed adds are spelled out: hipcc scalarises about half of them otherwise, and with two waves per SIMD a
+    // vector instruction is matrix-pipe time)
+    auto padd = [](f32x2 a, f32x2 b) {
+        f32x2 r;
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
+    auto psub = [](f32x2 a, f32x2 b) {
+        f32x2 r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
     f32x2 t[4][4];
     auto row_transform_col = [&](int c) {
         const f32x2 d0 = pa[c], d1 = pa[4 + c], d2 = pa[8 + c], d3 = pa[12 + c];
-        t[0][c] = d0 - d2;
-        t[1][c] = d1 + d2;
-        t[2][c] = d2 - d1;
-        t[3][c] = d1 - d3;
+        t[0][c] = psub(d0, d2);
+        t[1][c] = padd(d1, d2);
+        t[2][c] = psub(d2, d1);
+        t[3][c] = psub(d1, d3);
     };
     float *arow = As + ltile * ROW + 4 * quad + 2 * ph;
     float *brow = Bs + (slot_id >> 2) * ROW + 4 * (slot_id & 3) + 4 * ph * NT * ROW;  // + this thread's position half
     auto store_a = [&](int pos) {
         const int xi = pos >> 2, nu = pos & 3;
-        const f32x2 v = nu == 0 ? t[xi][0] - t[xi][2] : nu == 1 ? t[xi][1] + t[xi][2]
-                        : nu == 2 ? t[xi][2] - t[xi][1] : t[xi][1] - t[xi][3];
+        const f32x2 v = nu == 0 ? psub(t[xi][0], t[xi][2]) : nu == 1 ? padd(t[xi][1], t[xi][2])
+                        : nu == 2 ? psub(t[xi][2], t[xi][1]) : psub(t[xi][1], t[xi][3]);
         *reinterpret_cast<f32x2 *>(arow + pos * MT * ROW) = v;
     };
     auto store_b = [&](int pos, int slot) { *reinterpret_cast<float4 *>(brow + pos * NT * ROW) = pb[slot]; };
