@@ -19,6 +19,7 @@ H, W, C, N = [int(v) for v in args.shape.split(",")]
 B = args.batch
 lib = _lib.lib()
 lib.mpsr_debug_set_conv_winograd(1)
+lib.mpsr_debug_set_wino_waves(4)  # the stamps are in the four-wave kernel
 x = torch.randn((B, H, W, C), device="cuda")
 w = torch.randn((N, 9 * C), device="cuda") * 0.05
 y = torch.empty((B, H, W, N), device="cuda")
