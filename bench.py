@@ -542,6 +542,10 @@ def main():
             result["roofline"]["executed_flops_per_launch"] = round(executed / launches)
             result["roofline"]["launch_kinds"] = {"implicit_gemm": kinds[0], "winograd_f2x2_3x3": kinds[1],
                                                   "direct_narrow": kinds[2]}
+            result["roofline"]["note"] = ("achieved / frac count the ALGORITHMIC direct-convolution FLOPs (SURVEY 8(d)), "
+                                          "so they can exceed the peak: the 4 Winograd launches issue 16/36 of theirs and "
+                                          "the atrous layers skip out-of-image taps; executed / executed_frac and "
+                                          "mfma_busy (PMC) are the utilisation of the matrix pipes")
             if traffic:
                 result["roofline"]["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
                 result["roofline"]["mfma_busy"] = busy
