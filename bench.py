@@ -48,23 +48,52 @@ def _launch_ranks(argv):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = str(s.getsockname()[1])
+    import signal
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    codes = []
-    try:
+
+    def stop_all(sig=signal.SIGTERM, grace=10.0):
         for p in procs:
-            codes.append(p.wait())
-    finally:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+        t_end = time.monotonic() + grace
         for p in procs:
-            if p.poll() is None:  # a rank died: do not leave its peers waiting in a collective
-                p.terminate()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad or len(codes) != n:
-        raise SystemExit("bench.py: rank(s) failed (rank, exit code): %s" % bad)
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()  # the exact children started above, never a pattern
+                p.wait()
+
+    got_signal = []
+
+    def on_signal(signum, frame):  # a SIGTERM / SIGINT to the launcher goes to the ranks: none is left behind
+        got_signal.append(signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+    # poll ALL ranks: the first one that exits non-zero (or a signal to this process) ends the others, which would
+    # otherwise sit in the rendezvous or in an RCCL collective until its timeout
+    codes = [None] * n
+    bad = []
+    while any(c is None for c in codes) and not bad and not got_signal:
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0):
+                    bad.append((r, codes[r]))
+        if any(c is None for c in codes) and not bad:
+            time.sleep(0.05)
+    if bad or got_signal:
+        stop_all()
+        if got_signal:
+            raise SystemExit("bench.py: launcher received signal %d; ranks stopped" % got_signal[0])
+        raise SystemExit("bench.py: rank(s) failed (rank, exit code): %s; the other ranks were stopped" % bad)
     raise SystemExit(0)
 
 
@@ -167,15 +196,19 @@ def conv_replay(net, B):
     dev = net.device
     jobs = []
 
-    def add(part, idx, M_hw, alg_cin=None):
+    def add(part, idx, M_hw, alg_cin=None, raw=False):
         r = part.records[idx]
         Bq, H, W = M_hw
+        # inputs with the statistics of the step's own activations: every layer but the root reads the output of a
+        # ReLU (half zeros) -- a dense N(0,1) operand draws more power and ran the replay ~2 % slower than in situ
         x = torch.empty((Bq * H * W * r["cin"],), dtype=torch.float32, device=dev).normal_()
+        if not raw:
+            x.clamp_(min=0)
         y = torch.empty((Bq * H * W * r["cout"],), dtype=torch.float32, device=dev)
         jobs.append((x, y, part.blob, r, Bq, H, W, alg_cin or r["cin"]))  # alg_cin: K without zero padding
 
     tr = net.crop_trunk
-    add(tr, 0, (B * 576, 1, 1), 147)
+    add(tr, 0, (B * 576, 1, 1), 147, raw=True)
     for k in range(1, tr.n):
         add(tr, k, (B, 12, 12))
     dec = net.decoder
@@ -201,13 +234,13 @@ def conv_replay(net, B):
     # multiply-add FLOPs the library's kernels really issue for these launches: the Winograd kernel (decoder 3x3
     # layers) 16/36 of the direct count, the atrous layers only their in-image taps
     import ctypes
-    executed, kinds = 0.0, {0: 0, 1: 0, 2: 0}
+    executed, kinds = 0.0, {}
     for _, _, _, r, Bq, H, W, _ in jobs:
         kind, ex = ctypes.c_int(0), ctypes.c_double(0.0)
         _lib.check(lib.mpsr_conv2d_plan(Bq, H, W, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"],
                                         ctypes.byref(kind), ctypes.byref(ex)))
         executed += ex.value
-        kinds[kind.value] += 1
+        kinds[kind.value] = kinds.get(kind.value, 0) + 1
     # algorithmic HBM bytes of a launch: its input, weights and output once each
     alg_bytes = sum(4.0 * (Bq * H * W * (r["cin"] + r["cout"]) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
                     for _, _, _, r, Bq, H, W, _ in jobs)
@@ -236,6 +269,77 @@ def mfma_box_peak(device):
     e1.record()
     torch.cuda.synchronize()
     return cus * 4 * waves * iters * 16 * 4096.0 * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def roofline_object(net, args, device, ms_per_step):
+    """The dominant kernel family alone: every conv/FC launch of one step, timed with events on the launch stream.
+    `achieved` / `frac` are what the matrix pipes EXECUTE (mpsr_conv2d_plan: the Winograd launches issue 16/36 -- or
+    36/144 for F(4x4,3x3) -- of their direct-convolution products and the atrous layers skip out-of-image taps), so
+    0 < frac <= 1 and it is comparable with the PMC's MFMA-busy fraction; the ALGORITHMIC direct-convolution rate of
+    SURVEY 8(d) (12.393 GFLOP per crop) is next to it as algorithmic_achieved / algorithmic_frac and may exceed 1."""
+    run, launches, flops, alg_bytes, executed, kinds = conv_replay(net, args.batch)
+    run()
+    torch.cuda.synchronize()
+    reps = max(3, min(10, args.steps))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    pass_s = e0.elapsed_time(e1) * 1e-3 / reps
+    avg_s = pass_s / launches
+    # HBM traffic and MFMA-busy cycles cannot be counted from inside the process: they come from the newest
+    # committed rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/
+    # rNN_pmc_traffic.json), quoted with the round and commit they were collected at
+    traffic = busy = src = None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            traffic = round(pm["hbm_bytes_per_launch"])
+            busy = pm.get("mfma_busy")
+            src = {"file": os.path.relpath(path, ROOT), "round": pm.get("round"), "commit": pm.get("commit"),
+                   "collected": pm.get("collected")}
+            break
+        except Exception:
+            pass
+    fp32 = args.math == "fp32"
+    peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
+    kname = "conv_igemm_kernel + wino conv kernels (fp32 MFMA 32x32x2: implicit GEMM; Winograd for the decoder's 3x3 " \
+            "layers)" if fp32 else \
+        "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
+    alg = flops / launches / avg_s / 1e12
+    exe = executed / launches / avg_s / 1e12 if fp32 else alg
+    out = {"bound": "mfma", "kernel": kname, "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(exe / peak, 4), "traffic": traffic if fp32 else None,
+           "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
+           "flops_per_launch": round((executed if fp32 else flops) / launches),
+           "algorithmic_flops_per_launch": round(flops / launches),
+           "algorithmic_achieved": round(alg, 2), "algorithmic_frac": round(alg / peak, 4),
+           "algorithmic_bytes": round(alg_bytes / launches),
+           "kernel_ms_per_step": round(pass_s * 1e3, 3),
+           "kernel_ms_per_step_le_ms_per_step": bool(pass_s * 1e3 <= ms_per_step),
+           "replay": "the step's conv/FC launches back to back on post-ReLU-like operands (relu(N(0,1)); the root "
+                     "conv on N(0,1)) -- the step's own activations live in ping-pong scratch and cannot be replayed"}
+    if fp32:
+        out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
+                               "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0)}
+        out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
+                       "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
+                       "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction from the quoted collection")
+        if traffic:
+            out["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
+            out["mfma_busy"] = busy
+            out["traffic_source"] = src
+        try:
+            box = mfma_box_peak(device)
+            out["peak_measured_on_this_board"] = round(box, 1)
+            out["frac_of_measured"] = round(exe / box, 4)
+        except Exception as e:
+            out["peak_measured_on_this_board"] = repr(e)
+    return out
 
 
 def emd_object(device, b=256, n=2048):
@@ -275,19 +379,39 @@ def emd_object(device, b=256, n=2048):
             "bound": "v_exp_f32 issue (passes), HBM (materialised match)"}
 
 
-def cpu_baseline(weights, host, sample, npts):
-    """The CPU restatement (oracle/net.py on torch CPU, all host cores) + the C Chamfer oracle (1 thread) on the
-    first `sample` instances of the same workload.  Reported baseline only."""
+def _timed_threads(fn, parts, workers):
+    """Run fn(part) for every part on `workers` host threads (the C oracle is called through ctypes, which releases
+    the GIL: the threads are as independent as the processes SURVEY 8(d) describes); -> wall seconds."""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    if workers <= 1:
+        for p in parts:
+            fn(p)
+    else:
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(fn, parts))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(weights, host, sample, npts, budget_s=18.0):
+    """The CPU side of SURVEY 8(d), all `kind: port` (the oracle restatements; /root/reference does not exist on the
+    GPU box and TensorFlow 1.8 runs nowhere): `conv` = oracle/net.py on torch CPU with all host threads; `chamfer_1core`
+    / `chamfer_nproc` = the C restatement of the reference's single-threaded CPU kernel on one core and as one
+    independent worker per core; `emd_cfg5_subset` = the C restatement of approxmatch_cpu + matchcost + gradient on a
+    few 2048-point clouds.  The top-level value blends conv (all threads) + Chamfer (1 thread) over the same instances
+    as before.  Bounded: about `budget_s` seconds in all.  Reported baseline only."""
     from oracle import net as onet
     from oracle import ops as orc
-    if sample <= 0:  # size the sample for roughly 15 s of CPU work from a warm 8-instance probe of the trunk
-        sc = "FirstStageFeatureExtractor_crop/resnet_v1_101"
+    ncores = os.cpu_count() or 1
+    sc = "FirstStageFeatureExtractor_crop/resnet_v1_101"
+    B = host["crops"].shape[0]
+    if sample <= 0:  # size the conv sample for roughly half the budget from a warm probe of the trunk
         with torch.no_grad():
             onet.resnet101_block3(torch.from_numpy(host["crops"][:2]), weights, sc)  # warm-up (thread pool, oneDNN)
             t0 = time.perf_counter()
             onet.resnet101_block3(torch.from_numpy(host["crops"][:8]), weights, sc)
         per = (time.perf_counter() - t0) / 8 * 1.6  # trunk is ~64 % of the per-crop work
-        sample = int(max(8, min(host["crops"].shape[0], 15.0 / per)))
+        sample = int(max(8, min(B, 0.5 * budget_s / per)))
     s = slice(0, sample)
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -295,42 +419,276 @@ def cpu_baseline(weights, host, sample, npts):
                                  np.ones((sample, 1), np.int32), np.tile(np.array([[3.88, 1.63, 1.53]], np.float32),
                                                                          (sample, 1)),
                                  np.full((sample,), 2.17799973487854, np.float32), weights)
+    t_conv = time.perf_counter() - t0
     pred = ref["inst_xyz_map_local"].reshape(sample, -1, 3)[:, :npts].contiguous().numpy()
+    t0 = time.perf_counter()
     d1, i1, d2, i2 = orc.nn_distance(pred, host["gt"][s])
     orc.nn_distance_grad(pred, host["gt"][s], np.ones_like(d1), i1, np.ones_like(d2), i2)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "first %d instances of the same workload: oracle/net.py (PyTorch-CPU fp32 restatement of the "
-                      "TF1 graph, %d threads) + oracle C Chamfer fwd/bwd (1 thread), %.1f s" %
-                      (sample, torch.get_num_threads(), dt)}, ref
+    t_ch = time.perf_counter() - t0
+    dt = t_conv + t_ch
+    out = {"value": round(sample / dt, 3), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "first %d instances of the same workload: oracle/net.py (PyTorch-CPU fp32 restatement of the "
+                     "TF1 graph, %d threads) + oracle C Chamfer fwd/bwd (1 thread), %.1f s" %
+                     (sample, torch.get_num_threads(), dt),
+           "host_cores": ncores,
+           "conv": {"value": round(sample / t_conv, 3), "unit": "crops/s", "cores": torch.get_num_threads(),
+                    "kind": "port", "sample": "%d instances, trunk + squash + decoder + heads, %.1f s"
+                                              % (sample, t_conv)}}
+
+    # Chamfer fwd + bwd of the whole batch: the reference's CPU kernel is single-threaded by construction
+    def chamfer(sl):
+        a, b = host["gt"][sl], host["gt2"][sl]
+        e1, j1, e2, j2 = orc.nn_distance(a, b)
+        orc.nn_distance_grad(a, b, np.ones_like(e1), j1, np.ones_like(e2), j2)
+    host = dict(host, gt2=np.random.default_rng(4).standard_normal(host["gt"].shape, dtype=np.float32))
+    t1 = _timed_threads(chamfer, [slice(0, B)], 1)
+    out["chamfer_1core"] = {"value": round(B / t1, 2), "unit": "clouds/s", "cores": 1, "kind": "port",
+                            "sample": "%d cloud pairs of %d points, fwd + bwd, %.2f s" % (B, npts, t1)}
+    w = min(ncores, B)
+    parts = [slice(i * B // w, (i + 1) * B // w) for i in range(w)]
+    tn = _timed_threads(chamfer, parts, w)
+    out["chamfer_nproc"] = {"value": round(B / tn, 2), "unit": "clouds/s", "cores": w, "kind": "port",
+                            "sample": "the same %d pairs as %d independent single-threaded workers, %.2f s"
+                                      % (B, w, tn)}
+    # EMD at BASELINE cfg5's cloud size (2048 points, U(-1,1)): CPU semantics (11 levels, double state)
+    n5 = 2048
+    r6, r7 = np.random.default_rng(6), np.random.default_rng(7)
+    k1 = 2
+    k = max(k1, min(ncores, 64))
+    c1 = (r6.random((k, n5, 3), dtype=np.float32) * 2 - 1)
+    c2 = (r7.random((k, n5, 3), dtype=np.float32) * 2 - 1)
+
+    def emd(sl):
+        mt = orc.approx_match(c1[sl], c2[sl], semantics="cpu")
+        orc.match_cost(c1[sl], c2[sl], mt, semantics="cpu")
+        orc.match_cost_grad(c1[sl], c2[sl], mt, semantics="cpu")
+    te1 = _timed_threads(emd, [slice(0, k1)], 1)
+    ten = _timed_threads(emd, [slice(i, i + 1) for i in range(k)], k)
+    out["emd_cfg5_subset"] = {
+        "value": round(k / ten, 3), "unit": "clouds/s", "cores": k, "kind": "port",
+        "one_core_clouds_per_s": round(k1 / te1, 3),
+        "sample": "%d-cloud subset of cfg5's 256 x 2048^2 per-GPU share (approx_match + match_cost + grad, the "
+                  "reference CPU kernel's semantics), one cloud per worker on %d workers: %.2f s; 1 core on %d clouds: "
+                  "%.2f s; the full 256-cloud share would take %.0f s at the all-core rate" %
+                  (k, k, ten, k1, te1, 256 * ten / k)}
+    return out, ref
 
 
-def training_step_object(device, batch, inp, steps=3, warmup=2):
-    """ms per training step of `batch` instances on this GPU (crop trunk + decoder + heads trainable, 72.8 M
-    parameters in one flat buffer)."""
-    from monopsr_amd.core import config_utils, train_net, trainer
-    from monopsr_amd.core import weights as W
-    cfg = config_utils.default_config()
-    net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
-    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0)
-    sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
-                  cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"], mean_lwh=inp["mean_lwh"],
-                  prop_cen_z_offset=inp["z_off"])
-    sample.update(trainer.synthetic_ground_truth(sample, seed=7))
+def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_dev=None, make_trainer=None):
+    """ms per training step of `batch` instances per rank (crop trunk + decoder + heads trainable, 72.8 M parameters
+    in one flat buffer).  With a process group (N > 1) every rank trains its own shard and the flat 291 MB gradient
+    goes through core/trainer.ReverseBucketReducer (64 MiB buckets launched from the end of the buffer as backward
+    reports layers ready, averaged, THEN per-variable clip as the reference does: core/trainer.py:76-81); the step is
+    timed with and without the reduce (MAX over ranks), the difference being the exposed, non-overlapped part."""
+    world = dist.get_world_size() if dist is not None else 1
+    if make_trainer is None:
+        from monopsr_amd.core import config_utils, train_net, trainer
+        from monopsr_amd.core import weights as W
+        cfg = config_utils.default_config()
+        net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
+        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0)
+        sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
+                      cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"],
+                      mean_lwh=inp["mean_lwh"], prop_cen_z_offset=inp["z_off"])
+        sample.update(trainer.synthetic_ground_truth(sample, seed=7))
+    else:
+        tr, sample = make_trainer()
+        net = tr.net
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+
+    def timed(k):
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        vals = [tr.step(sample) for _ in range(k)]  # device scalars: no host sync inside the timed region
+        sync()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / k, [float(v) for v in vals]
+
+    out = {"params": int(net.params.numel()), "grad_bytes": int(net.grads.numel() * 4), "steps": steps,
+           "ranks": world,
+           "what": "fwd + configured losses (incl. global-map projection) + bwd + clip + Adam + EMA, fp32; decoder "
+                   "BN: per-rank batch statistics (no cross-rank statistics exchange)"}
     losses = [float(tr.step(sample)) for _ in range(warmup)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    timed = [tr.step(sample) for _ in range(steps)]  # device scalars: no host sync inside the timed region
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    losses += [float(v) for v in timed]
-    return {"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch / dt, 1), "steps": steps,
-            "params": int(net.params.numel()), "grad_bytes": int(net.grads.numel() * 4),
-            "what": "fwd + configured losses (incl. global-map projection) + bwd + clip + Adam + EMA, fp32, "
-                    "decoder BatchNorm on batch statistics; single rank (no all-reduce)",
-            "loss_per_step": [round(v, 1) for v in losses],
-            "note": "random-initialised weights and synthetic targets: the first Adam steps are a transient (the same "
-                    "run reaches 40 % of the initial loss after 10 steps, tools/train_bench.py)"}
+    if world > 1:
+        tr.reducer.enabled = False
+        dt_local, _ = timed(steps)
+        tr.reducer.enabled = True
+        timed(1)  # first reduced step outside the timed region (communicator warm-up)
+        dt, vals = timed(steps)
+        losses += vals
+        out.update({"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch * world / dt, 1),
+                    "ms_per_step_without_allreduce": round(dt_local * 1e3, 2),
+                    "exposed_allreduce_ms": round((dt - dt_local) * 1e3, 2),
+                    "allreduce": "ReverseBucketReducer: %d buckets of <= %d MiB, async, launched as backward reports "
+                                 "layers ready; average, then per-variable clip_by_norm, then Adam" %
+                                 (len(tr.reducer.buckets), tr.reducer.bucket_bytes >> 20),
+                    "gradients": "real (this step's backward), %d floats" % net.grads.numel()})
+        # the same buffer all-reduced alone: what the wire costs when nothing overlaps it
+        try:
+            dist.all_reduce(net.grads)
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dist.all_reduce(net.grads)
+            sync()
+            ta = (time.perf_counter() - t0) / 3
+            t = torch.tensor([ta], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ta = float(t.item())
+            nb = net.grads.numel() * 4
+            out["allreduce_alone_ms"] = round(ta * 1e3, 3)
+            out["allreduce_alone_busbw_GBps"] = round(nb / ta * 2 * (world - 1) / world / 1e9, 1)
+        except Exception as e:
+            out["allreduce_alone_ms"] = repr(e)
+    else:
+        dt, vals = timed(steps)
+        losses += vals
+        out.update({"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch / dt, 1)})
+    out["loss_per_step"] = [round(v, 1) for v in losses]
+    out["note"] = "random-initialised weights and synthetic targets: the first Adam steps are a transient"
+    return out
+
+
+def rank_proof(dist, rank, world, backend, red_dev):
+    """Evidence that N ranks on N distinct devices took part: an all-reduce of ones, every rank's device, and the
+    collective library's version."""
+    ones = torch.ones((1,), dtype=torch.float32, device=red_dev)
+    dist.all_reduce(ones)
+    cuda = torch.cuda.is_available()
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+          "device": torch.cuda.current_device() if cuda else None}
+    if cuda:
+        pr = torch.cuda.get_device_properties(me["device"])
+        me["name"] = pr.name
+        for k in ("uuid", "pci_bus_id", "pci_device_id"):
+            if hasattr(pr, k):
+                me[k] = str(getattr(pr, k))
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    ids = {(r.get("uuid") or r.get("pci_bus_id"), r["device"]) for r in ranks}
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            ver = repr(e)
+    return {"allreduce_of_ones": float(ones.item()), "world_size": world,
+            "backend": "nccl (RCCL)" if backend == "nccl" else backend, "rccl_version": ver,
+            "distinct_devices": len(ids), "ranks": ranks}
+
+
+def gather_rank_objects(dist, world, fn):
+    """Every rank runs fn() (errors become {"error": ...} so that no rank skips the collective) -> list by rank."""
+    try:
+        mine = fn()
+    except Exception as e:
+        mine = {"error": repr(e)}
+    objs = [None] * world
+    dist.all_gather_object(objs, mine)
+    return objs
+
+
+class Emitter:
+    """Rank 0 prints exactly ONE JSON line.  Once the headline exists a watchdog is armed: if the side measurements
+    that follow (extra objects, collectives with the other ranks) have not finished by the deadline, the watchdog
+    prints the line as it stands and ends the process -- a hang in an extra never costs the headline."""
+
+    def __init__(self, rank, deadline_s):
+        import threading
+        self.rank, self.lock, self.done, self.result = rank, threading.Lock(), False, None
+        self.timer = threading.Timer(deadline_s, self._expired)
+        self.timer.daemon = True
+        self.deadline_s = deadline_s
+
+    def arm(self, result):
+        self.result = result
+        self.timer.start()
+
+    def _expired(self):
+        with self.lock:
+            if not self.done and self.rank == 0 and self.result is not None:
+                for _ in range(5):
+                    try:
+                        line = json.dumps(dict(self.result, extras_timed_out_after_s=self.deadline_s))
+                        break
+                    except RuntimeError:  # the main thread was adding a key
+                        time.sleep(0.01)
+                print(line, flush=True)
+                self.done = True
+        os._exit(0 if self.rank == 0 else 3)
+
+    def emit(self, result):
+        with self.lock:
+            if not self.done and self.rank == 0:
+                print(json.dumps(result), flush=True)
+            self.done = True
+        self.timer.cancel()
+
+
+def rendezvous_only(rank, world):
+    """Test hook (tests/test_bench_launch.py): the whole N-rank plumbing of this file on CPU over gloo -- launch,
+    rendezvous, max-over-ranks timing, rank proof, per-rank gathers, the reducer-driven training-step object and the
+    all-rank EMD object -- with stand-in workloads where the hot path would run (it has no CPU form)."""
+    import torch.distributed as dist
+    from monopsr_amd.core.trainer import ReverseBucketReducer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    em = Emitter(rank, 300.0)
+    seen = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+    result = {"rendezvous_only": True, "n_gpus": world, "max_rank_plus_1": float(seen.item())}
+    em.arm(result)
+    result["rank_proof"] = rank_proof(dist, rank, world, "gloo", cpu)
+    result["per_rank_ms"] = [o["ms"] for o in gather_rank_objects(dist, world, lambda: {"ms": 1.0 + rank})]
+
+    class FakeNet:
+        params = torch.zeros(4096)
+        grads = torch.zeros(4096)
+
+    class FakeTrainer:  # four "layers" whose backward fills its slice of the flat gradient, last layer first
+        def __init__(self):
+            self.net = FakeNet()
+            self.spans = [(0, 1024), (1024, 2048), (2048, 3072), (3072, 4096)]
+            self.reducer = ReverseBucketReducer(self.net.grads, self.spans, bucket_bytes=4096)
+
+        def step(self, sample):
+            for li in (3, 2, 1, 0):
+                lo, hi = self.spans[li]
+                self.net.grads[lo:hi] = float(rank + 1)
+                self.reducer.layer_ready(li)
+            self.reducer.finish(average=True)
+            return self.net.grads.mean()
+    result["training_step"] = training_step_object(cpu, 4, None, steps=2, warmup=1, dist=dist, red_dev=cpu,
+                                                   make_trainer=lambda: (FakeTrainer(), None))
+    result["emd"] = emd_all_ranks(dist, world, lambda: {"fused_loss_ms": 1.0, "fused_clouds_per_s": 10.0 * (rank + 1)})
+    em.emit(result)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def emd_all_ranks(dist, world, fn):
+    """BASELINE cfg5 across ranks: every rank runs its 256-cloud share concurrently (no exchange: clouds are
+    independent); rank 0's object + the sum over ranks."""
+    dist.barrier()
+    objs = gather_rank_objects(dist, world, fn)
+    out = dict(objs[0])
+    ok = [o for o in objs if "fused_clouds_per_s" in o]
+    out["all_ranks"] = {"ranks_ok": len(ok), "fused_clouds_per_s_sum": round(sum(o["fused_clouds_per_s"] for o in ok), 1),
+                        "per_rank_fused_loss_ms": [o.get("fused_loss_ms") for o in objs],
+                        "errors": [o["error"] for o in objs if "error" in o],
+                        "note": "each rank timed its own share while the others ran theirs; no collective on the "
+                                "data path"}
+    return out
 
 
 def main():
@@ -341,12 +699,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="instances per GPU")
     ap.add_argument("--points", type=int, default=1024, help="points per cloud for Chamfer")
     ap.add_argument("--cpu-sample", type=int, default=-1,
-                    help="instances timed on the host CPU (0 = skip, -1 = size for ~15 s of CPU work)")
+                    help="instances timed on the host CPU (0 = skip, -1 = size for ~9 s of conv work)")
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="also all-reduce a 100,204,832-float buffer per step (size of the model's gradient)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-emd", action="store_true", help="skip the extra EMD (BASELINE config 5) object")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training_step object")
+    ap.add_argument("--train-batch", type=int, default=0, help="instances per rank of the training_step object "
+                                                               "(0 = --batch)")
     ap.add_argument("--streams", type=int, default=1,
                     help="split each GPU's batch into this many instance shards on separate HIP streams")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
@@ -356,6 +716,9 @@ def main():
                     help="N > 1: skip the extra region that repeats the step with the gradient-sized all-reduce")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3_mode measurement appended to a default fp32 run")
+    ap.add_argument("--extras-deadline", type=float, default=900.0,
+                    help="seconds after the headline is measured before the watchdog prints it without the "
+                         "unfinished extra objects")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -364,20 +727,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MPSR_BENCH_TEST_FAIL_RANK") == str(rank):  # test hooks of tests/test_bench_launch.py
+        raise SystemExit(7)
+    if os.environ.get("MPSR_BENCH_TEST_HANG"):
+        time.sleep(600)
     if os.environ.get("MPSR_BENCH_RENDEZVOUS_ONLY"):
-        # test hook (tests/test_bench_launch.py): the launch + rendezvous + max-over-ranks plumbing of an N-rank run
-        # on CPU (gloo), without the hot path
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        seen = torch.tensor([1.0 + rank], dtype=torch.float64)
-        dist.barrier()
-        dist.all_reduce(seen, op=dist.ReduceOp.MAX)
-        if rank == 0:
-            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "max_rank_plus_1": float(seen.item())}),
-                  flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
-        return
+        return rendezvous_only(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # MPSR_BENCH_SHARE_GPU: test hook for 1-GPU boxes -- every rank computes on cuda:0 and the ranks meet over gloo
@@ -400,6 +755,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world
     red_dev = device if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
+    multi = dist is not None and world > 1
+    emitter = Emitter(rank, args.extras_deadline)
 
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
@@ -429,6 +786,7 @@ def main():
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -457,13 +815,26 @@ def main():
                    "sharding": "instances/%d, no data-path collective" % n_gpus +
                                (" + all-reduce(401 MB synthetic grad buffer)" if args.allreduce_grads else "")},
     }
+    emitter.arm(result)  # from here on a hang in a side measurement costs the extras, not the line
 
-    if dist is not None and backend == "nccl" and not args.allreduce_grads and not args.no_allreduce_probe:
-        # BASELINE config 4 adds "data-parallel RCCL all-reduce" to the sharded step.  The metric path itself has no
-        # exchange (value above); this extra region repeats the step with an all-reduce of a buffer the size of the
-        # model's fp32 gradient (100,204,832 floats, synthetic contents -- the forward path produces no parameter
-        # gradient; the real one is exercised by tools/train_bench.py), launched asynchronously so RCCL overlaps the
-        # step's kernels as a trainer's bucketed reduce overlaps backward.
+    if multi:
+        # ---- N > 1 only: who took part, and how evenly
+        try:
+            result["rank_proof"] = rank_proof(dist, rank, world, backend, red_dev)
+        except Exception as e:
+            result["rank_proof"] = {"error": repr(e)}
+        try:
+            ms = gather_rank_objects(dist, world, lambda: {"ms": round(1e3 * t_own / args.steps, 3)})
+            result["per_rank_ms_per_step"] = [o.get("ms") for o in ms]
+            result["ms_per_step_max_over_ranks"] = result["ms_per_step"]
+        except Exception as e:
+            result["per_rank_ms_per_step"] = {"error": repr(e)}
+
+    if multi and backend == "nccl" and not args.allreduce_grads and not args.no_allreduce_probe:
+        # BASELINE config 4, forward form: the sharded metric step with an asynchronous all-reduce of a buffer the
+        # size of the FULL model's fp32 gradient (both trunks: 100,204,832 floats, synthetic contents -- the forward
+        # path produces no parameter gradient) overlapping it.  The REAL gradient exchange is the training_step
+        # object below.
         try:
             gbuf = torch.zeros((100204832,), dtype=torch.float32, device=device)
 
@@ -488,74 +859,17 @@ def main():
             result["with_grad_allreduce"] = {
                 "value": round(args.batch * n_gpus * k2 / el2, 2), "unit": "crops/s",
                 "ms_per_step": round(1e3 * el2 / k2, 3), "allreduce_bytes": int(gbuf.numel() * 4),
-                "note": "same step + async RCCL all-reduce(sum) of a gradient-sized synthetic fp32 buffer per step"}
+                "note": "same forward step + async RCCL all-reduce(sum) of a full-model-gradient-sized SYNTHETIC fp32 "
+                        "buffer per step; the real-gradient exchange is in training_step"}
             del gbuf
         except Exception as e:
             result["with_grad_allreduce"] = {"error": repr(e)}
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel alone: every conv/FC launch of one step, timed with events on the launch stream
-        run, launches, flops, alg_bytes, executed, kinds = conv_replay(net, args.batch)
-        run()
-        torch.cuda.synchronize()
-        reps = max(3, min(10, args.steps))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * launches)
-        achieved = flops / launches / avg_s / 1e12
-        # HBM traffic and MFMA-busy cycles cannot be counted from inside the process: they come from the newest
-        # committed rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/
-        # rNN_pmc_traffic.json), quoted with the round and commit they were collected at
-        traffic = busy = src = None
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            try:
-                with open(path) as f:
-                    pm = json.load(f)
-                traffic = round(pm["hbm_bytes_per_launch"])
-                busy = pm.get("mfma_busy")
-                src = {"file": os.path.relpath(path, ROOT), "round": pm.get("round"), "commit": pm.get("commit"),
-                       "collected": pm.get("collected")}
-                break
-            except Exception:
-                pass
-        peak = PEAK_F32_MFMA_TFLOPS if args.math == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        kname = "conv_igemm_kernel + wino_conv_kernel (fp32 MFMA 32x32x2: implicit GEMM; Winograd F(2x2,3x3) for the " \
-                "decoder's 3x3 layers)" if args.math == "fp32" else \
-            "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
-        result["roofline"] = {"bound": "mfma", "kernel": kname,
-                              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                              "frac": round(achieved / peak, 4), "traffic": traffic if args.math == "fp32" else None,
-                              "launches_per_step": launches, "avg_launch_us": round(avg_s * 1e6, 2),
-                              "flops_per_launch": round(flops / launches),
-                              "algorithmic_bytes": round(alg_bytes / launches)}
-        if args.math == "fp32":
-            # `achieved` counts the ALGORITHMIC multiply-adds of the direct convolution (the contract's definition);
-            # the decoder's 3x3 layers run as Winograd F(2x2,3x3) (16 products where the direct form has 36) and the
-            # atrous layers skip their out-of-image taps, so the matrix pipes issue fewer: `executed` is what they do
-            result["roofline"]["executed"] = round(executed / launches / avg_s / 1e12, 2)
-            result["roofline"]["executed_frac"] = round(executed / launches / avg_s / 1e12 / peak, 4)
-            result["roofline"]["executed_flops_per_launch"] = round(executed / launches)
-            result["roofline"]["launch_kinds"] = {"implicit_gemm": kinds[0], "winograd_f2x2_3x3": kinds[1],
-                                                  "direct_narrow": kinds[2]}
-            result["roofline"]["note"] = ("achieved / frac count the ALGORITHMIC direct-convolution FLOPs (SURVEY 8(d)), "
-                                          "so they can exceed the peak: the 4 Winograd launches issue 16/36 of theirs and "
-                                          "the atrous layers skip out-of-image taps; executed / executed_frac and "
-                                          "mfma_busy (PMC) are the utilisation of the matrix pipes")
-            if traffic:
-                result["roofline"]["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
-                result["roofline"]["mfma_busy"] = busy
-                result["roofline"]["traffic_source"] = src
-            try:
-                box = mfma_box_peak(device)
-                result["roofline"]["peak_measured_on_this_board"] = round(box, 1)
-                result["roofline"]["frac_of_measured"] = round(achieved / box, 4)
-            except Exception as e:
-                result["roofline"]["peak_measured_on_this_board"] = repr(e)
+        try:
+            result["roofline"] = roofline_object(net, args, device, result["ms_per_step"])
+        except Exception as e:
+            result["roofline"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline:
         # the Chamfer op alone, as the north star asks ("achieved HBM GB/s on nn_distance"): algorithmic bytes =
         # b*(n+m)*20 forward (12 read + 8 written per point), b*(n+m)*32 backward; the kernel is VALU-bound, so the
@@ -570,7 +884,7 @@ def main():
             nnd.nn_distance_grad(c1, c2, ones, i1, ones, i2)
             torch.cuda.synchronize()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            reps = 20
+            reps = 50
             ev[0].record()
             for _ in range(reps):
                 nnd.nn_distance(c1, c2)
@@ -587,11 +901,17 @@ def main():
                 "bound": "valu (fwd), hbm/lds (bwd)"}
         except Exception as e:
             result["nn_distance"] = {"error": repr(e)}
-    if rank == 0 and not args.no_roofline and not args.no_emd:
-        try:
-            result["emd"] = emd_object(device)
-        except Exception as e:
-            result["emd"] = {"error": repr(e)}
+    if not args.no_roofline and not args.no_emd:
+        if multi:  # cfg5 across ranks: every rank its own share, concurrently
+            try:
+                result["emd"] = emd_all_ranks(dist, world, lambda: emd_object(device))
+            except Exception as e:
+                result["emd"] = {"error": repr(e)}
+        elif rank == 0:
+            try:
+                result["emd"] = emd_object(device)
+            except Exception as e:
+                result["emd"] = {"error": repr(e)}
     if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
         # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
         # on the same inputs (NOT the headline: `value` above is fp32)
@@ -622,19 +942,26 @@ def main():
             result["bf16x3_mode"] = {"error": repr(e)}
         finally:
             _lib.set_conv_math("fp32")
-    if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_train_step and not args.no_roofline:
-        # one data-parallel TRAINING step of the same 256 instances (forward, the reference's configured
-        # loss set, backward, per-variable clip, Adam + moving average; map-decoder BatchNorm on batch statistics),
-        # timed like tools/train_bench.py.  A side measurement: never part of `value`.
-        try:
-            result["training_step"] = training_step_object(device, args.batch, inp)
-        except Exception as e:
-            result["training_step"] = {"error": repr(e)}
+    if args.math == "fp32" and not args.no_train_step and not args.no_roofline:
+        # SURVEY 8(f3) / BASELINE cfg4: one data-parallel TRAINING step of the same instances on EVERY rank (forward,
+        # the reference's configured loss set, backward, all-reduce of the real gradient, per-variable clip, Adam +
+        # moving average; map-decoder BatchNorm on per-rank batch statistics).  A side measurement: never part of
+        # `value`.  All ranks enter (it holds collectives); failures are symmetric (same code, same sizes).
+        if multi or rank == 0:
+            try:
+                tb = args.train_batch or args.batch
+                tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
+                ts = training_step_object(device, tb, tinp, dist=dist if multi else None, red_dev=red_dev)
+                result["training_step"] = ts
+            except Exception as e:
+                result["training_step"] = {"error": repr(e)}
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
-        result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
+        try:
+            result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)
+        except Exception as e:
+            result["cpu_baseline"] = {"error": repr(e)}
 
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    emitter.emit(result)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,7 +23,8 @@ class ReverseBucketReducer:
     def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None):
         """layer_spans[i]: the element range(s) of `flat` layer i's backward writes -- one (lo, hi) or a list of them
         (weight gradient AND bias gradient: a bucket holding any part of either must wait for the layer)."""
-        self.flat, self.group = flat, group
+        self.flat, self.group, self.bucket_bytes = flat, group, bucket_bytes
+        self.enabled = True  # False: buckets are tracked but nothing is exchanged (timing the step without it)
         n = max(1, bucket_bytes // flat.element_size())
         self.buckets = [(lo, min(lo + n, flat.numel())) for lo in range(0, flat.numel(), n)]
         # layers overlapping each bucket
@@ -45,7 +46,8 @@ class ReverseBucketReducer:
         self.works = []
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return (self.enabled and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size(self.group) > 1)
 
     def layer_ready(self, li):
         for bi in self.layer_buckets[li]:

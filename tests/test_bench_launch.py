@@ -32,7 +32,22 @@ def test_gpus_n_starts_n_ranks(n):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout  # rank 0 only
-    assert lines[0]["n_gpus"] == n and lines[0]["max_rank_plus_1"] == n  # every rank took part
+    res = lines[0]
+    assert res["n_gpus"] == n and res["max_rank_plus_1"] == n  # every rank took part
+    # the objects an N > 1 line carries, produced here by the same functions on stand-in workloads
+    proof = res["rank_proof"]
+    assert proof["allreduce_of_ones"] == n and proof["world_size"] == n
+    assert [r["rank"] for r in proof["ranks"]] == list(range(n)) and len({r["pid"] for r in proof["ranks"]}) == n
+    assert res["per_rank_ms"] == [1.0 + r for r in range(n)]
+    ts = res["training_step"]
+    for key in ("ms_per_step", "ms_per_step_without_allreduce", "exposed_allreduce_ms", "allreduce_alone_ms",
+                "gradients", "allreduce", "loss_per_step"):
+        assert key in ts, key
+    assert ts["ranks"] == n and "per-rank batch statistics" in ts["what"]
+    # the stand-in gradient is rank + 1 everywhere: averaged over ranks by the reducer
+    assert ts["loss_per_step"][-1] == pytest.approx(sum(range(1, n + 1)) / n, abs=0.06)
+    emd = res["emd"]["all_ranks"]
+    assert emd["ranks_ok"] == n and emd["fused_clouds_per_s_sum"] == 10.0 * sum(range(1, n + 1))
 
 
 def test_under_a_launcher_each_process_is_one_rank():
@@ -66,13 +81,61 @@ def test_a_failed_rank_fails_the_launch():
     assert r.returncode != 0 and "rank(s) failed" in r.stderr
 
 
+def test_a_rank_that_dies_early_does_not_leave_its_peers_waiting():
+    # rank 1 exits before the rendezvous; rank 0 would sit in it until the store timeout (the launcher
+    # must poll every rank and stop the others on the first failure)
+    import time
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2"], {"MPSR_BENCH_RENDEZVOUS_ONLY": "1", "MPSR_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0 and "(1, 7)" in r.stderr and "stopped" in r.stderr
+    assert time.monotonic() - t0 < 90
+
+
+def test_sigterm_to_the_launcher_stops_the_ranks():
+    import signal
+    import time
+    import psutil
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MPSR_BENCH_TEST_HANG="1")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    try:
+        kids = []
+        for _ in range(200):
+            kids = psutil.Process(p.pid).children()
+            if len(kids) == 2:
+                break
+            time.sleep(0.05)
+        assert len(kids) == 2
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=30)
+        assert p.returncode != 0
+        gone, alive = psutil.wait_procs(kids, timeout=15)
+        assert not alive
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
 @pytest.mark.gpu
 def test_two_ranks_of_the_real_step_on_one_gpu():
-    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "256", "--no-roofline",
-              "--cpu-sample", "0"], {"MPSR_BENCH_SHARE_GPU": "1"}, timeout=1200)
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "256", "--cpu-sample", "0"],
+             {"MPSR_BENCH_SHARE_GPU": "1"}, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1
     res = lines[0]
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 16
     assert res["value"] > 0 and abs(res["value"] - 16 * 2 / (res["ms_per_step"] * 2e-3)) < 0.01 * res["value"]
+    # the four N > 1 objects: rank proof, per-rank times, the real-gradient training step through the reducer, and
+    # the EMD share of every rank
+    assert res["rank_proof"]["allreduce_of_ones"] == 2 and len(res["rank_proof"]["ranks"]) == 2
+    assert len(res["per_rank_ms_per_step"]) == 2 and max(res["per_rank_ms_per_step"]) <= res["ms_per_step"] * 1.05
+    ts = res["training_step"]
+    assert "error" not in ts, ts
+    assert ts["ranks"] == 2 and ts["grad_bytes"] > 250e6 and ts["ms_per_step"] > 0
+    assert "exposed_allreduce_ms" in ts and "ms_per_step_without_allreduce" in ts
+    emd = res["emd"]
+    assert "error" not in emd and emd["all_ranks"]["ranks_ok"] == 2, emd
+    assert 0 < res["roofline"]["frac"] <= 1.0
