@@ -1017,7 +1017,7 @@ std::atomic<int> g_tile_override{-1};
 std::atomic<int> g_class_override{-1};
 std::atomic<int> g_sched_override{-1};
 std::atomic<int> g_sk_per_cu{0};
-std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 whenever possible
+std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
 
@@ -1095,6 +1095,11 @@ size_t winograd_scratch_floats(int C, int N);
 bool winograd_applies(int H, int W, int C, int N);
 int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                      int N, float *ws, size_t ws_floats, hipStream_t s);
+// winograd4.hip
+size_t winograd4_scratch_floats(int C, int N);
+bool winograd4_applies(int H, int W, int C, int N);
+int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s);
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
@@ -1148,15 +1153,20 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
         g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
         return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream);
-    // the big dense 3x3 layers (map decoder) go to the Winograd F(2x2,3x3) kernel when the caller leaves the schedule
-    // to the library: 2.25x fewer multiply-adds (winograd.hip)
+    // the big dense 3x3 layers (map decoder) go to a Winograd kernel when the caller leaves the schedule to the
+    // library: F(4x4,3x3) (winograd4.hip, 4x fewer multiply-adds) where the map divides into 4x4 blocks, else
+    // F(2x2,3x3) (winograd.hip, 2.25x fewer)
     {
         int wino = g_wino_override.load();
-        const bool can = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws &&
-                         g_math.load() == MATH_FP32 && winograd_applies(H, W, C, N) &&
-                         ws_floats >= winograd_scratch_floats(C, N);
-        if (wino < 0) wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
-        if (wino == 1 && can) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        const bool base = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws &&
+                          g_math.load() == MATH_FP32;
+        const bool can2 = base && winograd_applies(H, W, C, N) && ws_floats >= winograd_scratch_floats(C, N);
+        const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
+                          M64 * C * 4 < 0x7f000000LL;
+        if (wino < 0)
+            wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? (can4 ? 2 : 1) : 0;
+        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        if (wino >= 1 && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
@@ -1277,17 +1287,23 @@ extern "C" int mpsr_set_conv_math(int mode)
 extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
-// kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel; and
-// the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernel 16/36 of the direct count,
+// kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,
+// 3 = Winograd F(4x4,3x3); and
+// the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernels 16/36 or 36/144 of the direct count,
 // the implicit GEMM with border classes only the in-image taps.  For reporting (bench.py), not part of the compute path.
 extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
                                 double *executed_flops)
 {
     MPSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && kind && executed_flops, "conv2d_plan: bad arguments");
     const double M = (double)B * H * W;
-    const bool wino = KH == 3 && KW == 3 && dilation == 1 && mpsr::winograd_applies(H, W, C, N) && M >= 65536 &&
-                      C >= 64 && N >= 64 && g_math.load() == MATH_FP32;
-    if (wino) {
+    const bool wino_shape = KH == 3 && KW == 3 && dilation == 1 && M >= 65536 && C >= 64 && N >= 64 &&
+                            g_math.load() == MATH_FP32 && g_wino_override.load() != 0;
+    if (wino_shape && mpsr::winograd4_applies(H, W, C, N) && g_wino_override.load() != 1 && M * C * 4 < 0x7f000000LL) {
+        *kind = 3;  // F(4x4,3x3): 36 products per 4x4 block
+        *executed_flops = 2.0 * (double)B * (H / 4) * (W / 4) * 36.0 * C * N;
+        return MPSR_OK;
+    }
+    if (wino_shape && mpsr::winograd_applies(H, W, C, N)) {
         *kind = 1;
         *executed_flops = 2.0 * (double)B * (H / 2) * (W / 2) * 16.0 * C * N;
         return MPSR_OK;

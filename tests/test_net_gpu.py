@@ -230,6 +230,41 @@ def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu, waves):
     assert not torch.equal(got, direct) or C * N < 1024  # it really is a different evaluation
 
 
+@pytest.mark.parametrize("B,H,Wd,C,N,has_bias,relu", [
+    (2, 24, 24, 64, 64, True, True), (1, 48, 48, 32, 128, True, True), (3, 12, 8, 16, 40, False, False),
+    (1, 4, 4, 16, 4, True, False), (5, 12, 12, 48, 200, True, True), (4, 48, 48, 256, 128, True, True),
+    (2, 24, 24, 512, 256, True, True), (7, 4, 8, 16, 65, True, True), (9, 8, 4, 32, 64, True, False)])
+def test_conv2d_winograd4_vs_fp64(B, H, Wd, C, N, has_bias, relu):
+    """The Winograd F(4x4,3x3) kernel (csrc/winograd4.hip: 3x3, stride 1, SAME, maps that divide into 4x4 blocks):
+    ragged tile / channel counts (tiles not a multiple of 32, N not a multiple of 64), every border case of a 6x6
+    patch, the decoder's real layer shapes.  Tolerance 1e-4 of the tensor scale against float64 (measured ~1.5e-5:
+    transform constants up to 8 and 1/24; the north star's budget is 1e-3)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    rng = np.random.default_rng(B * 1000 + C + N)
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = _conv_ref(x, w, bias, None, 1, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    lib.mpsr_debug_set_conv_winograd(2)
+    try:
+        got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, 1, relu, split_k=0)
+        again = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, 1, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    _close(got, ref, 1e-4, "winograd F(4x4) %s" % ((B, H, Wd, C, N),))
+    assert torch.equal(got, again), "not deterministic"
+    lib.mpsr_debug_set_conv_winograd(0)
+    try:
+        direct = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, 1, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    assert not torch.equal(got, direct) or C * N < 1024  # it really is a different evaluation
+
+
 def test_border_class_tiling_is_bit_identical():
     """Skipping the all-zero taps of an atrous layer must not change a single bit (same products, same order)."""
     from monopsr_amd import _lib

@@ -47,7 +47,7 @@ def main():
                     "per workgroup, 1 stream-K; 1:G or 1:-N pins the workgroups per CU / the workgroup count")
     ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
                     "kernel: -1 heuristic, 1, 2")
-    ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0, 1")
+    ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3), 2 F(4x4,3x3)")
     ap.add_argument("--plain", default="-1", help="comma list: the decode-free 1x1 instantiation: -1 whenever it "
                     "applies, 0 never")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
