@@ -1417,6 +1417,10 @@ __global__ __launch_bounds__(256) void mfma_valu_kernel(float *out, int iters, f
     buf[threadIdx.x * 4] = av;
     __syncthreads();
     const float *lp = buf + (threadIdx.x & 63) * 4;
+    __shared__ __attribute__((aligned(16))) float wbuf[256 * 4 + 2048];
+    const unsigned wp = (unsigned)(size_t)(wbuf + threadIdx.x), wp2 = (unsigned)(size_t)(wbuf + threadIdx.x * 2),
+                   wp4 = (unsigned)(size_t)(wbuf + threadIdx.x * 4);
+    __attribute__((ext_vector_type(2))) float w2 = {av, bv};
     int sreg = iters;
     f32x4 lv = {0.f, 0.f, 0.f, 0.f};
     f32x16 acc;
@@ -1435,6 +1439,11 @@ __global__ __launch_bounds__(256) void mfma_valu_kernel(float *out, int iters, f
                 if (KIND == 1) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
                 if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(lv) : "v"((unsigned)(size_t)lp) : "memory");
                 if (KIND == 3) asm volatile("s_nop 0");
+                // LDS stores of this thread's own slot (conflict-free): 4, 8, 16 bytes, and the paired 4-byte form
+                if (KIND == 4) asm volatile("ds_write_b32 %0, %1" ::"v"(wp), "v"(v[q & 15]) : "memory");
+                if (KIND == 5) asm volatile("ds_write_b64 %0, %1" ::"v"(wp2), "v"(w2) : "memory");
+                if (KIND == 6) asm volatile("ds_write_b128 %0, %1" ::"v"(wp4), "v"(lv) : "memory");
+                if (KIND == 7) asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:4" ::"v"(wp), "v"(v[q & 15]), "v"(v[(q + 1) & 15]) : "memory");
             }
             if (KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -1467,16 +1476,23 @@ extern "C" int mpsr_debug_dispatch(float *out, int blocks, int lds_bytes, int sp
     return MPSR_OK;
 }
 
-// kind 0: vector ALU, 1: scalar ALU, 2: LDS reads (ds_read_b128), 3: s_nop
+// kind 0: vector ALU, 1: scalar ALU, 2: LDS reads (ds_read_b128), 3: s_nop, 4-7: LDS stores (ds_write_b32 / _b64 /
+// _b128 / ds_write2st64_b32); nv = 1, 2 (stores only), 4 or 8 of them after every MFMA
 extern "C" int mpsr_debug_mfma_mix(float *out, int cus, int waves_per_simd, int nv, int kind, int iters,
                                    mpsr_stream_t stream)
 {
-    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 && (nv == 4 || nv == 8),
+    MPSR_REQUIRE(out && cus > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 &&
+                     (nv == 4 || nv == 8 || ((nv == 1 || nv == 2) && kind >= 4)) && kind >= 0 && kind <= 7,
                  "mfma_mix: bad arguments");
     const dim3 grid((unsigned)(cus * waves_per_simd));
     hipStream_t s = mpsr::as_stream(stream);
 #define MIX(NV_, K_) hipLaunchKernelGGL((mfma_valu_kernel<NV_, K_>), grid, dim3(256), 0, s, out, iters, 1.f, 1e-3f)
-    if (nv == 4) {
+    if (kind >= 4) {
+        if (nv == 1) { if (kind == 4) MIX(1, 4); else if (kind == 5) MIX(1, 5); else if (kind == 6) MIX(1, 6); else MIX(1, 7); }
+        else if (nv == 2) { if (kind == 4) MIX(2, 4); else if (kind == 5) MIX(2, 5); else if (kind == 6) MIX(2, 6); else MIX(2, 7); }
+        else if (nv == 4) { if (kind == 4) MIX(4, 4); else if (kind == 5) MIX(4, 5); else if (kind == 6) MIX(4, 6); else MIX(4, 7); }
+        else { if (kind == 4) MIX(8, 4); else if (kind == 5) MIX(8, 5); else if (kind == 6) MIX(8, 6); else MIX(8, 7); }
+    } else if (nv == 4) {
         if (kind == 0) MIX(4, 0); else if (kind == 1) MIX(4, 1); else if (kind == 2) MIX(4, 2); else MIX(4, 3);
     } else {
         if (kind == 0) MIX(8, 0); else if (kind == 1) MIX(8, 1); else if (kind == 2) MIX(8, 2); else MIX(8, 3);

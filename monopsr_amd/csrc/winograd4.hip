@@ -21,9 +21,9 @@
 //     between the two halves -- the two loops are separate straight-line copies selected once, so the accumulators
 //     never meet a branch inside the K loop.
 //   * B side (transformed filters U, made per call by wino4_filter_kernel, laid out [channel block][position][n][8])
-//     needs no sharing at all: wave (g, nh) is the only reader of positions g x channels nh, so it copies exactly its
-//     own 9 x 32 rows through a PRIVATE single-buffered LDS region (a rolling window of three 16-byte loads in
-//     flight, written back right after the MFMAs that consumed the old contents): no barrier ever guards B.
+//     needs no sharing at all: wave (g, nh) is the only reader of positions g x channels nh, so its fragments go
+//     straight from L2 into registers (16 bytes per lane = the k pairing of the A side; one load = 1 KiB contiguous),
+//     requested one unit of 12 MFMAs ahead into the other of two register sets.  LDS carries A only.
 //   * one s_barrier per K step (the A hand-over).
 //   * epilogue: the 36 position accumulators of a (tile, channel) live in four waves; they are exchanged through
 //     LDS (all 144 KB, two rounds of 16 tiles), each thread then runs A^T M A for two (tile, channel) pairs (100
@@ -56,6 +56,7 @@ struct Wino4Params {
     int B, H, W, C, N, th, tw, T;  // th x tw tiles per image, T tiles in all
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes;
+    unsigned long long *trace;  // -DW4_TRACE builds: per-wave cycle stamps of two K steps (tools/wino4_trace.py)
 };
 
 // U[cb][pos][n][8] = (G g G^T)[pos] for filter g = w[n][(ky*3+kx)*C + c], c = cb*8 + j.  One thread per (n, c).
@@ -122,6 +123,13 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+#ifndef W4_SPREAD
+#define W4_SPREAD 0
+#endif
+#ifndef W4_APRE
+#define W4_APRE 0  // 1: read the next unit's A fragments during the current unit (12 more registers)
+#endif
+
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_kernel(const Wino4Params p)
 {
     using namespace f4;
@@ -135,6 +143,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (mb >= p.mblocks) return;  // block-uniform
     const int n0 = nb * NT, t0 = mb * MT;
 
+#ifdef W4_TRACE
+    unsigned long long ts[16];
+    int nts = 0;
+#define W4_STAMP(cond) do { if ((cond) && nts < 16) ts[nts++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4_STAMP(cond) do { } while (0)
+#endif
+    W4_STAMP(true);  // 0: start
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 1, nh = wave & 1;  // consumer role: position block, channel half
@@ -148,63 +164,105 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // descriptor moved back by one row + one pixel so that the per-thread base offset is never negative
     const unsigned shift = (unsigned)(p.W + 1) * (unsigned)p.C * 4u;
     char *xback = const_cast<char *>(reinterpret_cast<const char *>(p.x)) - shift;
-    unsigned abase;
-    bool rowok[6], colok[6];
+    // Only the ring of a 6x6 patch can leave the image (row 0 / 5, column 0 / 5): nine distinct per-thread byte
+    // offsets (this thread's pixel (0,0) of the patch, or an out-of-range value) cover the 36 requests; the pixel
+    // itself comes in through the scalar offset.  (One select per request instead would be hoisted out of the K loop
+    // by hipcc as 36 registers.)
+    unsigned voffc[3][3];
     {
         const int t = t0 + lt;
         const int tpi = p.th * p.tw;
         const int img = t / tpi, rem = t - img * tpi;
         const int ty = rem / p.tw, tx = rem - ty * p.tw;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-        abase = (unsigned)(((img * p.H + y0 + 1) * p.W + x0 + 1) * p.C + ch) * 4u;  // + shift, i.e. of pixel (y0+1, x0+1)
+        // (+ shift, i.e. relative to the moved-back descriptor this is the offset of pixel (y0, x0))
+        const unsigned abase = (unsigned)(((img * p.H + y0 + 1) * p.W + x0 + 1) * p.C + ch) * 4u;
+        const bool in = t < p.T;
+        const bool rowc[3] = {in && y0 >= 0, in, in && y0 + 5 < p.H};
+        const bool colc[3] = {x0 >= 0, true, x0 + 5 < p.W};
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            rowok[r] = t < p.T && y0 + r >= 0 && y0 + r < p.H;
-            colok[r] = x0 + r >= 0 && x0 + r < p.W;
-        }
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) voffc[a][b] = (rowc[a] && colc[b]) ? abase : OOB;
     }
     float pa[36];  // the patch, then its transform, row-major
-    auto load_patch1 = [&](int step, int i) __attribute__((always_inline)) {
-        const int r = i / 6, s = i % 6;
+    // request number L of a patch, column by column (the column transforms start with column 0)
+    auto load_patch1 = [&](int step, int L) __attribute__((always_inline)) {
+        const int s = L / 6, r = L % 6;
+#ifdef W4_SKIP_LOAD
+        if (step > 1) return;
+#endif
         const bool live = step < nsteps;
         // (a request past the last channel block goes through a zero-length descriptor: a scalar select)
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(xback, 0, live ? (int)(p.xbytes + shift) : 0, 0x00020000);
         const unsigned so = (unsigned)((r * p.W + s) * p.C + (live ? step : 0) * KC) * 4u;
-        pa[i] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rr, (rowok[r] && colok[s]) ? abase : OOB, so, 0));
+        pa[6 * r + s] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rr, voffc[r == 0 ? 0 : r == 5 ? 2 : 1][s == 0 ? 0 : s == 5 ? 2 : 1],
+                                                        so, 0));
     };
-    auto vertical = [&](int s) __attribute__((always_inline)) { bt6(pa[s], pa[6 + s], pa[12 + s], pa[18 + s], pa[24 + s], pa[30 + s]); };
-    auto horizontal = [&](int r) __attribute__((always_inline)) {
-        bt6(pa[6 * r], pa[6 * r + 1], pa[6 * r + 2], pa[6 * r + 3], pa[6 * r + 4], pa[6 * r + 5]);
+    // B^T applied to six values in place, in three parts of four operations (parts 0 and 1 read the original values,
+    // part 2 finishes from part 0's temporaries)
+    float ta, tb, tc, te;
+    auto bt_part = [&](int part, float &d0, float &d1, float &d2, float &d3, float &d4, float &d5)
+                       __attribute__((always_inline)) {
+#ifdef W4_SKIP_VALU
+        return;
+#endif
+        if (part == 0) {
+            ta = fmaf(-4.f, d2, d4);
+            tb = fmaf(-4.f, d1, d3);
+            tc = d4 - d2;
+            te = d3 - d1;
+        } else if (part == 1) {
+            d0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+            d5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+        } else {
+            d1 = ta + tb;
+            d2 = ta - tb;
+            d3 = fmaf(2.f, te, tc);
+            d4 = fmaf(-2.f, te, tc);
+        }
+    };
+    auto vertical = [&](int s, int part) __attribute__((always_inline)) {
+        bt_part(part, pa[s], pa[6 + s], pa[12 + s], pa[18 + s], pa[24 + s], pa[30 + s]);
+    };
+    auto horizontal = [&](int r, int part) __attribute__((always_inline)) {
+        bt_part(part, pa[6 * r], pa[6 * r + 1], pa[6 * r + 2], pa[6 * r + 3], pa[6 * r + 4], pa[6 * r + 5]);
     };
     // A[buf][pos][tile][8 channels], 16-byte halves swapped on odd 8-row blocks
     float *awr = lds + lt * 8 + 4 * ((ch >> 2) ^ ((lt >> 3) & 1)) + (ch & 3);
-    auto store_a = [&](int buf, int pos) __attribute__((always_inline)) { awr[buf * ABUF + pos * APOS] = pa[pos]; };
+    auto store_a = [&](int buf, int pos) __attribute__((always_inline)) {
+#ifndef W4_SKIP_STORE  // (timing experiments only: tools/README.md)
+        awr[buf * ABUF + pos * APOS] = pa[pos];
+#else
+        asm volatile("" ::"v"(pa[pos]));
+#endif
+    };
 
-    // ---- B copy (private to the wave): row 32 nh + (lane >> 1), half lane & 1 of each of its 9 positions
-    const __amdgpu_buffer_rsrc_t ru =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, (int)p.ubytes, 0x00020000);
-    const int brow = 32 * nh + (lane >> 1);
-    const unsigned bvoff = n0 + brow < p.N ? (unsigned)((n0 + brow) * KC + 4 * (lane & 1)) * 4u : OOB;
+    // ---- B fragments straight from the transformed filters (L2) into registers: wave (g, nh) is the only consumer
+    // of its 9 positions x 32 channels, so there is nothing to share through LDS.  Lane = (n = lane & 31, k half =
+    // lane >> 5): 16 bytes, one load instruction = 1 KiB contiguous.
+    const unsigned bvoff =
+        n0 + 32 * nh + (lane & 31) < p.N ? (unsigned)((n0 + 32 * nh + (lane & 31)) * KC + 4 * (lane >> 5)) * 4u : OOB;
     const unsigned bpstride = (unsigned)p.N * KC * 4u;  // bytes between positions of one channel block
-    float *bwr = lds + BOFF + gpos * BPOS + brow * 8 + 4 * ((lane & 1) ^ ((brow >> 3) & 1));
-    float4 bst[3];
-    auto load_b1 = [&](int step, int q, int slot) __attribute__((always_inline)) {  // position q = 3 a + b of the wave's block, for K step `step`
+    float4 fb[2][3];
+    auto load_b1 = [&](int step, int u, int j, int set) __attribute__((always_inline)) {
         const bool live = step < nsteps;
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
-        const unsigned so = ((unsigned)(live ? step : 0) * 36u + (unsigned)(gpos + 6 * (q / 3) + q % 3)) * bpstride;
-        bst[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, 0));
-    };
-    auto store_b = [&](int q, int slot) __attribute__((always_inline)) {
-        *reinterpret_cast<float4 *>(bwr + (6 * (q / 3) + q % 3) * BPOS) = bst[slot];
+        const unsigned so = ((unsigned)(live ? step : 0) * 36u + (unsigned)(gpos + 6 * u + j)) * bpstride;
+        fb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, 0));
     };
 
-    // ---- consumer fragment addresses
+    // ---- A fragment address: row = lane & 31 (tile), k half = lane >> 5
     const float *ard = lds + gpos * APOS + (lane & 31) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1));
-    const int frow = 32 * nh + (lane & 31);
-    const float *brd = lds + BOFF + gpos * BPOS + frow * 8 + 4 * ((lane >> 5) ^ ((frow >> 3) & 1));
+    float4 fa[1 + W4_APRE][3];
+    auto read_a = [&](int buf, int u, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            fa[set][j] = *reinterpret_cast<const float4 *>(ard + buf * ABUF + (6 * u + j) * APOS);
+    };
 
     f32x16 acc[9];
 #pragma unroll
@@ -212,102 +270,89 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
-    // One K step of this wave: 9 positions x 4 MFMAs, positions in interleaved pairs (two independent accumulators
-    // alternate); after MFMA number m (0..35) comes duty(m); after a position's MFMAs its B rows are replaced by the
-    // next step's and the load three positions further on is requested.
+    // One K step of this wave = 3 units (u = row a of the wave's 3x3 position block) of 12 MFMAs: the unit's three
+    // positions are three independent accumulators taken round-robin, k = 0..3 of the fragments outermost.  MFMA
+    // number m = 12 u + 3 k + j of the step is followed by duty(m) -- the producer work of this wave -- and the whole
+    // order is pinned (sched_barrier after every slot): hipcc otherwise gathers the duty arithmetic into one block
+    // behind the first MFMA.  The B fragments of the NEXT unit are requested in the first three slots of a unit
+    // (parity bpar of the register sets alternates unit by unit: 3 units per step, two steps per loop trip).
     auto kstep = [&](int s, auto buf_c, auto &&duty) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
-        auto frag_a = [&](int q) __attribute__((always_inline)) {
-            return *reinterpret_cast<const float4 *>(ard + buf * ABUF + (6 * (q / 3) + q % 3) * APOS);
-        };
-        auto frag_b = [&](int q) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(brd + (6 * (q / 3) + q % 3) * BPOS); };
-        auto refill = [&](int q) __attribute__((always_inline)) {
-            store_b(q, q % 3);
-            if (q + 3 < 9) load_b1(s + 1, q + 3, q % 3);
-            else load_b1(s + 2, q + 3 - 9, q % 3);
-        };
+        W4_STAMP((s >> 1) == 4);  // steps 8 and 9: step start, after each unit, after the barrier
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int q0 = 2 * pp, q1 = q0 + 1;
-            __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists every fragment read of the step to its top)
-            const float4 a0 = frag_a(q0), b0 = frag_b(q0), a1 = frag_a(q1), b1 = frag_b(q1);
-            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[q0], 0, 0, 0);
-            duty(8 * pp + 0);
-            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[q1], 0, 0, 0);
-            duty(8 * pp + 1);
-            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[q0], 0, 0, 0);
-            duty(8 * pp + 2);
-            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[q1], 0, 0, 0);
-            duty(8 * pp + 3);
-            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[q0], 0, 0, 0);
-            duty(8 * pp + 4);
-            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[q1], 0, 0, 0);
-            duty(8 * pp + 5);
-            acc[q0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[q0], 0, 0, 0);
-            duty(8 * pp + 6);
-            acc[q1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[q1], 0, 0, 0);
-            duty(8 * pp + 7);
-            refill(q0);
-            refill(q1);
-        }
-        {
+        for (int u = 0; u < 3; ++u) {
+            const int bpar = (3 * buf + u) & 1;
+            const int aset = W4_APRE ? bpar : 0;
+            if (!W4_APRE || u == 0) read_a(buf, u, aset);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 a0 = frag_a(8), b0 = frag_b(8);
-            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[8], 0, 0, 0);
-            duty(32);
-            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[8], 0, 0, 0);
-            duty(33);
-            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[8], 0, 0, 0);
-            duty(34);
-            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[8], 0, 0, 0);
-            duty(35);
-            refill(8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int m = 12 * u + 3 * k + j;
+                    const float av = k == 0 ? fa[aset][j].x : k == 1 ? fa[aset][j].y : k == 2 ? fa[aset][j].z : fa[aset][j].w;
+                    const float bv = k == 0 ? fb[bpar][j].x : k == 1 ? fb[bpar][j].y : k == 2 ? fb[bpar][j].z : fb[bpar][j].w;
+                    acc[3 * u + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[3 * u + j], 0, 0, 0);
+                    if (k == 0) {
+                        if (u < 2) load_b1(s, u + 1, j, bpar ^ 1);
+                        else load_b1(s + 1, 0, j, bpar ^ 1);
+                    }
+                    if (W4_APRE && k == 2 && j == 0 && u < 2) read_a(buf, u + 1, aset ^ 1);
+                    duty(m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            W4_STAMP((s >> 1) == 4);
         }
     };
-    // producer duties of a step.  request: one patch load per slot.  transform: slots 0-5 the six column transforms,
-    // then per row r (slots 6 + 5 r ..): the row transform and its six stores.
+    // Producer duties.  request: 18 loads in slots 3-11 and 18 in slots 15-23, two per slot -- behind each unit's B
+    // requests, so that a wait for those (the counter retires in order) never waits for younger patch loads.
+    // transform: slots 0-17 the six column transforms (3 parts each), slots 18-35 the six row transforms; the stores
+    // of a finished row follow two per slot from slot 21; the last row's six after the step's last MFMA.
     auto request = [&](int step) __attribute__((always_inline)) {
-        return [&, step](int slot) __attribute__((always_inline)) { load_patch1(step, slot); };
+        return [&, step](int slot) __attribute__((always_inline)) {
+#if W4_SPREAD
+            load_patch1(step, slot);  // one request per slot
+#else
+            if (slot >= 3 && slot < 12) {
+                load_patch1(step, 2 * (slot - 3));
+                load_patch1(step, 2 * (slot - 3) + 1);
+            } else if (slot >= 15 && slot < 24) {
+                load_patch1(step, 18 + 2 * (slot - 15));
+                load_patch1(step, 18 + 2 * (slot - 15) + 1);
+            }
+#endif
+        };
     };
     auto transform = [&](auto buf_c) __attribute__((always_inline)) {
         return [&](int slot) __attribute__((always_inline)) {
             constexpr int buf = decltype(buf_c)::value;
-            if (slot < 6) {
-                vertical(slot);
-            } else {
-                const int r = (slot - 6) / 5, k = (slot - 6) % 5;
-                if (k == 0) horizontal(r);
-                else if (k == 1) { store_a(buf, 6 * r + 0); store_a(buf, 6 * r + 1); }
-                else if (k == 2) { store_a(buf, 6 * r + 2); store_a(buf, 6 * r + 3); }
-                else if (k == 3) store_a(buf, 6 * r + 4);
-                else store_a(buf, 6 * r + 5);
+            if (slot < 18) vertical(slot / 3, slot % 3);
+            else horizontal((slot - 18) / 3, (slot - 18) % 3);
+            if (slot >= 21) {
+                store_a(buf, 2 * (slot - 21));
+                store_a(buf, 2 * (slot - 21) + 1);
             }
+            if (slot == 35)
+#pragma unroll
+                for (int i = 30; i < 36; ++i) store_a(buf, i);
         };
     };
 
-    // ---- prologue: B of step 0 for this wave; A of step 0 by waves 0-3; the patch of step 1 requested by waves 4-7
-    {
-        float4 b0[9];
+    // ---- prologue: B of (step 0, unit 0); A of step 0 by waves 0-3; the patch of step 1 requested by waves 4-7
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
-            b0[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   ru, bvoff, (unsigned)(gpos + 6 * (q / 3) + q % 3) * bpstride, 0));
+    for (int j = 0; j < 3; ++j) load_b1(0, 0, j, 0);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) load_patch1(dgrp, i);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) *reinterpret_cast<float4 *>(bwr + (6 * (q / 3) + q % 3) * BPOS) = b0[q];
-    }
+    for (int i = 0; i < 36; ++i) load_patch1(dgrp, i);
     if (dgrp == 0) {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) vertical(s);
+        for (int k = 0; k < 18; ++k) vertical(k / 3, k % 3);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) horizontal(r);
+        for (int k = 0; k < 18; ++k) horizontal(k / 3, k % 3);
 #pragma unroll
         for (int i = 0; i < 36; ++i) store_a(0, i);
     }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) load_b1(1, q, q);
     __syncthreads();
+    W4_STAMP(true);  // 1: prologue done
 
     // ---- K loop, two steps per trip.  Waves 0-3: even step = request the patch of step s + 2, odd step = transform
     // it into buffer 0.  Waves 4-7: even step = transform the patch of step s + 1 into buffer 1, odd step = request
@@ -316,33 +361,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < nsteps; s += 2) {
             kstep(s, IC<0>{}, request(s + 2));
             __syncthreads();
+            W4_STAMP(s == 8);
             kstep(s + 1, IC<1>{}, transform(IC<0>{}));
             __syncthreads();
+            W4_STAMP(s == 8);
         }
     } else {
         for (int s = 0; s < nsteps; s += 2) {
             kstep(s, IC<0>{}, transform(IC<1>{}));
             __syncthreads();
+            W4_STAMP(s == 8);
             kstep(s + 1, IC<1>{}, request(s + 3));
             __syncthreads();
+            W4_STAMP(s == 8);
         }
     }
-    // (the 16-pass MFMA needs 18 wait states before its result is read; made explicit as in conv_mfma.hip)
+    // (the 16-pass MFMA needs 18 wait states before its result is read; made explicit as in conv_mfma.hip.  Plain
+    // vector registers: with an "a" constraint hipcc splits the 256-register budget 128 + 128 and spills)
+#ifdef W4_TRACE
+    W4_STAMP(true);  // 12: K loop done
+#endif
+    int tid2 = tid;
     asm volatile("s_nop 15\n\ts_nop 7"
                  : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                   "+v"(acc[7]), "+v"(acc[8]));
+                   "+v"(acc[7]), "+v"(acc[8]), "+v"(tid2));  // (tid2: the epilogue's addresses are not hoisted above the loop)
 
     // ---- epilogue.  Two rounds of 16 tiles: every wave writes its 9 positions of those tiles as M[pos][tile][64 n];
     // then thread (tile = tid >> 5, n = tid & 31 and + 32) gathers the 36 positions of its two (tile, n) pairs and
     // finishes them.  Accumulator element e of a lane: tile row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the 32,
     // output channel 32 nh + (lane & 31).
-    float *mwr = lds + gpos * (16 * 64) + (4 * (lane >> 5)) * 64 + 32 * nh + (lane & 31);
-    const float *mrd = lds + (tid >> 5) * 64 + (tid & 31);
+    const int lane2 = tid2 & 63;
+    float *mwr = lds + gpos * (16 * 64) + (4 * (lane2 >> 5)) * 64 + 32 * nh + (lane2 & 31);
+    const float *mrd = lds + (tid2 >> 5) * 64 + (tid2 & 31);
     const int tpi = p.th * p.tw;
     float bias2[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int n = n0 + (tid & 31) + 32 * h;
+        const int n = n0 + (tid2 & 31) + 32 * h;
         bias2[h] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
@@ -358,7 +413,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 mwr[(6 * (q / 3) + q % 3) * (16 * 64) + trow * 64] = acc[q][e];
             }
         __syncthreads();
-        const int tt = t0 + 16 * round + (tid >> 5);
+        W4_STAMP(round == 0);  // 13: round 0 exchanged
+        const int tt = t0 + 16 * round + (tid2 >> 5);
         const int img = tt / tpi, rem = tt - img * tpi;
         const int ty = rem / p.tw, tx = rem - ty * p.tw;
 #pragma unroll
@@ -371,7 +427,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 6; ++j) m[j] = mrd[(6 * i + j) * (16 * 64) + 32 * h];
                 at4(m[0], m[1], m[2], m[3], m[4], m[5], z[i][0], z[i][1], z[i][2], z[i][3]);
             }
-            const int n = n0 + (tid & 31) + 32 * h;
+            const int n = n0 + (tid2 & 31) + 32 * h;
             const bool ok = tt < p.T && n < p.N;
             float *o = p.y + ((size_t)(img * p.H + 4 * ty) * p.W + 4 * tx) * p.N + n;
 #pragma unroll
@@ -386,10 +442,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        W4_STAMP(true);  // 14, 15: round finished (stores issued)
     }
+#ifdef W4_TRACE
+    if (p.trace && lane2 == 0) {
+        unsigned long long *dst = p.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 16; ++i) dst[i] = i < nts ? ts[i] : 0;
+    }
+#endif
 }
 
 }  // namespace
+
+static unsigned long long *g_wino4_trace = nullptr;
+extern "C" void mpsr_debug_set_wino4_trace(void *buf) { g_wino4_trace = static_cast<unsigned long long *>(buf); }
 
 namespace mpsr {
 
@@ -431,6 +497,7 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
     p.relu = relu;
     p.xbytes = (unsigned)xbytes;
     p.ubytes = (unsigned)(winograd4_scratch_floats(C, N) * 4);
+    p.trace = g_wino4_trace;
     const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd4: grid too large");
     hipLaunchKernelGGL(wino4_conv_kernel, dim3((unsigned)blocks), dim3(512), LDSF * sizeof(float), s, p);

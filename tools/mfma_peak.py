@@ -109,6 +109,12 @@ if __name__ == "__main__":
             print("%-13s " % name + "  ".join("%dw x%d: %.1f" % (w, nv, measure_mix(w, nv, kind, iters=4000 // w))
                                               for w in (1, 4, 7) for nv in (4, 8)))
         sys.exit(0)
+    if "--stores" in sys.argv:
+        # LDS stores next to MFMAs: TFLOP/s with n stores after every MFMA of every wave (1, 2 waves per SIMD)
+        for kind, name in ((4, "ds_write_b32"), (5, "ds_write_b64"), (6, "ds_write_b128"), (7, "ds_write2st64_b32")):
+            print("%-18s " % name + "  ".join("%dw x%d: %.1f" % (w, nv, measure_mix(w, nv, kind, iters=4000 // w))
+                                               for w in (1, 2) for nv in (1, 2, 4, 8)))
+        sys.exit(0)
     if "--valu" in sys.argv:
         for w in (1, 2, 4, 7):
             print("%d waves/SIMD, VALU per MFMA -> TFLOP/s: " % w + "  ".join(

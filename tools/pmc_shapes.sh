@@ -12,6 +12,6 @@ for SH in 12,12,1024,256,1,1,0 12,12,256,1024,1,1,1 12,12,256,256,3,4,0; do
     i=$((i+1))
     timeout 120 rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/p$i" -o pmc -- python3 tools/conv_layer_bench.py --tiles 3 --reps 3 --shape $SH > "$OUT/p$i.log" 2>&1 || echo "pass $i failed/timeout"
   done
-  python3 tools/pmc_summary.py "$OUT"/p*/pmc_counter_collection.csv | grep "conv_igemm\|kernel |" > "$OUT/summary.md"
+  python3 tools/pmc_summary.py "$OUT"/p*/pmc_counter_collection.csv | grep "conv\|kernel |" > "$OUT/summary.md"
   echo "== $SH"; cat "$OUT/summary.md"
 done
