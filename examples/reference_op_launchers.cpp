@@ -44,8 +44,8 @@ void NmDistanceGradKernelLauncher(int b, int n, const float *xyz1, int m, const 
 }
 
 // `temp` is what the reference's shell allocates: TensorShape{b, (n+m)*2} floats (tf_approxmatch.cpp:167-168).  That
-// size selects the library's compact path (same result as the fast path, about 2x slower); a shell edited to
-// allocate mpsr_approx_match_temp_floats(b, n, m) floats would pass that number here instead.
+// size makes the library keep its per-level state in the tail of `match` itself until those rows are written (same
+// result bit for bit and the same speed as with mpsr_approx_match_temp_floats(b, n, m) floats of scratch).
 void approxmatchLauncher(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp)
 {
     check(mpsr_approx_match(b, n, m, xyz1, xyz2, match, temp, (size_t)b * (size_t)(n + m) * 2, MPSR_LAUNCHER_STREAM),

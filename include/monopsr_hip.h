@@ -84,7 +84,10 @@ size_t mpsr_approx_match_temp_floats(int b, int n, int m);
  * xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n), device-kernel semantics.
  *   temp_floats >= mpsr_approx_match_temp_floats(b,n,m): fast path (match written once);
  *   temp_floats >= b*(n+m)*2, what the reference's op shell allocates (tf_approxmatch.cpp:168): same result bit for
- *     bit, match accumulated level by level as the reference does (about 2x slower);
+ *     bit.  The per-level state then lives in the tail of each cloud's own block of `match` until those rows are
+ *     written last (same passes, same single write of match: as fast as the fast path); clouds too small or too
+ *     ragged for that (n*m < 11*(n+m)+n, or more than 64 rows of state) accumulate match level by level as the
+ *     reference does.  `match` must not be read by anyone else while the call runs (it never could be);
  *   less: MPSR_ERR_WORKSPACE, nothing is written. */
 int mpsr_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
                       size_t temp_floats, mpsr_stream_t stream);

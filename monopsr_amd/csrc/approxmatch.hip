@@ -123,9 +123,12 @@ template <bool HOST>
 struct State {
     using S = typename Sem<HOST>::S;
     S *remL, *remR, *ratL, *ratR;
-    __host__ __device__ State(void *temp, int cloud, int n, int m, int slots)
+    // cstride = words between the states of consecutive clouds; 0 = packed (the caller's temp buffer).  A non-zero
+    // stride places each cloud's state inside another per-cloud array (the tail of its match block, see
+    // mpsr_approx_match_ex)
+    __host__ __device__ State(void *temp, int cloud, int n, int m, int slots, size_t cstride = 0)
     {
-        S *base = static_cast<S *>(temp) + (size_t)cloud * ((size_t)(n + m) * (1 + slots));
+        S *base = static_cast<S *>(temp) + (size_t)cloud * (cstride ? cstride : (size_t)(n + m) * (1 + slots));
         remL = base;
         remR = base + n;
         ratL = base + n + m;
@@ -139,7 +142,7 @@ struct State {
 template <bool HOST, int MODE>
 __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2, void *temp, int lev,
-                                                            int slots)
+                                                            int slots, size_t cstride)
 {
     using S = typename Sem<HOST>::S;
     constexpr bool kDo3 = MODE != 0, kDo1 = MODE != 2;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
     const float *p2 = xyz2 + (size_t)cloud * m * 3;
-    const State<HOST> st(temp, cloud, n, m, slots);
+    const State<HOST> st(temp, cloud, n, m, slots, cstride);
     const int cur = slots > 1 ? lev : 0, prev = slots > 1 ? lev - 1 : 0;
     S *ratL_cur = st.ratL + (size_t)cur * n;
     const S *ratL_prev = st.ratL + (size_t)prev * n, *ratR_prev = st.ratR + (size_t)prev * m;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
 template <bool HOST>
 __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                                const float *__restrict__ xyz2, void *temp, int lev,
-                                                               int slots)
+                                                               int slots, size_t cstride)
 {
     using S = typename Sem<HOST>::S;
     __shared__ float4 tile[kTile];
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
     const float *p2 = xyz2 + (size_t)cloud * m * 3;
-    const State<HOST> st(temp, cloud, n, m, slots);
+    const State<HOST> st(temp, cloud, n, m, slots, cstride);
     const int cur = slots > 1 ? lev : 0;
     const S *ratL_cur = st.ratL + (size_t)cur * n;
     S *ratR_cur = st.ratR + (size_t)cur * m;
@@ -408,10 +411,11 @@ constexpr int kEmitRows = 64;
 // Writes match once from the ratios of every level.  The contiguous index ("column") of the output is the giver k in
 // the DEVICE layout [m][n] and the receiver l in the HOST layout [n][m]; threads run along it.
 // grid (ceil(cols / 256), ceil(rows / kEmitRows), b).
+// `row_limit`: rows at or above it are left to emd_emit_tail_kernel (the state lives there); `cstride` as in State.
 template <bool HOST>
 __global__ __launch_bounds__(256) void emd_emit_kernel(int n, int m, const float *__restrict__ xyz1,
                                                       const float *__restrict__ xyz2, void *temp,
-                                                      float *__restrict__ match)
+                                                      float *__restrict__ match, size_t cstride, int row_limit)
 {
     using S = typename Sem<HOST>::S;
     constexpr int L = Sem<HOST>::levels;
@@ -421,11 +425,12 @@ __global__ __launch_bounds__(256) void emd_emit_kernel(int n, int m, const float
     const int cols = HOST ? m : n, rows = HOST ? n : m;
     const float *pc = (HOST ? xyz2 : xyz1) + (size_t)cloud * cols * 3;  // column points
     const float *pr = (HOST ? xyz1 : xyz2) + (size_t)cloud * rows * 3;  // row points
-    const State<HOST> st(temp, cloud, n, m, L);
+    const State<HOST> st(temp, cloud, n, m, L, cstride);
     const S *ratC = HOST ? st.ratR : st.ratL, *ratRow = HOST ? st.ratL : st.ratR;
     const int c = blockIdx.x * 256 + tid;
     const int r0 = blockIdx.y * kEmitRows;
-    const int nr = min(kEmitRows, rows - r0);
+    const int nr = min(kEmitRows, min(rows, row_limit) - r0);
+    if (nr <= 0) return;  // block-uniform
     for (int i = tid; i < nr * 3; i += 256) rowp[i / 3][i % 3] = pr[(size_t)r0 * 3 + i];
     for (int i = tid; i < nr * L; i += 256) rowr[i / L][i % L] = ratRow[(size_t)(i % L) * rows + r0 + i / L];
     const bool live = c < cols;
@@ -441,6 +446,37 @@ __global__ __launch_bounds__(256) void emd_emit_kernel(int n, int m, const float
         const float v = HOST ? pair_match<true>(rowp[r][0], rowp[r][1], rowp[r][2], x, y, z, rowr[r], rc)
                              : pair_match<false>(x, y, z, rowp[r][0], rowp[r][1], rowp[r][2], rc, rowr[r]);
         out[(size_t)r * cols] = v;
+    }
+}
+
+// The rows of a cloud's match block that hold its own state (mpsr_approx_match_ex, "state inside match"): ONE
+// workgroup per cloud copies every ratio those rows need into LDS -- all levels of all givers, and the tail rows'
+// receiver ratios -- and only then overwrites the rows.  DEVICE layout and arithmetic: the entries are the same
+// pair_match values the emit kernel writes.  Dynamic LDS: L * n floats.  grid (b), 256 threads.
+__global__ __launch_bounds__(256) void emd_emit_tail_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                           const float *__restrict__ xyz2, void *temp,
+                                                           float *__restrict__ match, size_t cstride, int row0)
+{
+    constexpr int L = Sem<false>::levels;
+    extern __shared__ __attribute__((aligned(16))) float ratl[];  // [L][n]
+    __shared__ float rowp[kEmitRows][4];
+    __shared__ float rowr[kEmitRows][L + 1];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const float *pc = xyz1 + (size_t)cloud * n * 3, *pr = xyz2 + (size_t)cloud * m * 3;
+    const State<false> st(temp, cloud, n, m, L, cstride);
+    const int nr = m - row0;  // <= kEmitRows (checked by the host)
+    for (int i = tid; i < L * n; i += 256) ratl[i] = st.ratL[i];
+    for (int i = tid; i < nr * 3; i += 256) rowp[i / 3][i % 3] = pr[(size_t)row0 * 3 + i];
+    for (int i = tid; i < nr * L; i += 256) rowr[i / L][i % L] = st.ratR[(size_t)(i % L) * m + row0 + i / L];
+    __syncthreads();  // nothing below reads the state in global memory any more
+    float *out = match + ((size_t)cloud * m + row0) * n;
+    for (int c = tid; c < n; c += 256) {
+        const float x = pc[3 * c], y = pc[3 * c + 1], z = pc[3 * c + 2];
+        float rc[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) rc[i] = ratl[(size_t)i * n + c];
+        for (int r = 0; r < nr; ++r)
+            out[(size_t)r * n + c] = pair_match<false>(x, y, z, rowp[r][0], rowp[r][1], rowp[r][2], rc, rowr[r]);
     }
 }
 
@@ -814,17 +850,18 @@ size_t state_floats(int b, int n, int m, int levels, bool host)
 // each level (the compact path accumulates match there)
 template <bool HOST, typename F>
 int run_passes(int b, int n, int m, const float *xyz1, const float *xyz2, void *temp, int slots, hipStream_t s,
-               F between)
+               F between, size_t cstride = 0)
 {
     constexpr int L = Sem<HOST>::levels;
     const dim3 gl(mpsr::ceil_div(n, kThreads * kPT), b), gr(mpsr::ceil_div(m, kThreads * kPT), b);
-    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots);
+    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots, cstride);
     for (int lev = 0; lev < L; ++lev) {
-        hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots);
+        hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots,
+                           cstride);
         if (int rc = between(lev)) return rc;
         if (lev + 1 < L)
             hipLaunchKernelGGL((emd_giver_kernel<HOST, 1>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev + 1,
-                               slots);
+                               slots, cstride);
         // the giver capacity after the last level is never read: no trailing sweep 3
     }
     MPSR_CHECK_LAUNCH("emd passes");
@@ -861,7 +898,8 @@ extern "C" int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, cons
         if (int rc = run_passes<true>(b, n, m, xyz1, xyz2, temp, Sem<true>::levels, s, [](int) { return 0; })) return rc;
         dim3 grid(mpsr::ceil_div(m, 256), mpsr::ceil_div(n, kEmitRows), b);
         MPSR_REQUIRE(grid.y <= 65535, "approx_match: n=%d too large", n);
-        hipLaunchKernelGGL(emd_emit_kernel<true>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match);
+        hipLaunchKernelGGL(emd_emit_kernel<true>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match, (size_t)0,
+                           0x7fffffff);
         MPSR_CHECK_LAUNCH("emd_emit_kernel");
         return MPSR_OK;
     }
@@ -870,7 +908,8 @@ extern "C" int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, cons
     if (temp_floats >= full) {
         if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
             return rc;
-        hipLaunchKernelGGL(emd_emit_kernel<false>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match);
+        hipLaunchKernelGGL(emd_emit_kernel<false>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match, (size_t)0,
+                           0x7fffffff);
         MPSR_CHECK_LAUNCH("emd_emit_kernel");
         return MPSR_OK;
     }
@@ -879,7 +918,35 @@ extern "C" int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, cons
                           "approx_match: temp holds %zu floats; needs %zu (b*(n+m)*2, the reference shell's scratch) "
                           "or %zu (mpsr_approx_match_temp_floats, the fast path)",
                           temp_floats, compact, full);
-    // the reference shell's scratch: one ratio slot, match accumulated level by level
+    // The reference shell's scratch (tf_approxmatch.cpp:167-168) cannot hold the ratios of every level -- but the
+    // caller's match block can, until it is written: the state of a cloud goes into the LAST words of its own n*m
+    // block, the passes run exactly as on the fast path, the emit kernel writes the rows in front of the state, and
+    // emd_emit_tail_kernel (one workgroup per cloud, the needed ratios first copied to LDS) the few rows under it.
+    // Same kernels, same arithmetic, same bits as the fast path, and the same single write of match (256 x 2048^2:
+    // 6.7 ms where the level-by-level fallback below needs 27 ms).  Conditions: the state fits behind at least one
+    // full row, its rows fit one tail workgroup (<= kEmitRows rows, L * n floats of LDS).
+    {
+        constexpr int L = Sem<false>::levels;
+        const size_t S = (size_t)(n + m) * (1 + L), block = (size_t)n * m;
+        if (block >= S + (size_t)n) {
+            const int row0 = (int)((block - S) / (size_t)n);
+            const size_t lds = (size_t)L * n * sizeof(float);
+            if (m - row0 <= kEmitRows && lds <= 128 * 1024) {
+                float *state = match + (block - S);  // cloud 0's state; cloud c's is c * block words further
+                if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, state, L, s, [](int) { return 0; }, block)) return rc;
+                hipLaunchKernelGGL(emd_emit_kernel<false>, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)state, match,
+                                   block, row0);
+                MPSR_CHECK_LAUNCH("emd_emit_kernel");
+                MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_emit_tail_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(emd_emit_tail_kernel, dim3(b), dim3(256), lds, s, n, m, xyz1, xyz2, (void *)state,
+                                   match, block, row0);
+                MPSR_CHECK_LAUNCH("emd_emit_tail_kernel");
+                return MPSR_OK;
+            }
+        }
+    }
+    // small or very ragged clouds: one ratio slot in the caller's scratch, match accumulated level by level
     return run_passes<false>(b, n, m, xyz1, xyz2, temp, 1, s, [&](int lev) {
         hipLaunchKernelGGL(emd_accumulate_kernel, grid, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, match, lev);
         return 0;

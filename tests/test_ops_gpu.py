@@ -246,10 +246,14 @@ def test_emd_reference_known_answers_through_hip():
     np.testing.assert_almost_equal(am.emd_loss_fwd_bwd(a, b_)[0].cpu().numpy(), [6.0, 5.196152], decimal=2)
 
 
-@pytest.mark.parametrize("b,n,m", [(2, 40, 40), (2, 12, 4), (3, 257, 513), (1, 2304, 2304)])
+@pytest.mark.parametrize("b,n,m", [(2, 40, 40), (2, 12, 4), (3, 257, 513), (1, 2304, 2304), (2, 64, 2048),
+                                   (5, 2048, 2048), (2, 2048, 1024), (3, 1000, 3000)])
 def test_emd_compact_scratch_is_bit_identical(b, n, m):
     """With the reference op shell's scratch (b*(n+m)*2 floats, tf_approxmatch.cpp:168) the result is the same bit for
-    bit as with the library's own size; less than that is refused (nothing overrun)."""
+    bit as with the library's own size; less than that is refused (nothing overrun).  Covers both forms behind that
+    size: the state kept in the tail of match (40x40, 257x513, 2304^2, 2048^2, 2048x1024, 1000x3000: more than one
+    cloud, so a cloud's state rows border the next cloud's block) and the level-by-level fallback (12x4: block
+    smaller than the state; 64x2048: the state would span 363 rows)."""
     from monopsr_amd import _lib
     from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
     rng = np.random.default_rng(n + m)
