@@ -4,9 +4,11 @@ Method names, arguments, output_dict keys and the order of operations are the re
 layer runs through the HIP fp32-MFMA GEMM (DeviceNet.fully_connected), the per-box scalar algebra (a few flops
 per box) is plain tensor arithmetic on the GPU.  The fused native fast path for the same graph is
 mpsr_heads_fwd (DeviceNet.heads_fwd); tests check that both agree.
-Every output type the reference's methods accept is implemented ('offset' / 'est' / 'gt' / 'direct', alpha
-'dc' / 'dc_rotation' / 'prob' / 'gt', the predicted valid-mask head); monopsr_model_000.yaml uses the first of
-each.  The global maps (:663-772) run through the geometry kernels (datasets/kitti/instance_utils.py); box
+Every output type the reference's methods accept is implemented for the FORWARD path on a DeviceNet ('offset' /
+'est' / 'gt' / 'direct', alpha 'dc' / 'dc_rotation' / 'prob' / 'gt', the predicted valid-mask head);
+monopsr_model_000.yaml uses the first of each, and that set is what trains: on a TrainNet (core/train_net.py) a
+variant that needs a layer outside monopsr_model_000's set raises InvalidArgumentError instead of running without
+gradients (tests/test_output_variants_gpu.py).  The global maps (:663-772) run through the geometry kernels (datasets/kitti/instance_utils.py); box
 rescoring (:805-860) is fused into mpsr_format_boxes (MonoPSRModel.format_predictions).
 """
 import math
@@ -109,6 +111,13 @@ class MonoPSROutputBuilder:
         from monopsr_amd.core import device_net
         output_key = constants.KEY_VALID_MASK_MAPS
         name = 'output/' + output_key + '/' + output_key
+        if self.net is not None and not hasattr(self.net, '_weights'):
+            from monopsr_amd import _lib
+            raise _lib.InvalidArgumentError(
+                'the predicted valid-mask head is inference-only: %s holds no trainable layer for %r (its '
+                'convolution has no gradient path and its weights are outside the flat parameter buffer); build the '
+                'model on a DeviceNet, or drop valid_mask_maps from output_config for training'
+                % (type(self.net).__name__, name))
         if self.net is None or name + '/weights' not in self.net._weights:
             raise ValueError('no weights for the predicted valid-mask head', name)
         if name not in self.net._fc_cache:

@@ -149,7 +149,15 @@ class TrainNet:
         return ops.max_pool(x, k, s, padding)
 
     def fully_connected(self, x, name, relu):
-        """Differentiable slim.fully_connected `name` (used by MonoPSROutputBuilder in training mode)."""
+        """Differentiable slim.fully_connected `name` (used by MonoPSROutputBuilder in training mode).  The flat
+        parameter buffer holds the FC layers of monopsr_model_000's output set (core/weights.head_fc_specs); the
+        other output types of the builder (alpha 'dc_rotation' with its own variable, view_ang 'offset', cen_z
+        'direct', the predicted valid mask) are inference-only: asking for them here is an error, not a silent
+        layer without gradients."""
+        if name not in self.fc_index:
+            raise _lib.InvalidArgumentError(
+                "TrainNet has no trainable layer %r: it trains the output set of monopsr_model_000.yaml (%s); the "
+                "output builder's other variants are inference-only (DeviceNet)" % (name, ", ".join(self.fc_index)))
         idx, fin = self.fc_index[name]
         L = self.layers[idx]
         L.relu = bool(relu)

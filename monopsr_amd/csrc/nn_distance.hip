@@ -277,14 +277,10 @@ extern "C" int mpsr_nn_distance_bwd(int b, int n, const float *xyz1, int m, cons
     hipStream_t s = mpsr::as_stream(stream);
     const size_t lds = sizeof(float) * 3 * ((size_t)n + m);
     if (lds <= kGradLdsLimit) {
-        // raise the kernel's dynamic-LDS cap once per process (thread-safe; the status is remembered)
-        static std::once_flag once;
-        static hipError_t attr_status = hipSuccess;
-        std::call_once(once, [] {
-            attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(nn_grad_lds_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLdsLimit);
-        });
-        MPSR_CHECK_HIP(attr_status);
+        // raise the kernel's dynamic-LDS cap (per call: the attribute belongs to the current device, the call is
+        // cheap and idempotent, and a process may use several GPUs)
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_grad_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLdsLimit));
         const int big = n > m ? n : m;
         const int threads = big >= 1024 ? 1024 : (big > 256 ? 512 : 256);
         hipLaunchKernelGGL(nn_grad_lds_kernel, dim3(b), dim3(threads), lds, s, n, xyz1, m, xyz2, grad_dist1, idx1,

@@ -640,17 +640,11 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
     if (ws_floats < winograd_scratch_floats(C, N) || !ws)
         return fail(MPSR_ERR_WORKSPACE, "conv3x3_winograd: scratch holds %zu floats, needs %zu", ws_floats,
                     winograd_scratch_floats(C, N));
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float)));
-        if (attr_status == hipSuccess)
-            attr_status = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv8_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(kLdsFloats * sizeof(float)));
-    });
-    MPSR_CHECK_HIP(attr_status);
+    // (per call: the attribute belongs to the current device; cheap and idempotent)
+    MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g_wino_waves.load() == 8
+                                                                          ? reinterpret_cast<const void *>(wino_conv8_kernel)
+                                                                          : reinterpret_cast<const void *>(wino_conv_kernel)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
     {
         const long long total = (long long)N * C;
         hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
