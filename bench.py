@@ -554,7 +554,9 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         losses += vals
         out.update({"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch / dt, 1)})
     out["loss_per_step"] = [round(v, 1) for v in losses]
-    out["note"] = "random-initialised weights and synthetic targets: the first Adam steps are a transient"
+    out["note"] = ("random-initialised weights and synthetic targets: the first Adam steps are a transient (every "
+                   "parameter moves by the learning rate whatever its gradient); the list is the loss of every step "
+                   "run, warm-up included")
     return out
 
 
@@ -951,7 +953,9 @@ def main():
             try:
                 tb = args.train_batch or args.batch
                 tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
-                ts = training_step_object(device, tb, tinp, dist=dist if multi else None, red_dev=red_dev)
+                # N = 1: 2 + 18 steps, so that the line shows the loss past the first Adam steps' transient
+                ts = training_step_object(device, tb, tinp, steps=6 if multi else 18, dist=dist if multi else None,
+                                          red_dev=red_dev)
                 result["training_step"] = ts
             except Exception as e:
                 result["training_step"] = {"error": repr(e)}
