@@ -316,6 +316,95 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float *__rest
     }
 }
 
+// The same layer on the matrix pipes, for N <= 3 (the xyz head itself): taps go into the GEMM's N.  With
+//     G[p][3 t + o] = sum_c x[p][c] * w[o][t][c]            (a 1x1 GEMM: K = C, N = 9 taps x 3 outputs = 27 <= 32)
+// the convolution is y[p][o] = bias[o] + sum_t G[p + delta_t][3 t + o]: a 27-wide v_mfma_f32_32x32x2_f32 tile wastes
+// 5/32 instead of 29/32, the input is read ONCE (no 18x18 halo re-staging: a workgroup takes R + 2 full-width image
+// rows, 1.25x at R = 8), and the tap sum is a 9-term LDS gather.  The weights live in registers as B fragments for the
+// whole kernel (16 x 16 bytes per lane at C = 128); A fragments come straight from global memory in fragment layout
+// (lane = pixel row x k half, 16 bytes: 32-byte runs per pixel, both halves of a 64-byte line by consecutive
+// requests) -- nothing but G goes through LDS.  grid (ceil(H / R), B), 256 threads, dynamic LDS (R+2) * W * 27 floats.
+constexpr int kNarrowRows = 8;
+using nf32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int KB>  // K blocks of 8 channels held as B fragments (C = 8 * KB)
+__global__ __launch_bounds__(256) void conv3x3_narrow_mfma_kernel(const float *__restrict__ x, int H, int W,
+                                                                  const float *__restrict__ w,
+                                                                  const float *__restrict__ bias, int relu, int nout,
+                                                                  float *__restrict__ y, unsigned xbytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float g[];  // [(R+2) * W pixels][27]
+    constexpr int C = 8 * KB;
+    const int b = blockIdx.y, y0 = blockIdx.x * kNarrowRows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = (kNarrowRows + 2) * W;  // pixels of rows y0 - 1 .. y0 + R, row-major
+    // B fragments: lane (n = lane & 31, k half = lane >> 5) holds W'[n][8 j + 4 h .. + 3], W'[3 t + o][c] = w[o][t][c]
+    float4 bf[KB];
+    {
+        const int n = lane & 31, t = n / 3, o = n - 3 * t;
+        const bool live = n < 9 * 3 && o < nout;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            bf[j] = live ? *reinterpret_cast<const float4 *>(w + (size_t)o * 9 * C + (size_t)t * C + 8 * j + 4 * (lane >> 5))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)xbytes, 0x00020000);
+    const int ntiles = (P + 31) / 32;
+    for (int rt = wave; rt < ntiles; rt += 4) {
+        // this lane's pixel: p = 32 rt + (lane & 31) -> image row y0 - 1 + p / W; rows outside the image and pixels past
+        // P read as zeros (out-of-range offset), so their G is exactly 0
+        const int pix = 32 * rt + (lane & 31);
+        const int py = pix / W, gy = y0 - 1 + py;
+        const bool ok = pix < P && gy >= 0 && gy < H;
+        const unsigned off = ok ? (unsigned)((((size_t)b * H + gy) * W + (pix - py * W)) * C + 4 * (lane >> 5)) * 4u : 0x80000000u;
+        nf32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        float4 a[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            a[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, (unsigned)j * 32u, 0));
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, bf[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, bf[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, bf[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, bf[j].w, acc, 0, 0, 0);
+        }
+        // accumulator element e of a lane: pixel row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile, column n = lane & 31
+        const int n = lane & 31;
+        if (n < 27) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (pr < P) g[pr * 27 + n] = acc[e];
+            }
+        }
+    }
+    __syncthreads();
+    // tap sum: output pixel (y0 + r, xx) reads G of tile row r + ky (ky = 0..2), column xx + kx - 1
+    const int nrows = min(kNarrowRows, H - y0);
+    for (int i = tid; i < nrows * W; i += 256) {
+        const int r = i / W, xx = i - r * W;
+        float out[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = xx + kx - 1;
+                if (sx < 0 || sx >= W) continue;
+                const float *src = g + ((r + ky) * W + sx) * 27 + 3 * (ky * 3 + kx);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) out[o] += src[o];
+            }
+        float *dst = y + (((size_t)b * H + y0 + r) * W + xx) * nout;
+        for (int o = 0; o < nout; ++o) {
+            const float v = out[o] + (bias ? bias[o] : 0.f);
+            dst[o] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 }  // namespace
 
 namespace mpsr {
@@ -323,6 +412,33 @@ namespace mpsr {
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s)
 {
+    // N <= 3 with C = 32 .. 128: the GEMM-with-taps-in-N kernel on the matrix pipes (above)
+    {
+        const size_t lds = (size_t)(kNarrowRows + 2) * W * 27 * sizeof(float);
+        const long long xb = (long long)B * H * W * C * 4;
+        if (N <= 3 && C % 8 == 0 && C >= 32 && C <= 128 && lds <= 64 * 1024 && B <= 65535 && xb < 0x7fffffffLL &&
+            ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+            const dim3 grid(ceil_div(H, kNarrowRows), B);
+#define MPSR_NARROW(KB_)                                                                                              \
+    {                                                                                                                 \
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_narrow_mfma_kernel<KB_>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL(conv3x3_narrow_mfma_kernel<KB_>, grid, dim3(256), lds, s, x, H, W, w, bias, relu, N, y,     \
+                           (unsigned)xb);                                                                              \
+    }
+            switch (C / 8) {
+                case 4: MPSR_NARROW(4); break;
+                case 8: MPSR_NARROW(8); break;
+                case 12: MPSR_NARROW(12); break;
+                case 16: MPSR_NARROW(16); break;
+                default: goto direct;
+            }
+#undef MPSR_NARROW
+            MPSR_CHECK_LAUNCH("conv3x3_narrow_mfma_kernel");
+            return MPSR_OK;
+        }
+    }
+direct:
     dim3 grid(ceil_div(W, kNarrowTile), ceil_div(H, kNarrowTile), B);
     if (grid.z > 65535) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: batch %d exceeds 65535", B);
     switch (N) {
