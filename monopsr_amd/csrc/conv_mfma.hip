@@ -1189,7 +1189,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         // better; the wide 1x1 layers among them (block3 conv1 / shortcut, squash: C >= 512, N a multiple of 128)
         // take 96x128 tiles -- 3 per CU, all resident at once, 40 % less L2 -> LDS traffic per multiply-add
         if (N <= 32) sel = 4;
-        else if (p.M >= 131072) sel = 0;
+        else if (p.M >= 131072) sel = N <= 64 ? 1 : 0;  // (N = 64: the root conv over im2col rows, 38 vs 66 us)
         else if (KH == 1 && KW == 1 && C >= 512 && N >= 256 && N % 128 == 0 && p.M >= 24576 && math == MATH_FP32) sel = 5;
         else sel = 3;
         // bf16x3: 3 bf16 matrix instructions replace 8 fp32 ones at 1/16 of the cycles each, so LDS and the operand
