@@ -22,4 +22,7 @@ python3 tools/pmc_summary.py $OUT/p*/pmc_counter_collection.csv > $OUT/${TAG}_pm
 python3 tools/pmc_reduce.py $TAG $COMMIT $OUT/p*/pmc_counter_collection.csv > $OUT/${TAG}_pmc_traffic.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ops -o ops -- python3 tools/ops_bench.py > $OUT/${TAG}_ops_bench.json 2> $OUT/ops.err || echo "ops pass failed"
 cp $OUT/ops/*kernel_stats.csv $OUT/${TAG}_ops_kernel_stats.csv 2>/dev/null
+# the vendor fp32 GEMM on the heavy layers' im2col shapes and this library's per-layer table, at the same commit
+timeout 300 python3 tools/gemm_reference.py > $OUT/${TAG}_vendor_gemm_reference.txt 2> $OUT/gemm.err || echo "gemm reference failed"
+timeout 300 python3 tools/conv_layer_bench.py --tiles=-1 --split 0 --rounds 3 > $OUT/${TAG}_layers.txt 2> $OUT/layers.err || echo "layer table failed"
 cat $OUT/${TAG}_pmc_traffic.json
