@@ -454,6 +454,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
+// FETCH_SIZE calibration (tools/fetch_calibration.sh): stream a buffer exactly once, MODE 0 with 16 bytes per lane
+// fully coalesced (the pattern MI355X_MICROARCH.md calibrates: the counter reports half the bytes), MODE 1 with this
+// file's patch-request pattern -- 4 bytes per lane, 8 lanes = one 32-byte run, 8 runs 256 bytes apart per instruction,
+// the rest of each 256-byte row by the following instructions.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256) void w4_fetch_calibration_kernel(const float *__restrict__ p, size_t floats,
+                                                                   float *__restrict__ sink)
+{
+    float acc = 0.f;
+    if (MODE == 0) {
+        const float4 *q = reinterpret_cast<const float4 *>(p);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < floats / 4; i += (size_t)gridDim.x * 256) {
+            const float4 v = q[i];
+            acc += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        const int lane = threadIdx.x & 63, tl = lane >> 3, ch = lane & 7;
+        const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+        for (size_t blk = wave; blk * 512 + 512 <= floats; blk += nwaves)  // 8 rows x 64 floats per block
+#pragma unroll
+            for (int chunk = 0; chunk < 8; ++chunk) acc += p[blk * 512 + (size_t)tl * 64 + chunk * 8 + ch];
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+}  // namespace
+extern "C" int mpsr_debug_fetch_calibration(const float *p, size_t floats, int mode, float *sink, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(p && sink && floats >= 512 && (mode == 0 || mode == 1), "fetch_calibration: bad arguments");
+    if (mode == 0)
+        hipLaunchKernelGGL(w4_fetch_calibration_kernel<0>, dim3(4096), dim3(256), 0, mpsr::as_stream(stream), p, floats, sink);
+    else
+        hipLaunchKernelGGL(w4_fetch_calibration_kernel<1>, dim3(4096), dim3(256), 0, mpsr::as_stream(stream), p, floats, sink);
+    MPSR_CHECK_LAUNCH("w4_fetch_calibration_kernel");
+    return MPSR_OK;
+}
+
 static unsigned long long *g_wino4_trace = nullptr;
 extern "C" void mpsr_debug_set_wino4_trace(void *buf) { g_wino4_trace = static_cast<unsigned long long *>(buf); }
 
