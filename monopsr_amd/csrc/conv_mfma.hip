@@ -1089,7 +1089,7 @@ int launch_sk(ConvParams &p, int B, bool use_classes, int mode, bool counters_cl
 namespace mpsr {
 
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
-                   int N, hipStream_t s);  // image_ops.hip
+                   int N, hipStream_t s, int in_c8);  // image_ops.hip
 // winograd.hip
 size_t winograd_scratch_floats(int C, int N);
 bool winograd_applies(int H, int W, int C, int N);
@@ -1099,7 +1099,7 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
 size_t winograd4_scratch_floats(int C, int N);
 bool winograd4_applies(int H, int W, int C, int N);
 int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s);
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8);
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
@@ -1131,6 +1131,16 @@ int auto_split_k(int M, int N, int ksteps, const float *ws, size_t ws_floats)
     return s < 1 ? 1 : (int)s;
 }
 
+// True when conv2d() with split_k = 0 would send this 3x3 layer to the F(4x4,3x3) kernel (network.hip asks before it
+// lays the decoder's internal tensors out channel-blocked, which only that kernel reads).
+bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, size_t ws_floats)
+{
+    const long long M64 = (long long)B * H * W;
+    const int wino = g_wino_override.load();
+    return ws && (wino < 0 || wino == 2) && g_tile_override.load() < 0 && M64 >= 65536 && C >= 64 && N >= 64 &&
+           winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
+}
+
 // Shared by the network-level entry points (network.hip).
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
@@ -1152,7 +1162,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // tile (an explicit tile override keeps them on the MFMA path so tests cover both)
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
         g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
-        return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream);
+        return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream, 0);
     // the big dense 3x3 layers (map decoder) go to a Winograd kernel when the caller leaves the schedule to the
     // library: F(4x4,3x3) (winograd4.hip, 4x fewer multiply-adds) where the map divides into 4x4 blocks, else
     // F(2x2,3x3) (winograd.hip, 2.25x fewer)
@@ -1167,7 +1177,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
                           M64 * C * 4 < 0x7f000000LL;
         if (wino < 0)
             wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? (can4 ? 2 : 1) : 0;
-        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0);
         if (wino >= 1 && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
     ConvParams p;

@@ -124,6 +124,34 @@ __global__ __launch_bounds__(256) void resize_bilinear_rows_kernel(const float *
     reinterpret_cast<T *>(out)[((size_t)b * OH + oy) * OW * cv + idx] = lerp4(lerp4(tl, tr, xl), lerp4(bl, br, xl), yl);
 }
 
+// NHWC in, channel-blocked out ([B][C/8][OH][OW][8], the layout the decoder's Winograd kernels read: network.hip).
+// Thread = one output pixel x 8 channels, lanes run along the output row: a wave writes 32-byte pieces that are
+// contiguous in memory (the 4x larger side of the traffic); the reads are 32-byte pieces of the small, L2-resident
+// source.  Same arithmetic as the kernels above.  grid (ceil(C/8 * OW / 256), OH, B).
+__global__ __launch_bounds__(256) void resize_bilinear_c8out_kernel(const float *__restrict__ in, int H, int W, int C,
+                                                                    int OH, int OW, float hscale, float wscale,
+                                                                    float *__restrict__ out)
+{
+    const unsigned planes = (unsigned)C / 8u;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= planes * (unsigned)OW) return;
+    const unsigned plane = idx / (unsigned)OW, ox = idx - plane * (unsigned)OW;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const float sy = (float)oy * hscale, sx = (float)ox * wscale;
+    const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float yl = sy - (float)y0, xl = sx - (float)x0;
+    const float4 *base = reinterpret_cast<const float4 *>(in + (size_t)b * H * W * C) + plane * 2;
+    const size_t cv = (size_t)C / 4;
+    float4 *dst = reinterpret_cast<float4 *>(out + ((((size_t)b * planes + plane) * OH + oy) * OW + ox) * 8);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 tl = base[((size_t)y0 * W + x0) * cv + h], tr = base[((size_t)y0 * W + x1) * cv + h];
+        const float4 bl = base[((size_t)y1 * W + x0) * cv + h], br = base[((size_t)y1 * W + x1) * cv + h];
+        dst[h] = lerp4(lerp4(tl, tr, xl), lerp4(bl, br, xl), yl);
+    }
+}
+
 // slim.max_pool2d; pad_top/pad_left are the SAME-padding offsets (0 for VALID); padded cells never win.
 template <int V>
 __global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__ in, int H, int W, int C, int OH,
@@ -259,6 +287,23 @@ extern "C" int mpsr_resize_bilinear(const float *in, int B, int H, int W, int C,
     return MPSR_OK;
 }
 
+namespace mpsr {
+// tf.image.resize_bilinear with the output written channel-blocked (see resize_bilinear_c8out_kernel); C % 8 == 0.
+int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
+                       hipStream_t s)
+{
+    MPSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && OH > 0 && OW > 0 && B <= 65535 && OH <= 65535 && in &&
+                     out && aligned16(in) && aligned16(out),
+                 "resize_bilinear_c8: bad arguments");
+    const float hscale = (align_corners && OH > 1) ? (float)(H - 1) / (float)(OH - 1) : (float)H / (float)OH;
+    const float wscale = (align_corners && OW > 1) ? (float)(W - 1) / (float)(OW - 1) : (float)W / (float)OW;
+    const dim3 grid((unsigned)ceil_div((C / 8) * OW, 256), (unsigned)OH, (unsigned)B);
+    hipLaunchKernelGGL(resize_bilinear_c8out_kernel, grid, dim3(256), 0, s, in, H, W, C, OH, OW, hscale, wscale, out);
+    MPSR_CHECK_LAUNCH("resize_bilinear_c8out_kernel");
+    return MPSR_OK;
+}
+}  // namespace mpsr
+
 extern "C" int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s_, int pad_same, float *out,
                              mpsr_stream_t stream)
 {
@@ -388,7 +433,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float *__rest
 constexpr int kNarrowRows = 8;
 using nf32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int KB>  // K blocks of 8 channels held as B fragments (C = 8 * KB)
+template <int KB, bool IN_C8>  // K blocks of 8 channels held as B fragments (C = 8 * KB); input NHWC or [C/8][H][W][8]
 __global__ __launch_bounds__(256) void conv3x3_narrow_mfma_kernel(const float *__restrict__ x, int H, int W,
                                                                   const float *__restrict__ w,
                                                                   const float *__restrict__ bias, int relu, int nout,
@@ -417,14 +462,18 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_mfma_kernel(const float *_
         const int pix = 32 * rt + (lane & 31);
         const int py = pix / W, gy = y0 - 1 + py;
         const bool ok = pix < P && gy >= 0 && gy < H;
-        const unsigned off = ok ? (unsigned)((((size_t)b * H + gy) * W + (pix - py * W)) * C + 4 * (lane >> 5)) * 4u : 0x80000000u;
+        // (C8: the 32 pixels of a tile are 32 x 32 contiguous bytes per K block -- one request = 1 KiB contiguous)
+        const unsigned off = !ok ? 0x80000000u
+                             : IN_C8 ? (unsigned)((((size_t)b * KB * H + gy) * W + (pix - py * W)) * 8 + 4 * (lane >> 5)) * 4u
+                                     : (unsigned)((((size_t)b * H + gy) * W + (pix - py * W)) * C + 4 * (lane >> 5)) * 4u;
+        const unsigned kstride = IN_C8 ? (unsigned)H * (unsigned)W * 32u : 32u;  // bytes between K blocks
         nf32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         float4 a[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j)
-            a[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, (unsigned)j * 32u, 0));
+            a[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, (unsigned)j * kstride, 0));
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, bf[j].x, acc, 0, 0, 0);
@@ -471,7 +520,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_mfma_kernel(const float *_
 namespace mpsr {
 // Used by conv2d() for 3x3, dilation 1, N <= 4, C % 32 == 0 layers without residual.
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
-                   int N, hipStream_t s)
+                   int N, hipStream_t s, int in_c8)
 {
     // N <= 3 with C = 32 .. 128: the GEMM-with-taps-in-N kernel on the matrix pipes (above)
     {
@@ -481,11 +530,16 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
             ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
             const dim3 grid(ceil_div(H, kNarrowRows), B);
 #define MPSR_NARROW(KB_)                                                                                              \
-    {                                                                                                                 \
-        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_narrow_mfma_kernel<KB_>),             \
+    if (in_c8) {                                                                                                      \
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_narrow_mfma_kernel<KB_, true>),       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL(conv3x3_narrow_mfma_kernel<KB_>, grid, dim3(256), lds, s, x, H, W, w, bias, relu, N, y,     \
-                           (unsigned)xb);                                                                              \
+        hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<KB_, true>), grid, dim3(256), lds, s, x, H, W, w, bias, relu,   \
+                           N, y, (unsigned)xb);                                                                        \
+    } else {                                                                                                          \
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_narrow_mfma_kernel<KB_, false>),      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<KB_, false>), grid, dim3(256), lds, s, x, H, W, w, bias, relu,  \
+                           N, y, (unsigned)xb);                                                                        \
     }
             switch (C / 8) {
                 case 4: MPSR_NARROW(4); break;
@@ -500,6 +554,7 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
         }
     }
 direct:
+    if (in_c8) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: a channel-blocked input needs N <= 3, C = 32..128");
     dim3 grid(ceil_div(W, kNarrowTile), ceil_div(H, kNarrowTile), B);
     if (grid.z > 65535) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: batch %d exceeds 65535", B);
     switch (N) {

@@ -11,7 +11,20 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
            hipStream_t stream);
 size_t conv_scratch_floats(long long M, int N);
+bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, size_t ws_floats);
+int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8);
+int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
+                   int N, hipStream_t s, int in_c8);
+int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
+                       hipStream_t s);
 }
+
+#include <atomic>
+// 1 (default): the map decoder's internal tensors are channel-blocked whenever all four of its 3x3 layers go to the
+// F(4x4,3x3) kernel; 0: NHWC throughout (tests compare the two bit for bit)
+static std::atomic<int> g_decoder_c8{1};
+extern "C" void mpsr_debug_set_decoder_c8(int on) { g_decoder_c8 = on; }
 
 namespace {
 
@@ -184,6 +197,41 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
     if ((rc = run_layer(blob, L[0], crop_feat, B, fh, fw, nullptr, part, 0, sk, skn, s))) return rc;
     if ((rc = run_layer(blob, L[1], full_feat, B, fh, fw, part, sq, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(sq, B, fh, fw, csq, 2, 2, 0, feat_box3d, stream))) return rc;
+    // Channel-blocked internal tensors ([C/8][H][W][8], "C8") when all four 3x3 layers run on the F(4x4,3x3) kernel: a
+    // K step of that kernel then reads whole 128-byte lines instead of 32 bytes of every pixel's line (NHWC re-fetched
+    // the lines from beyond L2: 1.87x the layers' own bytes, profiles/r03_*), and the xyz head's A loads become 1 KiB
+    // contiguous.  Layouts: r1, a, r2, c are C8; b (the input of the second resize) and a requested feat_map are NHWC.
+    // Same kernels, same arithmetic order: bit-identical to the NHWC chain (tests/test_net_gpu.py).
+    const bool xyz_c8 = !feat_map && xyz_map && L[6].cout <= 3 && L[6].cin % 8 == 0 && L[6].cin >= 32 && L[6].cin <= 128 &&
+                        (size_t)10 * mw * 27 * sizeof(float) <= 64 * 1024 && L[6].kh == 3 && L[6].dilation == 1;
+    const bool c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 &&
+                    L[2].kh == 3 && L[3].kh == 3 && L[4].kh == 3 && L[5].kh == 3 && L[2].dilation == 1 &&
+                    L[3].dilation == 1 && L[4].dilation == 1 && L[5].dilation == 1 &&
+                    mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn) &&
+                    mpsr::conv2d_takes_winograd4(B, hh, hw, L[3].cin, L[3].cout, sk, skn) &&
+                    mpsr::conv2d_takes_winograd4(B, mh, mw, L[4].cin, L[4].cout, sk, skn) &&
+                    mpsr::conv2d_takes_winograd4(B, mh, mw, L[5].cin, L[5].cout, sk, skn);
+    if (c8) {
+        auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
+            return mpsr::conv3x3_winograd4(x, B, H, W, Lr.cin, blob + Lr.w_off, Lr.b_off >= 0 ? blob + Lr.b_off : nullptr,
+                                           Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8);
+        };
+        if ((rc = mpsr::resize_bilinear_c8(sq, B, fh, fw, csq, hh, hw, 1, r1, s))) return rc;
+        if ((rc = wino(L[2], r1, hh, hw, a, 1, 1))) return rc;
+        if ((rc = wino(L[3], a, hh, hw, b, 1, 0))) return rc;
+        if ((rc = mpsr::resize_bilinear_c8(b, B, hh, hw, c2, mh, mw, 1, r2, s))) return rc;
+        if ((rc = wino(L[4], r2, mh, mw, c, 1, 1))) return rc;
+        if ((rc = wino(L[5], c, mh, mw, fm, 1, xyz_c8 ? 1 : 0))) return rc;
+        if (xyz_map) {
+            if (xyz_c8)
+                rc = mpsr::conv3x3_narrow(fm, B, mh, mw, L[6].cin, blob + L[6].w_off,
+                                          L[6].b_off >= 0 ? blob + L[6].b_off : nullptr, L[6].relu, xyz_map, L[6].cout, s, 1);
+            else
+                rc = run_layer(blob, L[6], fm, B, mh, mw, nullptr, xyz_map, 1, nullptr, 0, s);
+            if (rc) return rc;
+        }
+        return MPSR_OK;
+    }
     if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
     if ((rc = run_layer(blob, L[2], r1, B, hh, hw, nullptr, a, 0, sk, skn, s))) return rc;
     if ((rc = run_layer(blob, L[3], a, B, hh, hw, nullptr, b, 0, sk, skn, s))) return rc;

@@ -130,6 +130,10 @@ using IC = std::integral_constant<int, V>;
 #define W4_APRE 0  // 1: read the next unit's A fragments during the current unit (12 more registers)
 #endif
 
+// IN_C8 / OUT_C8: the tensor is channel-blocked, [B][C/8][H][W][8] ("C8"), instead of NHWC.  A K step then reads
+// whole 128-byte lines (4 pixels x 8 channels) instead of 32 bytes out of every pixel's line: the decoder's internal
+// tensors use it (network.hip), the generic mpsr_conv2d_nhwc_f32 path does not.
+template <bool IN_C8, bool OUT_C8>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_kernel(const Wino4Params p)
 {
     using namespace f4;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- A producer: thread = (tile, channel of the step)
     const int lt = 8 * (wave & 3) + (lane >> 3), ch = lane & 7;
     // descriptor moved back by one row + one pixel so that the per-thread base offset is never negative
-    const unsigned shift = (unsigned)(p.W + 1) * (unsigned)p.C * 4u;
+    const unsigned shift = (unsigned)(p.W + 1) * (IN_C8 ? 8u : (unsigned)p.C) * 4u;
     char *xback = const_cast<char *>(reinterpret_cast<const char *>(p.x)) - shift;
     // Only the ring of a 6x6 patch can leave the image (row 0 / 5, column 0 / 5): nine distinct per-thread byte
     // offsets (this thread's pixel (0,0) of the patch, or an out-of-range value) cover the 36 requests; the pixel
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ty = rem / p.tw, tx = rem - ty * p.tw;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
         // (+ shift, i.e. relative to the moved-back descriptor this is the offset of pixel (y0, x0))
-        const unsigned abase = (unsigned)(((img * p.H + y0 + 1) * p.W + x0 + 1) * p.C + ch) * 4u;
+        const unsigned abase = IN_C8 ? (unsigned)(((img * (p.C / 8) * p.H + y0 + 1) * p.W + x0 + 1) * 8 + ch) * 4u
+                                     : (unsigned)(((img * p.H + y0 + 1) * p.W + x0 + 1) * p.C + ch) * 4u;
         const bool in = t < p.T;
         const bool rowc[3] = {in && y0 >= 0, in, in && y0 + 5 < p.H};
         const bool colc[3] = {x0 >= 0, true, x0 + 5 < p.W};
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (a request past the last channel block goes through a zero-length descriptor: a scalar select)
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(xback, 0, live ? (int)(p.xbytes + shift) : 0, 0x00020000);
-        const unsigned so = (unsigned)((r * p.W + s) * p.C + (live ? step : 0) * KC) * 4u;
+        const unsigned so = IN_C8 ? (unsigned)(((live ? step : 0) * p.H + r) * p.W + s) * 32u
+                                  : (unsigned)((r * p.W + s) * p.C + (live ? step : 0) * KC) * 4u;
         pa[6 * r + s] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rr, voffc[r == 0 ? 0 : r == 5 ? 2 : 1][s == 0 ? 0 : s == 5 ? 2 : 1],
                                                         so, 0));
@@ -429,7 +435,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             const int n = n0 + (tid2 & 31) + 32 * h;
             const bool ok = tt < p.T && n < p.N;
-            float *o = p.y + ((size_t)(img * p.H + 4 * ty) * p.W + 4 * tx) * p.N + n;
+            // NHWC: 64 channels x 4 bytes contiguous per pixel; C8: 32-byte runs, the four pixels of a tile row complete
+            // a 128-byte line over four consecutive stores
+            const size_t pstride = OUT_C8 ? 8 : (size_t)p.N;
+            float *o = OUT_C8 ? p.y + (((size_t)(img * (p.N / 8) + n / 8) * p.H + 4 * ty) * p.W + 4 * tx) * 8 + (n & 7)
+                              : p.y + ((size_t)(img * p.H + 4 * ty) * p.W + 4 * tx) * p.N + n;
 #pragma unroll
             for (int xx = 0; xx < 4; ++xx) {
                 float yv[4];
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int yy = 0; yy < 4; ++yy) {
                     float v = yv[yy] + bias2[h];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (ok) o[((size_t)yy * p.W + xx) * p.N] = v;
+                    if (ok) o[((size_t)yy * p.W + xx) * pstride] = v;
                 }
             }
         }
@@ -505,10 +515,11 @@ bool winograd4_applies(int H, int W, int C, int N)
 }
 
 int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s)
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8)
 {
     using namespace f4;
     MPSR_REQUIRE(winograd4_applies(H, W, C, N), "conv3x3_winograd4: needs H, W multiples of 4 and C %% 16 == 0");
+    MPSR_REQUIRE(!out_c8 || N % 8 == 0, "conv3x3_winograd4: a channel-blocked output needs N %% 8 == 0 (N=%d)", N);
     if (ws_floats < winograd4_scratch_floats(C, N) || !ws)
         return fail(MPSR_ERR_WORKSPACE, "conv3x3_winograd4: scratch holds %zu floats, needs %zu", ws_floats,
                     winograd4_scratch_floats(C, N));
@@ -516,8 +527,11 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
     MPSR_REQUIRE(xbytes + (long long)(W + 1) * C * 4 < 0x7ff00000LL && winograd4_scratch_floats(C, N) * 4 < 0x7ff00000ULL,
                  "conv3x3_winograd4: tensor exceeds the 2 GiB this kernel's offsets address; split the batch");
     // (set on every call: cheap, idempotent, and right for whichever device is current)
-    MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
+    const void *kfn = in_c8 ? (out_c8 ? reinterpret_cast<const void *>(wino4_conv_kernel<true, true>)
+                                      : reinterpret_cast<const void *>(wino4_conv_kernel<true, false>))
+                            : (out_c8 ? reinterpret_cast<const void *>(wino4_conv_kernel<false, true>)
+                                      : reinterpret_cast<const void *>(wino4_conv_kernel<false, false>));
+    MPSR_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
     {
         const long long total = (long long)N * C;
         hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
@@ -537,7 +551,11 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
     p.trace = g_wino4_trace;
     const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd4: grid too large");
-    hipLaunchKernelGGL(wino4_conv_kernel, dim3((unsigned)blocks), dim3(512), LDSF * sizeof(float), s, p);
+    const dim3 grid((unsigned)blocks), block(512);
+    if (in_c8 && out_c8) hipLaunchKernelGGL((wino4_conv_kernel<true, true>), grid, block, LDSF * sizeof(float), s, p);
+    else if (in_c8) hipLaunchKernelGGL((wino4_conv_kernel<true, false>), grid, block, LDSF * sizeof(float), s, p);
+    else if (out_c8) hipLaunchKernelGGL((wino4_conv_kernel<false, true>), grid, block, LDSF * sizeof(float), s, p);
+    else hipLaunchKernelGGL((wino4_conv_kernel<false, false>), grid, block, LDSF * sizeof(float), s, p);
     MPSR_CHECK_LAUNCH("wino4_conv_kernel");
     return MPSR_OK;
 }

@@ -140,3 +140,33 @@ def test_a_batch_above_max_chunk():
         assert _rel(f8, feat[lo:lo + 8]) < 2e-5
         _, _, x8 = net.squash_decoder(f8, full[lo:lo + 8].contiguous(), (48, 48), want_feat_map=False)
         assert _rel(x8, xyz[lo:lo + 8]) < 2e-5
+
+
+@pytest.mark.parametrize("want_feat_map", [False, True])
+def test_decoder_channel_blocked_layout_is_bit_identical(want_feat_map):
+    """mpsr_squash_decoder_fwd keeps its internal tensors channel-blocked ([C/8][H][W][8]) when all four 3x3 layers run
+    on the F(4x4,3x3) kernel (network.hip; the batch must be large enough for the library to pick that kernel): same
+    kernels and the same order of arithmetic as the NHWC chain, so every output must agree bit for bit -- with the
+    feature map requested (last conv writes NHWC, xyz head reads NHWC) and without (both channel-blocked)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    lib = _lib.lib()
+    B = 128
+    net = dn.DeviceNet(W.synthetic_weights(seed=3, width_div=2), width_div=2)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    crop = torch.randn((B, 12, 12, 512), device="cuda", generator=g).clamp_(min=0)
+    full = torch.randn((B, 12, 12, 512), device="cuda", generator=g).clamp_(min=0)
+    outs = {}
+    for on in (1, 0):
+        lib.mpsr_debug_set_decoder_c8(on)
+        try:
+            outs[on] = [t.clone() if t is not None else None
+                        for t in net.squash_decoder(crop, full, (48, 48), want_feat_map=want_feat_map)]
+        finally:
+            lib.mpsr_debug_set_decoder_c8(1)
+    for a, b in zip(outs[1], outs[0]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert float(outs[1][2].abs().max()) > 0
