@@ -126,6 +126,9 @@ using IC = std::integral_constant<int, V>;
 #ifndef W4_SPREAD
 #define W4_SPREAD 0
 #endif
+#ifndef W4_BPRE
+#define W4_BPRE 1  // B fragments requested this many units (of 12 MFMAs) ahead: 1 (two register sets) or 2 (three)
+#endif
 #ifndef W4_APRE
 #define W4_APRE 0  // 1: read the next unit's A fragments during the current unit (12 more registers)
 #endif
@@ -252,8 +255,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned bvoff =
         n0 + 32 * nh + (lane & 31) < p.N ? (unsigned)((n0 + 32 * nh + (lane & 31)) * KC + 4 * (lane >> 5)) * 4u : OOB;
     const unsigned bpstride = (unsigned)p.N * KC * 4u;  // bytes between positions of one channel block
-    float4 fb[2][3];
+    float4 fb[1 + W4_BPRE][3];
     auto load_b1 = [&](int step, int u, int j, int set) __attribute__((always_inline)) {
+#ifdef W4_SKIP_BLOAD
+        if (step > 0) return;
+#endif
         const bool live = step < nsteps;
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
@@ -287,8 +293,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         W4_STAMP((s >> 1) == 4);  // steps 8 and 9: step start, after each unit, after the barrier
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const int bpar = (3 * buf + u) & 1;
-            const int aset = W4_APRE ? bpar : 0;
+            // register set of this unit's B fragments: distance 1 -> the two sets alternate unit by unit (3 units per
+            // step, two steps per loop trip); distance 2 -> unit u always uses set u
+            const int bpar = W4_BPRE == 2 ? u : (3 * buf + u) & 1;
+            const int aset = W4_APRE ? ((3 * buf + u) & 1) : 0;
             if (!W4_APRE || u == 0) read_a(buf, u, aset);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -300,8 +308,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float bv = k == 0 ? fb[bpar][j].x : k == 1 ? fb[bpar][j].y : k == 2 ? fb[bpar][j].z : fb[bpar][j].w;
                     acc[3 * u + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[3 * u + j], 0, 0, 0);
                     if (k == 0) {
-                        if (u < 2) load_b1(s, u + 1, j, bpar ^ 1);
-                        else load_b1(s + 1, 0, j, bpar ^ 1);
+                        if (W4_BPRE == 2) {  // unit u + 2 (of this step or the next) into the set unit u - 1 just left
+                            if (u == 0) load_b1(s, 2, j, 2);
+                            else load_b1(s + 1, u - 1, j, u - 1);
+                        } else {
+                            if (u < 2) load_b1(s, u + 1, j, bpar ^ 1);
+                            else load_b1(s + 1, 0, j, bpar ^ 1);
+                        }
                     }
                     if (W4_APRE && k == 2 && j == 0 && u < 2) read_a(buf, u + 1, aset ^ 1);
                     duty(m);
@@ -347,6 +360,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- prologue: B of (step 0, unit 0); A of step 0 by waves 0-3; the patch of step 1 requested by waves 4-7
 #pragma unroll
     for (int j = 0; j < 3; ++j) load_b1(0, 0, j, 0);
+    if (W4_BPRE == 2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_b1(0, 1, j, 1);
 #pragma unroll
     for (int i = 0; i < 36; ++i) load_patch1(dgrp, i);
     if (dgrp == 0) {
