@@ -644,12 +644,14 @@ def rendezvous_only(rank, world):
     from monopsr_amd.core.trainer import ReverseBucketReducer
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cpu = torch.device("cpu")
-    em = Emitter(rank, 300.0)
+    em = Emitter(rank, float(os.environ.get("MPSR_BENCH_TEST_DEADLINE", "300")))
     seen = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(seen, op=dist.ReduceOp.MAX)
     result = {"rendezvous_only": True, "n_gpus": world, "max_rank_plus_1": float(seen.item())}
     em.arm(result)
+    if os.environ.get("MPSR_BENCH_TEST_HANG_EXTRAS"):  # test hook: an extra that never returns
+        time.sleep(3600)
     result["rank_proof"] = rank_proof(dist, rank, world, "gloo", cpu)
     result["per_rank_ms"] = [o["ms"] for o in gather_rank_objects(dist, world, lambda: {"ms": 1.0 + rank})]
 

@@ -91,6 +91,17 @@ def test_a_rank_that_dies_early_does_not_leave_its_peers_waiting():
     assert time.monotonic() - t0 < 90
 
 
+def test_a_hanging_extra_does_not_cost_the_headline():
+    # once `value` exists a watchdog is armed: extras that do not finish by the deadline are dropped, the line is
+    # printed as it stands (marked), every rank exits 0
+    r = _run(["--gpus", "2"], {"MPSR_BENCH_RENDEZVOUS_ONLY": "1", "MPSR_BENCH_TEST_HANG_EXTRAS": "1",
+                               "MPSR_BENCH_TEST_DEADLINE": "3"}, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["extras_timed_out_after_s"] == 3.0
+    assert "rank_proof" not in lines[0]
+
+
 def test_sigterm_to_the_launcher_stops_the_ranks():
     import signal
     import time
