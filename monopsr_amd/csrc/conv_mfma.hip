@@ -1099,7 +1099,10 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
 size_t winograd4_scratch_floats(int C, int N);
 bool winograd4_applies(int H, int W, int C, int N);
 int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8);
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8, float *part,
+                      size_t part_floats);
+size_t winograd4_split_floats(int B, int H, int W, int N);
+extern std::atomic<int> g_wino4_split;
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
@@ -1177,7 +1180,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
                           M64 * C * 4 < 0x7f000000LL;
         if (wino < 0)
             wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? (can4 ? 2 : 1) : 0;
-        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0);
+        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
         if (wino >= 1 && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
     ConvParams p;
@@ -1340,7 +1343,12 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
 extern "C" size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N)
 {
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0) return 0;
-    return mpsr::conv_scratch_floats((long long)B * H * W, N);
+    size_t n = mpsr::conv_scratch_floats((long long)B * H * W, N);
+    // with the (opt-in) position-split Winograd kernel enabled, large maps with N a multiple of 128 park the partial
+    // outputs of half their workgroups behind the transformed filters (winograd4.hip)
+    if (mpsr::g_wino4_split.load() != 0 && (long long)B * H * W >= 65536 && N % 128 == 0 && H % 4 == 0 && W % 4 == 0)
+        n += mpsr::winograd4_split_floats(B, H, W, N) + 64;
+    return n;
 }
 
 extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float *w, const float *bias,

@@ -2,6 +2,7 @@
 // centroid / shape regression heads.  Host-side layer sequencing in C++ over the kernels of conv_mfma.hip and
 // image_ops.hip; no allocation, no synchronisation, everything on the caller's stream, scratch carved from the
 // caller's workspace.
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -13,7 +14,10 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 size_t conv_scratch_floats(long long M, int N);
 bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, size_t ws_floats);
 int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8);
+                      float *y, int N, float *ws, size_t ws_floats, hipStream_t s, int in_c8, int out_c8, float *part,
+                      size_t part_floats);
+size_t winograd4_split_floats(int B, int H, int W, int N);
+extern std::atomic<int> g_wino4_split;
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s, int in_c8);
 int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
@@ -158,8 +162,11 @@ extern "C" size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, in
 {
     if (B <= 0) return 0;
     const size_t Mf = (size_t)B * fh * fw, Mh = (size_t)B * (mh / 2) * (mw / 2), Mm = (size_t)B * mh * mw;
+    // (+ with the opt-in position-split Winograd kernel enabled, the partial outputs it parks: the larger map size)
+    const size_t parth = mpsr::winograd4_split_floats(B, mh / 2, mw / 2, 256), partm = mpsr::winograd4_split_floats(B, mh, mw, 128);
+    const size_t part = mpsr::g_wino4_split.load() != 0 ? fbytes((parth > partm ? parth : partm) + 64) : 0;
     return 2 * fbytes(Mf * 512) + fbytes(Mh * 512) + 2 * fbytes(Mh * 256) + fbytes(Mm * 256) + 2 * fbytes(Mm * 128) +
-           fbytes(mpsr::conv_scratch_floats((long long)Mm, 512));
+           fbytes(mpsr::conv_scratch_floats((long long)Mm, 512)) + part;
 }
 
 extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh,
@@ -190,6 +197,20 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
     for (int i = 2; i < n_layers; ++i) cwide = L[i].cout > cwide ? L[i].cout : cwide;
     const size_t skn = mpsr::conv_scratch_floats((long long)Mm, cwide > 512 ? cwide : 512);
     float *sk = ar.floats(skn);
+    // optional: partial outputs of the position-split Winograd kernel (absent in a workspace sized by an older
+    // mpsr_decoder_workspace_bytes: the 64-channel-block kernel then runs)
+    size_t partn = 0;
+    float *partb = nullptr;
+    if (ar.ok && mpsr::g_wino4_split.load() != 0 && c2 % 128 == 0 && c3 % 128 == 0 && hh % 4 == 0 && hw % 4 == 0 && mh % 4 == 0 && mw % 4 == 0) {
+        const size_t a1 = mpsr::winograd4_split_floats(B, hh, hw, c2), a2 = mpsr::winograd4_split_floats(B, mh, mw, c3);
+        partn = (a1 > a2 ? a1 : a2) + 64;
+        partb = ar.floats(partn);
+        if (!ar.ok) {
+            ar.ok = true;
+            partb = nullptr;
+            partn = 0;
+        }
+    }
     if (!ar.ok)
         return mpsr::fail(MPSR_ERR_WORKSPACE, "squash_decoder_fwd: workspace %zu bytes too small", workspace_bytes);
     int rc;
@@ -214,7 +235,7 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
     if (c8) {
         auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
             return mpsr::conv3x3_winograd4(x, B, H, W, Lr.cin, blob + Lr.w_off, Lr.b_off >= 0 ? blob + Lr.b_off : nullptr,
-                                           Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8);
+                                           Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8, partb, partn);
         };
         if ((rc = mpsr::resize_bilinear_c8(sq, B, fh, fw, csq, hh, hw, 1, r1, s))) return rc;
         if ((rc = wino(L[2], r1, hh, hw, a, 1, 1))) return rc;

@@ -265,6 +265,52 @@ def test_conv2d_winograd4_vs_fp64(B, H, Wd, C, N, has_bias, relu):
     assert not torch.equal(got, direct) or C * N < 1024  # it really is a different evaluation
 
 
+@pytest.mark.parametrize("B,H,Wd,C,N,has_bias,relu", [
+    (1, 48, 48, 32, 128, True, True), (4, 48, 48, 256, 128, True, True), (2, 24, 24, 512, 256, True, True),
+    (3, 12, 8, 16, 128, False, False), (1, 4, 4, 16, 128, True, False), (5, 12, 20, 48, 384, True, True),
+    (37, 24, 24, 64, 128, True, True)])
+def test_conv2d_winograd4_position_split_vs_fp64(B, H, Wd, C, N, has_bias, relu):
+    """The position-split F(4x4,3x3) kernel (csrc/winograd4.hip: two workgroups per 32 tiles x 128 channels, each with 18
+    of the 36 positions, partial outputs combined through a ticket): taken when N % 128 == 0 and the scratch has room
+    for the partials, which this test provides.  Against float64 (1e-4), against the 64-channel-block kernel (same
+    products, another order of the final sums: 1e-5), and repeated runs must agree bit for bit whichever half of a
+    pair arrives first."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import weights as W
+    lib = _lib.lib()
+    rng = np.random.default_rng(B * 1000 + C + N)
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = _conv_ref(x, w, bias, None, 1, relu)
+    w_ok, _ = W.fold_conv(w)
+    xd, wd = _dev(x), _dev(w_ok)
+    bd = _dev(bias) if has_bias else None
+    tiles = B * (H // 4) * (Wd // 4)
+    nws = lib.mpsr_conv2d_scratch_floats(B, H, Wd, N) + B * H * Wd * N + ((tiles + 31) // 32) * (N // 128) * 4 + 256
+    ws = torch.full((nws,), float("nan"), device="cuda")  # poisoned: tickets / flags must be reset by the library
+
+    def run(split):
+        y = torch.empty((B, H, Wd, N), device="cuda")
+        lib.mpsr_debug_set_conv_winograd(2)
+        lib.mpsr_debug_set_wino4_split(split)
+        try:
+            _lib.check(lib.mpsr_conv2d_nhwc_f32(xd.data_ptr(), B, H, Wd, C, wd.data_ptr(),
+                                                bd.data_ptr() if has_bias else None, None, y.data_ptr(), N, 3, 3, 1,
+                                                int(relu), 0, ws.data_ptr(), nws, _lib.stream()))
+        finally:
+            lib.mpsr_debug_set_conv_winograd(-1)
+            lib.mpsr_debug_set_wino4_split(1)
+        return y
+    got = run(1)
+    _close(got, ref, 1e-4, "winograd F(4x4) split %s" % ((B, H, Wd, C, N),))
+    whole = run(0)
+    _close(got, whole, 1e-5, "split vs 64-channel-block kernel")
+    assert not torch.equal(got, whole)  # it really is the other kernel
+    for _ in range(4):
+        assert torch.equal(run(1), got), "depends on the order of arrival"
+
+
 def test_border_class_tiling_is_bit_identical():
     """Skipping the all-zero taps of an atrous layer must not change a single bit (same products, same order)."""
     from monopsr_amd import _lib
