@@ -618,12 +618,18 @@ class Emitter:
     def _expired(self):
         with self.lock:
             if not self.done and self.rank == 0 and self.result is not None:
-                for _ in range(5):
+                line = None
+                for _ in range(20):
                     try:
                         line = json.dumps(dict(self.result, extras_timed_out_after_s=self.deadline_s))
                         break
-                    except RuntimeError:  # the main thread was adding a key
+                    except (RuntimeError, TypeError, ValueError):  # the main thread was adding a key / a half-built object
                         time.sleep(0.01)
+                if line is None:  # fall back to the contract's own keys, which were complete before the watchdog was armed
+                    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                            "scaling", "vs_baseline", "dtype", "data", "config")
+                    line = json.dumps(dict({k: self.result[k] for k in keys if k in self.result},
+                                           extras_timed_out_after_s=self.deadline_s))
                 print(line, flush=True)
                 self.done = True
         os._exit(0)  # every rank: the launcher must not turn a printed headline into a failed run

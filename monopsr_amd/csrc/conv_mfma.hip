@@ -1178,8 +1178,9 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
                           ws_floats >= winograd_scratch_floats(C, N);
         const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
                           M64 * C * 4 < 0x7f000000LL;
-        if (wino < 0)
-            wino = (split_k == 0 && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? (can4 ? 2 : 1) : 0;
+        // (the automatic choice is conv2d_takes_winograd4's -- one copy of the rule, network.hip asks it too)
+        if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
+                             : (M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
         if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
         if (wino >= 1 && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
