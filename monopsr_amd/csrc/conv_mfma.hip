@@ -1017,7 +1017,7 @@ std::atomic<int> g_tile_override{-1};
 std::atomic<int> g_class_override{-1};
 std::atomic<int> g_sched_override{-1};
 std::atomic<int> g_sk_per_cu{0};
-std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) whenever possible
+std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) / 3 F(3x3,3x3) on atrous sub-grids whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
 
@@ -1103,6 +1103,11 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
                       size_t part_floats);
 size_t winograd4_split_floats(int B, int H, int W, int N);
 extern std::atomic<int> g_wino4_split;
+// winograd3.hip
+size_t winograd3_scratch_floats(int C, int N);
+bool winograd3_applies(int H, int W, int C, int dilation);
+int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
+                      float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s);
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
@@ -1166,6 +1171,18 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
         g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
         return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream, 0);
+    // atrous 3x3 layers whose pixel sub-grids are 3x3 (block3's conv2: 12x12 at dilation 4): every sub-grid is one
+    // Winograd F(3x3,3x3) tile with an all-zero halo -- 25 products where the border-class implicit GEMM executes 49
+    // (winograd3.hip).  fp32 mode only (the bf16x3 implicit GEMM is faster than fp32 Winograd there).
+    {
+        const int wino = g_wino_override.load();
+        const bool can3 = KH == 3 && KW == 3 && dilation > 1 && !residual && split_k == 0 && ws &&
+                          g_math.load() == MATH_FP32 && winograd3_applies(H, W, C, dilation) &&
+                          ws_floats >= winograd3_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
+        const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
+                                         (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64);
+        if (can3 && want3) return conv3x3_winograd3(x, B, H, W, C, w, bias, relu, y, N, dilation, ws, ws_floats, stream);
+    }
     // the big dense 3x3 layers (map decoder) go to a Winograd kernel when the caller leaves the schedule to the
     // library: F(4x4,3x3) (winograd4.hip, 4x fewer multiply-adds) where the map divides into 4x4 blocks, else
     // F(2x2,3x3) (winograd.hip, 2.25x fewer)
@@ -1182,7 +1199,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
                              : (M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
         if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
-        if (wino >= 1 && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        if ((wino == 1 || wino == 2) && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
@@ -1304,7 +1321,7 @@ extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
 // kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,
-// 3 = Winograd F(4x4,3x3); and
+// 3 = Winograd F(4x4,3x3), 4 = Winograd F(3x3,3x3) on the 3x3 sub-grids of an atrous layer; and
 // the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernels 16/36 or 36/144 of the direct count,
 // the implicit GEMM with border classes only the in-image taps.  For reporting (bench.py), not part of the compute path.
 extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
@@ -1312,6 +1329,17 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
 {
     MPSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && kind && executed_flops, "conv2d_plan: bad arguments");
     const double M = (double)B * H * W;
+    {
+        const int wo = g_wino_override.load();
+        if (KH == 3 && KW == 3 && dilation > 1 && mpsr::winograd3_applies(H, W, C, dilation) && g_math.load() == MATH_FP32 &&
+            M * C * 4 < 0x7f000000LL &&
+            (wo == 3 || (wo < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
+                         (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64))) {
+            *kind = 4;  // 25 products per 3x3 sub-grid
+            *executed_flops = 2.0 * (double)B * dilation * dilation * 25.0 * C * N;
+            return MPSR_OK;
+        }
+    }
     const bool wino_any = KH == 3 && KW == 3 && dilation == 1 && M >= 65536 && C >= 64 && N >= 64 &&
                           g_wino_override.load() != 0;
     const bool wino_shape = wino_any && g_math.load() == MATH_FP32;

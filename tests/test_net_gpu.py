@@ -311,6 +311,42 @@ def test_conv2d_winograd4_position_split_vs_fp64(B, H, Wd, C, N, has_bias, relu)
         assert torch.equal(run(1), got), "depends on the order of arrival"
 
 
+@pytest.mark.parametrize("B,dil,C,N,has_bias,relu", [
+    (8, 4, 64, 64, True, True), (3, 4, 32, 40, False, False), (1, 4, 16, 4, True, False), (5, 2, 48, 200, True, True),
+    (64, 4, 256, 256, True, True), (7, 3, 16, 65, True, True), (33, 4, 128, 128, True, True)])
+def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu):
+    """The Winograd F(3x3,3x3) kernel for atrous 3x3 layers whose pixel sub-grids are 3x3 (csrc/winograd3.hip: H = W =
+    3 * dilation; block3's conv2 is 12x12 at dilation 4): ragged tile / channel counts, the seven-position waves, the
+    real layer shape.  Against float64 (1e-5 of the tensor scale; measured ~5e-6), deterministic, and really another
+    evaluation than the border-class implicit GEMM (which must agree to 1e-5 as well)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    H = 3 * dil
+    rng = np.random.default_rng(B * 1000 + C + N + dil)
+    x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = _conv_ref(x, w, bias, None, dil, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    lib.mpsr_debug_set_conv_winograd(3)
+    try:
+        got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+        again = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    _close(got, ref, 1e-5, "winograd F(3x3) atrous %s" % ((B, dil, C, N),))
+    assert torch.equal(got, again), "not deterministic"
+    lib.mpsr_debug_set_conv_winograd(0)
+    try:
+        direct = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    _close(got, direct, 1e-5, "winograd vs implicit GEMM")
+    assert not torch.equal(got, direct) or C * N < 1024
+
+
 def test_border_class_tiling_is_bit_identical():
     """Skipping the all-zero taps of an atrous layer must not change a single bit (same products, same order)."""
     from monopsr_amd import _lib
