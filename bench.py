@@ -273,8 +273,9 @@ def mfma_box_peak(device):
 
 def roofline_object(net, args, device, ms_per_step):
     """The dominant kernel family alone: every conv/FC launch of one step, timed with events on the launch stream.
-    `achieved` / `frac` are what the matrix pipes EXECUTE (mpsr_conv2d_plan: the Winograd launches issue 16/36 -- or
-    36/144 for F(4x4,3x3) -- of their direct-convolution products and the atrous layers skip out-of-image taps), so
+    `achieved` / `frac` are what the matrix pipes EXECUTE (mpsr_conv2d_plan: the Winograd launches issue 16/36 --
+    36/144 for F(4x4,3x3), 25/81 for F(3x3,3x3) on block3's atrous sub-grids -- of their direct-convolution products and
+    the other atrous layers skip out-of-image taps), so
     0 < frac <= 1 and it is comparable with the PMC's MFMA-busy fraction; the ALGORITHMIC direct-convolution rate of
     SURVEY 8(d) (12.393 GFLOP per crop) is next to it as algorithmic_achieved / algorithmic_frac and may exceed 1."""
     run, launches, flops, alg_bytes, executed, kinds = conv_replay(net, args.batch)
@@ -307,8 +308,8 @@ def roofline_object(net, args, device, ms_per_step):
             pass
     fp32 = args.math == "fp32"
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
-    kname = "conv_igemm_kernel + wino conv kernels (fp32 MFMA 32x32x2: implicit GEMM; Winograd for the decoder's 3x3 " \
-            "layers)" if fp32 else \
+    kname = "conv_igemm_kernel + wino conv kernels (fp32 MFMA 32x32x2: implicit GEMM; Winograd F(4x4,3x3) for the " \
+            "decoder's 3x3 layers, F(3x3,3x3) for block3's atrous 3x3 layers)" if fp32 else \
         "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
     alg = flops / launches / avg_s / 1e12
     exe = executed / launches / avg_s / 1e12 if fp32 else alg
@@ -325,7 +326,8 @@ def roofline_object(net, args, device, ms_per_step):
                      "conv on N(0,1)) -- the step's own activations live in ping-pong scratch and cannot be replayed"}
     if fp32:
         out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
-                               "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0)}
+                               "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0),
+                               "winograd_f3x3_3x3_atrous_subgrids": kinds.get(4, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
                        "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
                        "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction from the quoted collection")
