@@ -128,6 +128,9 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     float pa[25];  // 5x5: the 3x3 data arrives in the middle, the transforms expand it in place
     auto load_patch1 = [&](int step, int L) __attribute__((always_inline)) {
         const int j = L / 3, i = L % 3;  // column by column
+#ifdef W3_SKIP_LOAD
+        if (step > 1) return;
+#endif
         const bool live = step < nsteps;
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, live ? (int)p.xbytes : 0, 0x00020000);
@@ -135,6 +138,9 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
         pa[5 * (i + 1) + (j + 1)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, abase, so, 0));
     };
     auto vertical = [&](int j) __attribute__((always_inline)) {  // data column j (0..2) -> all five rows of it
+#ifdef W3_SKIP_VALU
+        return;
+#endif
         float t0_, t1_, t2_, t3_, t4_;
         bt5(pa[5 + j + 1], pa[10 + j + 1], pa[15 + j + 1], t0_, t1_, t2_, t3_, t4_);
         pa[j + 1] = t0_;
@@ -144,6 +150,9 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
         pa[20 + j + 1] = t4_;
     };
     auto horizontal = [&](int r) __attribute__((always_inline)) {  // row r (0..4): three values -> five
+#ifdef W3_SKIP_VALU
+        return;
+#endif
         float t0_, t1_, t2_, t3_, t4_;
         bt5(pa[5 * r + 1], pa[5 * r + 2], pa[5 * r + 3], t0_, t1_, t2_, t3_, t4_);
         pa[5 * r] = t0_;
@@ -154,7 +163,13 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     };
     // A[buf][pos][tile][8 channels], 16-byte halves swapped on odd 8-row blocks
     float *awr = lds + lt * 8 + 4 * ((ch >> 2) ^ ((lt >> 3) & 1)) + (ch & 3);
-    auto store_a = [&](int buf, int pos) __attribute__((always_inline)) { awr[buf * ABUF + pos * APOS] = pa[pos]; };
+    auto store_a = [&](int buf, int pos) __attribute__((always_inline)) {
+#ifndef W3_SKIP_STORE  // (timing experiments only)
+        awr[buf * ABUF + pos * APOS] = pa[pos];
+#else
+        asm volatile("" ::"v"(pa[pos]));
+#endif
+    };
 
     // ---- B fragments from the transformed filters, lane = (n = lane & 31, k half = lane >> 5)
     const unsigned bvoff = n0 + 32 * nh + (lane & 31) < p.N
@@ -162,6 +177,9 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     const unsigned bpstride = (unsigned)p.N * KC * 4u;
     float4 fb[NU][3];
     auto load_b1 = [&](int step, int q, int set, int j) __attribute__((always_inline)) {  // position q of the wave
+#ifdef W3_SKIP_BLOAD
+        if (step > 0) return;
+#endif
         const bool live = step < nsteps;
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
