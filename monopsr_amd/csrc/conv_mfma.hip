@@ -1109,6 +1109,25 @@ bool winograd3_applies(int H, int W, int C, int dilation);
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
                       float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s);
 
+// pointwise.hip
+bool pointwise_applies(long long M, int K, int N);
+int pointwise_override();
+int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                      int relu, float *y, int N, hipStream_t s);
+
+// True when conv2d() sends a 1x1 layer to the 288 x 128 pointwise kernel (pointwise.hip): the wide trunk layers, where
+// the launch makes at least one workgroup per CU.
+bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k)
+{
+    const int pw = pointwise_override();
+    if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || g_math.load() != MATH_FP32 || g_tile_override.load() >= 0 ||
+        !pointwise_applies(M, C, N))
+        return false;
+    if (pw == 1) return true;
+    const long long wgs = ((M + 287) / 288) * ((N + 127) / 128);
+    return split_k == 0 && N % 128 == 0 && C >= 512 && wgs >= 256;
+}
+
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
 //  * stream-K: two partial-tile slabs per persistent workgroup + one counter per tile.  Bounded over every tile
 //    instantiation by 8 workgroups/CU x 64x64 or 4/CU x 96x128 / 128x64 or 3/CU x 128x128 on 256 CUs, i.e.
@@ -1201,6 +1220,8 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
         if ((wino == 1 || wino == 2) && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
+    if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
+        return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;
@@ -1321,7 +1342,8 @@ extern "C" int mpsr_get_conv_math(void) { return g_math; }
 
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
 // kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,
-// 3 = Winograd F(4x4,3x3), 4 = Winograd F(3x3,3x3) on the 3x3 sub-grids of an atrous layer; and
+// 3 = Winograd F(4x4,3x3), 4 = Winograd F(3x3,3x3) on the 3x3 sub-grids of an atrous layer, 5 = the pointwise kernel
+// of the wide 1x1 layers (pointwise.hip); and
 // the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernels 16/36 or 36/144 of the direct count,
 // the implicit GEMM with border classes only the in-image taps.  For reporting (bench.py), not part of the compute path.
 extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
@@ -1356,6 +1378,11 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0) {
         *kind = 2;
         *executed_flops = 2.0 * M * 9.0 * C * N;
+        return MPSR_OK;
+    }
+    if (mpsr::conv2d_takes_pointwise((long long)B * H * W, C, N, KH, KW, 0)) {
+        *kind = 5;  // 288 x 128 pointwise kernel
+        *executed_flops = 2.0 * M * C * N;
         return MPSR_OK;
     }
     *kind = 0;

@@ -5,6 +5,8 @@ Tolerance: BASELINE north_star allows 1e-3 relative on float tensors; the fp32-M
 tensor's scale here (measured drift is ~1e-6..1e-5; it differs from the oracle only by summation order and by
 folding BatchNorm into the weights).
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -309,6 +311,49 @@ def test_conv2d_winograd4_position_split_vs_fp64(B, H, Wd, C, N, has_bias, relu)
     assert not torch.equal(got, whole)  # it really is the other kernel
     for _ in range(4):
         assert torch.equal(run(1), got), "depends on the order of arrival"
+
+
+@pytest.mark.parametrize("B,H,Wd,C,N,has_bias,has_res,relu", [
+    (4, 12, 12, 256, 1024, True, True, True),     # block3 conv3's shape: two whole row groups
+    (3, 12, 12, 1024, 256, True, False, True),    # conv1: 1.5 row groups (rows past M), 32 stages
+    (5, 7, 9, 64, 160, False, True, False),       # M = 315 (not a multiple of 32), N % 128 != 0, two stages
+    (1, 3, 5, 128, 32, True, False, False),       # one partial tile, one live wave
+    (16, 12, 12, 512, 384, True, True, True),     # eight row groups x three column blocks
+    (2, 12, 12, 96, 128, True, True, True)])      # K = 96: an odd number of stages (the last one multiplies zeros)
+def test_conv2d_pointwise_vs_fp64(B, H, Wd, C, N, has_bias, has_res, relu):
+    """The 288 x 128 pointwise kernel of the wide 1x1 layers (csrc/pointwise.hip) against float64: whole and ragged
+    row groups, rows past M, column blocks past N, residual / bias / ReLU in the epilogue; deterministic; and the same
+    sums as the implicit GEMM up to the order of the additions."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    rng = np.random.default_rng(B * 100 + C + N)
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, C, N)) / np.sqrt(C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    res = rng.standard_normal((B, H, Wd, N)).astype(np.float32) if has_res else None
+    ref = _conv_ref(x, w, bias, res, 1, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+
+    def run(mode):
+        lib.mpsr_debug_set_conv_pointwise(mode)
+        try:
+            return dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, _dev(res) if has_res else None, 1, 1,
+                             1, relu, split_k=0)
+        finally:
+            lib.mpsr_debug_set_conv_pointwise(-1)
+    kind, flops = ctypes.c_int(-1), ctypes.c_double(0)
+    lib.mpsr_debug_set_conv_pointwise(1)
+    try:
+        _lib.check(lib.mpsr_conv2d_plan(B, H, Wd, C, N, 1, 1, 1, ctypes.byref(kind), ctypes.byref(flops)))
+    finally:
+        lib.mpsr_debug_set_conv_pointwise(-1)
+    assert kind.value == 5 and flops.value == 2.0 * B * H * Wd * C * N
+    got = run(1)
+    _close(got, ref, 1e-5, "pointwise %s" % ((B, H, Wd, C, N),))
+    assert torch.equal(run(1), got), "not deterministic"
+    _close(got, run(0), 1e-5, "pointwise vs implicit GEMM")
 
 
 @pytest.mark.parametrize("B,dil,C,N,has_bias,relu", [

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
                     "kernel: -1 heuristic, 1, 2")
     ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3), 2 F(4x4,3x3)")
+    ap.add_argument("--pw", default="-1", help="comma list: the 288x128 pointwise kernel for 1x1 layers: -1 heuristic, "
+                    "0 never, 1 wherever it applies")
     ap.add_argument("--plain", default="-1", help="comma list: the decode-free 1x1 instantiation: -1 whenever it "
                     "applies, 0 never")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
@@ -70,11 +72,13 @@ def main():
         scheds.append((int(a), int(b) if b else 0))
     winos = [int(v) for v in args.wino.split(",")]
     plains = [int(v) for v in args.plain.split(",")]
-    combos = [(t, sc, d, wv, pl) for t in tiles for sc in scheds for d in depths for wv in winos for pl in plains]
+    pws = [int(v) for v in args.pw.split(",")]
+    combos = [(t, sc, d, wv, pl, pw) for t in tiles for sc in scheds for d in depths for wv in winos for pl in plains
+              for pw in pws]
 
     def label(c):
-        t, (a, b), d, wv, pl = c
-        return "t%d s%d:%d d%d w%d p%d" % (t, a, b, d, wv, pl)
+        t, (a, b), d, wv, pl, pw = c
+        return "t%d s%d:%d d%d w%d p%d pw%d" % (t, a, b, d, wv, pl, pw)
     print("%-28s %3s %9s | %s" % ("layer", "n", "GFLOP", "  ".join(label(c) + " TF/s (us)" for c in combos)))
     total = {c: 0.0 for c in combos}
     shapes = SHAPES
@@ -99,7 +103,7 @@ def main():
         samples = {c: [] for c in combos}
         for rnd in range(args.rounds):
             for c in combos:
-                t, sc, d, wv, pl = c
+                t, sc, d, wv, pl, pw = c
                 if t == 4 and N > 32:
                     continue
                 lib.mpsr_debug_set_conv_tile(t)
@@ -107,6 +111,7 @@ def main():
                 lib.mpsr_debug_set_conv_depth(d)
                 lib.mpsr_debug_set_conv_winograd(wv)
                 lib.mpsr_debug_set_conv_plain(pl)
+                lib.mpsr_debug_set_conv_pointwise(pw)
 
                 def run():
                     _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, W, C, w.data_ptr(), bias.data_ptr(),
@@ -133,6 +138,7 @@ def main():
         lib.mpsr_debug_set_conv_depth(-1)
         lib.mpsr_debug_set_conv_winograd(-1)
         lib.mpsr_debug_set_conv_plain(-1)
+        lib.mpsr_debug_set_conv_pointwise(-1)
         print("%-28s %3d %9.2f | %s" % (name, count, flop / 1e9, "  ".join(cells)))
     print("per-step conv time (ms): " + "  ".join("%s %.2f" % (label(c), total[c] / 1e3) for c in combos))
 
