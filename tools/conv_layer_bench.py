@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3), 2 F(4x4,3x3)")
     ap.add_argument("--pw", default="-1", help="comma list: the 288x128 pointwise kernel for 1x1 layers: -1 heuristic, "
                     "0 never, 1 wherever it applies")
+    ap.add_argument("--pws-per-cu", type=int, default=2)
     ap.add_argument("--plain", default="-1", help="comma list: the decode-free 1x1 instantiation: -1 whenever it "
                     "applies, 0 never")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved rounds over all variants of a shape; the "
@@ -63,6 +64,7 @@ def main():
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
     lib.mpsr_debug_set_conv_classes(args.classes)
+    lib.mpsr_debug_set_pointwise_stream_per_cu(args.pws_per_cu)
     depths = [int(d) for d in args.depth.split(",")]
     dev = torch.device("cuda")
     B = args.batch

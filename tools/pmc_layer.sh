@@ -15,5 +15,5 @@ for P in \
   i=$((i+1))
   timeout 90 rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/p$i" -o pmc -- python3 tools/conv_layer_bench.py --tiles $TILE --reps 3 --shape $SHAPE $EXTRA > "$OUT/p$i.log" 2>&1 || echo "pass $i failed/timeout"
 done
-python3 tools/pmc_summary.py "$OUT"/p*/pmc_counter_collection.csv | grep "conv\|kernel |" > "$OUT/summary.md"
+python3 tools/pmc_summary.py "$OUT"/p*/pmc_counter_collection.csv | grep "conv\|pw_\|kernel |" > "$OUT/summary.md"
 cat "$OUT/summary.md"
