@@ -1115,25 +1115,18 @@ int pointwise_override();
 int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
                       int relu, float *y, int N, hipStream_t s);
 
-bool pointwise_stream_applies(long long M, int K, int N);
-int conv1x1_pointwise_stream(const float *x, long long M, int K, const float *w, const float *bias,
-                             const float *residual, int relu, float *y, int N, hipStream_t s);
-
-// Which pointwise kernel (pointwise.hip) conv2d() sends a 1x1 layer to: 0 none (implicit GEMM), 1 the 288 x 128 tile
-// kernel (long K: block3's conv1, the projection shortcut, the squash layers), 2 the streaming kernel (short K, wide
-// N: block3's conv3 and its residual).
-int conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k)
+// True when conv2d() sends a 1x1 layer to the persistent pointwise kernel (pointwise.hip): the wide trunk layers, where
+// the launch has at least two 96 x 128 tiles per CU (measured: block3's conv1 / conv3 / shortcut, block2's conv3, the
+// squash layers; block2's conv1 with its 384 tiles stays on the implicit GEMM).
+bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k)
 {
     const int pw = pointwise_override();
     if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || g_math.load() != MATH_FP32 || g_tile_override.load() >= 0 ||
         !pointwise_applies(M, C, N))
-        return 0;
-    if (pw == 1) return 1;
-    if (pw == 2) return pointwise_stream_applies(M, C, N) ? 2 : 0;
-    if (split_k != 0 || N % 128 != 0) return 0;
-    const long long wgs = ((M + 287) / 288) * ((N + 127) / 128);
-    if (C >= 512 && wgs >= 256) return 1;
-    return 0;
+        return false;
+    if (pw > 0) return true;
+    const long long tiles = ((M + 95) / 96) * ((N + 127) / 128);
+    return split_k == 0 && N % 128 == 0 && tiles >= 512;
 }
 
 // Scratch behind `ws` when the caller leaves the schedule to the library (split_k == 0).
@@ -1228,9 +1221,8 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
         if ((wino == 1 || wino == 2) && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
-    if (const int pwk = conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
-        return pwk == 2 ? conv1x1_pointwise_stream(x, M64, C, w, bias, residual, relu, y, N, stream)
-                        : conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
+    if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
+        return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;
@@ -1390,7 +1382,7 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
         return MPSR_OK;
     }
     if (mpsr::conv2d_takes_pointwise((long long)B * H * W, C, N, KH, KW, 0)) {
-        *kind = 5;  // the pointwise kernels
+        *kind = 5;  // the persistent pointwise kernel
         *executed_flops = 2.0 * M * C * N;
         return MPSR_OK;
     }

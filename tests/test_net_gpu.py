@@ -316,14 +316,16 @@ def test_conv2d_winograd4_position_split_vs_fp64(B, H, Wd, C, N, has_bias, relu)
 @pytest.mark.parametrize("B,H,Wd,C,N,has_bias,has_res,relu", [
     (4, 12, 12, 256, 1024, True, True, True),     # block3 conv3's shape: two whole row groups
     (3, 12, 12, 1024, 256, True, False, True),    # conv1: 1.5 row groups (rows past M), 32 stages
-    (5, 7, 9, 64, 160, False, True, False),       # M = 315 (not a multiple of 32), N % 128 != 0, two stages
+    (5, 7, 9, 128, 160, False, True, False),      # M = 315 (not a multiple of 32), N % 128 != 0, four stages
     (1, 3, 5, 128, 32, True, False, False),       # one partial tile, one live wave
-    (16, 12, 12, 512, 384, True, True, True),     # eight row groups x three column blocks
-    (2, 12, 12, 96, 128, True, True, True)])      # K = 96: an odd number of stages (the last one multiplies zeros)
+    (16, 12, 12, 512, 384, True, True, True),     # 24 row groups x three column blocks
+    (2, 12, 12, 192, 128, True, True, True),      # six stages
+    (40, 12, 12, 256, 1024, True, True, True),    # 480 tiles on 512 workgroups ... 
+    (100, 12, 12, 256, 512, True, True, False)])  # ... and 600: one or two tiles per workgroup (both accumulator sets)
 def test_conv2d_pointwise_vs_fp64(B, H, Wd, C, N, has_bias, has_res, relu):
-    """The 288 x 128 pointwise kernel of the wide 1x1 layers (csrc/pointwise.hip) against float64: whole and ragged
-    row groups, rows past M, column blocks past N, residual / bias / ReLU in the epilogue; deterministic; and the same
-    sums as the implicit GEMM up to the order of the additions."""
+    """The persistent pointwise kernel of the wide 1x1 layers (csrc/pointwise.hip) against float64: whole and ragged
+    row groups, rows past M, column blocks past N, one to several tiles per workgroup, residual / bias / ReLU;
+    deterministic; and the same sums as the implicit GEMM up to the order of the additions."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W

@@ -48,8 +48,8 @@ def main():
     ap.add_argument("--depth", default="-1", help="comma list: register staging depth of the one-tile-per-workgroup "
                     "kernel: -1 heuristic, 1, 2")
     ap.add_argument("--wino", default="-1", help="comma list: Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3), 2 F(4x4,3x3)")
-    ap.add_argument("--pw", default="-1", help="comma list: the 288x128 pointwise kernel for 1x1 layers: -1 heuristic, "
-                    "0 never, 1 wherever it applies")
+    ap.add_argument("--pw", default="-1", help="comma list: the persistent pointwise kernel for 1x1 layers: -1 "
+                    "heuristic, 0 never, 1 wherever it applies")
     ap.add_argument("--pws-per-cu", type=int, default=2)
     ap.add_argument("--plain", default="-1", help="comma list: the decode-free 1x1 instantiation: -1 whenever it "
                     "applies, 0 never")
@@ -64,7 +64,7 @@ def main():
     tiles = [int(t) for t in args.tiles.split(",")]
     lib = _lib.lib()
     lib.mpsr_debug_set_conv_classes(args.classes)
-    lib.mpsr_debug_set_pointwise_stream_per_cu(args.pws_per_cu)
+    lib.mpsr_debug_set_pointwise_per_cu(args.pws_per_cu)
     depths = [int(d) for d in args.depth.split(",")]
     dev = torch.device("cuda")
     B = args.batch

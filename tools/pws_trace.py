@@ -1,4 +1,4 @@
-"""Per-wave timeline of one steady-state tile (the workgroup's third) of pw_stream_kernel (library built with
+"""Per-wave timeline of one steady-state tile (the workgroup's third) of pw_conv_kernel (library built with
 -DPWS_TRACE):
     tools/build_variant.sh pwstrace pointwise.hip -DPWS_TRACE
     MPSR_LIB_PATH=abl/pwstrace.so python tools/pws_trace.py [--shape 256,1024,1]
@@ -21,7 +21,7 @@ args = ap.parse_args()
 K, N, res = [int(v) for v in args.shape.split(",")]
 B, H, W = args.batch, 12, 12
 lib = _lib.lib()
-lib.mpsr_debug_set_conv_pointwise(2)
+lib.mpsr_debug_set_conv_pointwise(1)
 x = torch.randn((B, H, W, K), device="cuda").clamp_(min=0)
 w = torch.randn((N, K), device="cuda") * 0.05
 r = torch.randn((B, H, W, N), device="cuda") if res else None
@@ -36,11 +36,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = trace.cpu().numpy().reshape(grid, 4, 16)
 t = t[t[:, 0, 0] != 0]
-d = np.diff(t[:, :, :14], axis=2).astype(np.float64)
-names = ["init (LDS -> acc, bias)", "stage 0", "  barrier", "stage 1 (res loads)", "  barrier", "stage 2 (loads+writes)",
-         "  barrier", "stage 3 (res writes)", "  barrier", "stage 4", "  barrier", "stages 5..", "stores"]
+d = np.diff(t[:, :, :13], axis=2).astype(np.float64)
+names = ["init (LDS -> acc, bias)", "stage 0 (stores)", "  barrier", "stage 1 (stores, res loads)", "  barrier",
+         "stage 2 (stores, res loads+writes)", "  barrier", "stage 3 (res writes)", "  barrier", "stage 4", "  barrier",
+         "stages 5.."]
 print("%d workgroups; K = %d: %d stages of 48 MFMAs (3072 cycles of matrix pipe each)" % (len(t), K, K // 32))
 for i, nme in enumerate(names):
-    print("  %-24s " % nme + " ".join("%7.0f" % np.median(d[:, wv, i]) for wv in range(4)))
+    print("  %-36s " % nme + " ".join("%7.0f" % np.median(d[:, wv, i]) for wv in range(4)))
 print("  tile: %.0f cycles (median over workgroups, wave 0); matrix pipe alone would need %d" % (
-    np.median(t[:, 0, 13] - t[:, 0, 0]), (K // 32) * 3072))
+    np.median(t[:, 0, 12] - t[:, 0, 0]), (K // 32) * 3072))
