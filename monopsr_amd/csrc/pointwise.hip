@@ -21,10 +21,9 @@
 //     stages) into a 48 KB LDS copy of the tile; tile t + 1 starts its accumulators from that copy (48 ds_read_b32,
 //     then + bias as one more MFMA k: A = 1, B = bias): no residual load waits in front of an MFMA, none occupies a
 //     register across a K loop, no vector-ALU arithmetic in front of the stores except the ReLU;
-//   * two accumulator sets alternate: a finished tile is stored from its set during the first three stages of the next
-//     tile (ReLU + one store per element -- 2 x 128 contiguous bytes per instruction -- every third MFMA slot: 12 KB
-//     per wave over three stages is what a CU's store path sustains next to the loads; issued in one burst behind the
-//     K loop the same stores held the wave for 9000 cycles);
+//   * two accumulator sets alternate: a finished tile is stored from its set during the first eight stages of the next
+//     tile (ReLU + one store per element -- 2 x 128 contiguous bytes per instruction -- every eighth MFMA slot; issued
+//     in one burst behind the K loop the same stores held the wave for 9000 cycles);
 //   * the A stages and B chunks run on across tile boundaries as one stream (the next tile's first two stages are
 //     requested during this tile's last two);
 //   * tile sequence of workgroup b: b, b + G, ...; G is a multiple of 8 x column blocks, so b keeps its XCD and its
@@ -66,7 +65,9 @@ struct PwsParams {
     unsigned long long *trace;  // -DPWS_TRACE builds: 16 stamps per wave (the workgroup's third tile)
 };
 
-template <bool RES>
+// LONG: K >= 256 (eight or more stages: the stores of a tile are spread over the next tile's first eight); otherwise
+// four stages carry them.
+template <bool RES, bool LONG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_conv_kernel(const PwsParams p)
 {
     using namespace pws;
@@ -173,13 +174,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // at D + 2); the B chunk of the next stage (m = 11); and the residual duty -- DUTY 1 / 2: the first / second six
     // pieces of the next tile's residual requested (D = 9 + 6 n); DUTY 2 / 3: the first / second six written to LDS
     // (D = 7 + 6 n).
-    // ST = 1, 2, 3: also ReLU + store of elements 16 (ST - 1) .. + 15 of the previous tile (the other accumulator set), one
-    // per three slots (D = 1 + 3 n): 12 KB per wave over three stages is what a CU's store path sustains next to the
-    // loads (~10 bytes a cycle); issued in one burst behind the K loop the same stores held the wave for 9000 cycles.
-    auto stage_body = [&](auto set_c, auto buf_c, auto duty_c, auto st_c, int s, RowRef xc, bool clive, RowRef xn,
-                          bool nlive, RowRef rn, RowRef yp) __attribute__((always_inline)) {
+    // SE0 >= 0: also ReLU + store of elements SE0, SE0 + 1, ... of the previous tile (the other accumulator set), one
+    // every SSTEP slots (D = 1 + SSTEP n) -- the 48 stores of a tile are spread over its first eight stages (four when
+    // K = 128 / 192): one in-order counter covers loads and stores, so every wait for an A / B request also waits for
+    // the stores issued before it, and those complete sooner the thinner they are spread (12 KB per wave in one burst
+    // behind the K loop held the wave for 9000 cycles; over three stages the stages after them took 3x as long).
+    auto stage_body = [&](auto set_c, auto buf_c, auto duty_c, auto se0_c, auto sstep_c, int s, RowRef xc, bool clive,
+                          RowRef xn, bool nlive, RowRef rn, RowRef yp) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, buf = decltype(buf_c)::value, DUTY = decltype(duty_c)::value,
-                      ST = decltype(st_c)::value;
+                      SE0 = decltype(se0_c)::value, SSTEP = decltype(sstep_c)::value;
         read_a(buf, 0, 0);
         // stage s + 2 of this tile, or stage s + 2 - nst of the next one (scalar selects)
         const bool wrap2 = s + 2 >= nst;
@@ -204,12 +207,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float bv = k == 0 ? fb[kb].x : k == 1 ? fb[kb].y : k == 2 ? fb[kb].z : fb[kb].w;
                     acc[SET][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[SET][j], 0, 0, 0);
                     if (m == 0 && kb < 3) read_a(buf, kb + 1, set ^ 1);
-                    if constexpr (ST > 0) if (D % 3 == 1) {
-                        const int q = ST - 1, e = D / 3;
+#ifndef PWS_SKIP_STORE  // (timing experiments only: tools/README.md)
+                    if constexpr (SE0 >= 0) if (D % SSTEP == 1 && SE0 + D / SSTEP < 16 * WT) {
+                        const int q = (SE0 + D / SSTEP) / 16, e = (SE0 + D / SSTEP) % 16;
                         __builtin_amdgcn_raw_buffer_store_b32(
                             __builtin_bit_cast(unsigned, fmaxf(acc[SET ^ 1][q][e], relu_lo)),
                             rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
                     }
+#endif
                     if (D >= 4 && D < 4 + 12 * WT && (D - 4) % 12 == 0) store_a(buf ^ 1, (D - 4) / 12);
                     if (D >= 6 && D < 6 + 12 * WT && (D - 6) % 12 == 0) load_a(xa, a_st, (D - 6) / 12);
                     if (m == 11) load_b(b_live, b_st, kb);
@@ -218,8 +223,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         // 6 + n into it)
                         if ((DUTY == 2 || DUTY == 3) && D >= 7 && D < 7 + 36 && (D - 7) % 6 == 0)
                             store_r((DUTY - 2) * 6 + (D - 7) / 6);
+#ifndef PWS_SKIP_RES
                         if ((DUTY == 1 || DUTY == 2) && D >= 9 && D < 9 + 36 && (D - 9) % 6 == 0)
                             load_r(rn, (DUTY - 1) * 6 + (D - 9) / 6);
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -276,32 +283,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ... + bias as one more k: A = (1, 0) over the lane halves, B = bias of the lane's column
 #pragma unroll
         for (int q = 0; q < WT; ++q) acc[SET][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(one, bias, acc[SET][q], 0, 0, 0);
-        PWS_STAMP(i == 2);  // 1: accumulators initialised
-        stage_body(IC<SET>{}, IC<0>{}, IC<0>{}, IC<1>{}, 0, xc, true, xn, nlive, rn, yp);
-        PWS_STAMP(i == 2);  // 2: stage 0 issued
-        __syncthreads();  // (every wave has read its part of the residual copy: the next tile's may be written)
-        PWS_STAMP(i == 2);  // 3: barrier
-        stage_body(IC<SET>{}, IC<1>{}, IC<1>{}, IC<2>{}, 1, xc, true, xn, nlive, rn, yp);
-        PWS_STAMP(i == 2);  // 4
-        __syncthreads();
-        PWS_STAMP(i == 2);  // 5
-        stage_body(IC<SET>{}, IC<0>{}, IC<2>{}, IC<3>{}, 2, xc, true, xn, nlive, rn, yp);
-        PWS_STAMP(i == 2);  // 6
-        __syncthreads();
-        PWS_STAMP(i == 2);  // 7
-        stage_body(IC<SET>{}, IC<1>{}, IC<3>{}, IC<0>{}, 3, xc, true, xn, nlive, rn, yp);
-        PWS_STAMP(i == 2);  // 8
-        __syncthreads();
-        PWS_STAMP(i == 2);  // 9
-        for (int s = 4; s < nst; s += 2) {
-            stage_body(IC<SET>{}, IC<0>{}, IC<0>{}, IC<0>{}, s, xc, true, xn, nlive, rn, yp);
-            PWS_STAMP(i == 2 && s == 4);  // 10
-            __syncthreads();
-            PWS_STAMP(i == 2 && s == 4);  // 11
-            stage_body(IC<SET>{}, IC<1>{}, IC<0>{}, IC<0>{}, s + 1, xc, true, xn, nlive, rn, yp);
-            __syncthreads();
+        // stage (s, buffer s & 1, residual duty, first stored element, slots per store)
+#define PWS_STAGE(S_, DUTY_, SE0_, SSTEP_)                                                                            \
+    stage_body(IC<SET>{}, IC<(S_) & 1>{}, IC<DUTY_>{}, IC<SE0_>{}, IC<SSTEP_>{}, S_, xc, true, xn, nlive, rn, yp);    \
+    __syncthreads()
+        if constexpr (LONG) {
+            PWS_STAGE(0, 0, 0, 8);  // (after this barrier every wave has read its part of the residual copy: the
+            PWS_STAGE(1, 1, 6, 8);  //  next tile's may be written)
+            PWS_STAGE(2, 2, 12, 8);
+            PWS_STAGE(3, 3, 18, 8);
+            PWS_STAGE(4, 0, 24, 8);
+            PWS_STAGE(5, 0, 30, 8);
+            PWS_STAGE(6, 0, 36, 8);
+            PWS_STAGE(7, 0, 42, 8);
+            for (int s = 8; s < nst; s += 2) {
+                stage_body(IC<SET>{}, IC<0>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+                stage_body(IC<SET>{}, IC<1>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s + 1, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+            }
+        } else {
+            PWS_STAGE(0, 0, 0, 4);
+            PWS_STAGE(1, 1, 12, 4);
+            PWS_STAGE(2, 2, 24, 4);
+            PWS_STAGE(3, 3, 36, 4);
+            for (int s = 4; s < nst; s += 2) {
+                stage_body(IC<SET>{}, IC<0>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+                stage_body(IC<SET>{}, IC<1>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s + 1, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+            }
         }
-        PWS_STAMP(i == 2);  // 12: K loop done
+#undef PWS_STAGE
+        PWS_STAMP(i == 2);  // 1: K loop done
     };
     int i = 0;
     for (; i < n_my; i += 2) {
@@ -385,11 +399,20 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
     if (grid > p.ntiles) grid = p.ntiles;
     p.trace = g_pw_trace;
     const size_t lds_bytes = (size_t)LDS_B;
-    const void *kfn = residual ? reinterpret_cast<const void *>(pw_conv_kernel<true>)
-                               : reinterpret_cast<const void *>(pw_conv_kernel<false>);
-    MPSR_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (residual) hipLaunchKernelGGL(pw_conv_kernel<true>, dim3(grid), dim3(256), lds_bytes, s, p);
-    else hipLaunchKernelGGL(pw_conv_kernel<false>, dim3(grid), dim3(256), lds_bytes, s, p);
+#define MPSR_PW(RES_, LONG_)                                                                                          \
+    do {                                                                                                              \
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<RES_, LONG_>),               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
+        hipLaunchKernelGGL((pw_conv_kernel<RES_, LONG_>), dim3(grid), dim3(256), lds_bytes, s, p);                    \
+    } while (0)
+    if (K / KS >= 8) {
+        if (residual) MPSR_PW(true, true);
+        else MPSR_PW(false, true);
+    } else {
+        if (residual) MPSR_PW(true, false);
+        else MPSR_PW(false, false);
+    }
+#undef MPSR_PW
     MPSR_CHECK_LAUNCH("pw_conv_kernel");
     return MPSR_OK;
 }

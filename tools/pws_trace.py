@@ -36,12 +36,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = trace.cpu().numpy().reshape(grid, 4, 16)
 t = t[t[:, 0, 0] != 0]
-d = np.diff(t[:, :, :13], axis=2).astype(np.float64)
-names = ["init (LDS -> acc, bias)", "stage 0 (stores)", "  barrier", "stage 1 (stores, res loads)", "  barrier",
-         "stage 2 (stores, res loads+writes)", "  barrier", "stage 3 (res writes)", "  barrier", "stage 4", "  barrier",
-         "stages 5.."]
+names = ["K loop of the tile"]
+d = np.diff(t[:, :, :2], axis=2).astype(np.float64)
 print("%d workgroups; K = %d: %d stages of 48 MFMAs (3072 cycles of matrix pipe each)" % (len(t), K, K // 32))
 for i, nme in enumerate(names):
     print("  %-36s " % nme + " ".join("%7.0f" % np.median(d[:, wv, i]) for wv in range(4)))
 print("  tile: %.0f cycles (median over workgroups, wave 0); matrix pipe alone would need %d" % (
-    np.median(t[:, 0, 12] - t[:, 0, 0]), (K // 32) * 3072))
+    np.median(t[:, 0, 1] - t[:, 0, 0]), (K // 32) * 3072))
