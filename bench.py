@@ -328,7 +328,7 @@ def roofline_object(net, args, device, ms_per_step):
         out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
                                "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0),
                                "winograd_f3x3_3x3_atrous_subgrids": kinds.get(4, 0),
-                               "pointwise_persistent": kinds.get(5, 0)}
+                               "pointwise_persistent": kinds.get(5, 0), "fc_few_rows": kinds.get(6, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
                        "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
                        "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction from the quoted collection")

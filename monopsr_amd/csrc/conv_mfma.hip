@@ -1115,6 +1115,21 @@ int pointwise_override();
 int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
                       int relu, float *y, int N, hipStream_t s);
 
+bool fc_rows_applies(long long M, int K, int N);
+int fc_rows(const float *x, long long M, int K, const float *w, const float *bias, const float *residual, int relu,
+            float *y, int N, hipStream_t s);
+
+// True when conv2d() sends a 1x1 layer / FC with few rows to fc_rows_kernel (pointwise.hip): launches whose 64 x 64
+// tiles would cover less than half of the CUs (the heads' 256-row layers).
+bool conv2d_takes_fc_rows(long long M, int C, int N, int KH, int KW, int split_k)
+{
+    const int pw = pointwise_override();
+    if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || g_math.load() != MATH_FP32 || g_tile_override.load() >= 0 ||
+        g_sched_override.load() >= 0 || !fc_rows_applies(M, C, N))
+        return false;
+    return ((M + 63) / 64) * ((N + 63) / 64) <= 128;
+}
+
 // True when conv2d() sends a 1x1 layer to the persistent pointwise kernel (pointwise.hip): the wide trunk layers, where
 // the launch has at least two 96 x 128 tiles per CU (measured: block3's conv1 / conv3 / shortcut, block2's conv3, the
 // squash layers; block2's conv1 with its 384 tiles stays on the implicit GEMM).
@@ -1223,6 +1238,8 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     }
     if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
         return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
+    if (conv2d_takes_fc_rows(M64, C, N, KH, KW, split_k))
+        return fc_rows(x, M64, C, w, bias, residual, relu, y, N, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;
@@ -1344,7 +1361,7 @@ extern "C" int mpsr_get_conv_math(void) { return g_math; }
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
 // kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,
 // 3 = Winograd F(4x4,3x3), 4 = Winograd F(3x3,3x3) on the 3x3 sub-grids of an atrous layer, 5 = the pointwise kernel
-// of the wide 1x1 layers (pointwise.hip); and
+// of the wide 1x1 layers, 6 = the few-row FC kernel (both pointwise.hip); and
 // the multiply-add FLOPs the chosen kernel really issues (2 x MACs): the Winograd kernels 16/36 or 36/144 of the direct count,
 // the implicit GEMM with border classes only the in-image taps.  For reporting (bench.py), not part of the compute path.
 extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
@@ -1383,6 +1400,11 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
     }
     if (mpsr::conv2d_takes_pointwise((long long)B * H * W, C, N, KH, KW, 0)) {
         *kind = 5;  // the persistent pointwise kernel
+        *executed_flops = 2.0 * M * C * N;
+        return MPSR_OK;
+    }
+    if (mpsr::conv2d_takes_fc_rows((long long)B * H * W, C, N, KH, KW, 0)) {
+        *kind = 6;  // few-row FC kernel
         *executed_flops = 2.0 * M * C * N;
         return MPSR_OK;
     }

@@ -350,6 +350,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fully-connected layers with few rows (the heads: M = batch = 256 rows, K ~ 1024, N = 1024 / 27 / 2; reference
+// monopsr_output_builder.py:126-302).  A 64 x 64-tile GEMM makes 64 workgroups of them -- a quarter of the CUs, each
+// running a 1000-deep K loop alone (36 us per layer).  Here a workgroup owns ONE 32 x 32 output tile (8 x 32 = 256
+// workgroups for 256 x 1024) and its four waves split K; both operands' fragments come straight from global memory
+// (lane = (row, k half), 16 bytes: the four 8-k chunks of a 128-byte line are requested together, eight chunks in
+// flight per wave), no LDS in the K loop; the four partial tiles are summed through LDS and wave 0 applies bias /
+// residual / ReLU.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, const float *__restrict__ residual,
+                                                      float *__restrict__ y, int M, int N, int K, int relu,
+                                                      unsigned xbytes, unsigned wbytes)
+{
+    __shared__ __attribute__((aligned(16))) float part[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = (N + 31) >> 5;
+    const int r0 = (blockIdx.x / ntn) * 32, n0 = (blockIdx.x % ntn) * 32;
+    const int kper = K >> 2;            // K a multiple of 32: every wave gets whole 8-k chunks
+    const int nch = kper >> 3;          // chunks per wave
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned OOB = 0x80000000u;
+    const unsigned koff = (unsigned)(wave * kper + 4 * h) * 4u;
+    const unsigned aoff = r0 + i < M ? (unsigned)(r0 + i) * (unsigned)K * 4u + koff : OOB;
+    const unsigned boff = n0 + i < N ? (unsigned)(n0 + i) * (unsigned)K * 4u + koff : OOB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, (int)wbytes, 0x00020000);
+    constexpr int PF = 8;  // chunks in flight
+    float4 fa[PF], fb[PF];
+    auto request = [&](int c, int slot) __attribute__((always_inline)) {
+        const bool live = c < nch;
+        const __amdgpu_buffer_rsrc_t rxl =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, live ? (int)xbytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rwl =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, live ? (int)wbytes : 0, 0x00020000);
+        fa[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxl, aoff, (live ? c : 0) * 32, 0));
+        fb[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwl, boff, (live ? c : 0) * 32, 0));
+    };
+    (void)rx;
+    (void)rw;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < PF; ++c) request(c, c);
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const float4 a = fa[u], b = fb[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            request(c0 + PF + u, u);
+        }
+    }
+    // (the 16-pass MFMA needs 18 wait states before its result is read; explicit as in conv_mfma.hip)
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    // accumulator element e of a lane: row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31
+    const int col = n0 + i;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float v = ((acc[e] + part[0][e][lane]) + part[1][e][lane]) + part[2][e][lane] + bv;
+        if (row < M && col < N) {
+            if (residual) v += residual[(size_t)row * N + col];
+            if (relu) v = fmaxf(v, 0.f);
+            y[(size_t)row * N + col] = v;
+        }
+    }
+}
+
 std::atomic<int> g_pw_override{-1};  // -1 heuristic, 0 never, 1 wherever it applies
 std::atomic<int> g_pws_per_cu{2};
 unsigned long long *g_pw_trace = nullptr;
@@ -414,6 +494,26 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
     }
 #undef MPSR_PW
     MPSR_CHECK_LAUNCH("pw_conv_kernel");
+    return MPSR_OK;
+}
+
+
+// Few-row fully-connected layers (fc_rows_kernel): K a multiple of 32 up to 4096 (longer K: the stream-K kernel, whose
+// tiles share the operand traffic), 32-bit byte offsets.
+bool fc_rows_applies(long long M, int K, int N)
+{
+    return M > 0 && M <= 2048 && K >= 128 && K <= 4096 && K % 32 == 0 && N > 0 && M * K * 4 < 0x7f000000LL &&
+           (long long)N * K * 4 < 0x7f000000LL;
+}
+
+int fc_rows(const float *x, long long M, int K, const float *w, const float *bias, const float *residual, int relu,
+            float *y, int N, hipStream_t s)
+{
+    MPSR_REQUIRE(fc_rows_applies(M, K, N), "fc_rows: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
+    const unsigned grid = (unsigned)(((M + 31) / 32) * ((N + 31) / 32));
+    hipLaunchKernelGGL(fc_rows_kernel<0>, dim3(grid), dim3(256), 0, s, x, w, bias, residual, y, (int)M, N, K, relu,
+                       (unsigned)(M * K * 4), (unsigned)((long long)N * K * 4));
+    MPSR_CHECK_LAUNCH("fc_rows_kernel");
     return MPSR_OK;
 }
 

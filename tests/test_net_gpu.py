@@ -358,6 +358,48 @@ def test_conv2d_pointwise_vs_fp64(B, H, Wd, C, N, has_bias, has_res, relu):
     _close(got, run(0), 1e-5, "pointwise vs implicit GEMM")
 
 
+@pytest.mark.parametrize("M,K,N,has_bias,has_res,relu", [
+    (256, 1056, 1024, True, False, True),   # the heads' first FC (concat row padded to a multiple of 32)
+    (256, 1024, 27, True, False, False),    # narrow output: one column tile, 5 dead columns
+    (256, 1024, 2, False, False, False),
+    (100, 160, 40, True, True, True),       # rows and columns past the end, residual
+    (1, 128, 33, True, False, True)])
+def test_fc_few_rows_vs_fp64(M, K, N, has_bias, has_res, relu):
+    """Fully-connected layers with few rows (csrc/pointwise.hip fc_rows_kernel: one 32 x 32 tile per workgroup, its four
+    waves split K) against float64, and that the plan reports them."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, 1, 1, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    res = rng.standard_normal((M, 1, 1, N)).astype(np.float32) if has_res else None
+    ref = x.reshape(M, K).astype(np.float64) @ w.T.astype(np.float64)
+    if has_bias:
+        ref = ref + bias
+    if has_res:
+        ref = ref + res.reshape(M, N)
+    if relu:
+        ref = np.maximum(ref, 0)
+    lib = _lib.lib()
+    kind, flops = ctypes.c_int(-1), ctypes.c_double(0)
+    _lib.check(lib.mpsr_conv2d_plan(M, 1, 1, K, N, 1, 1, 1, ctypes.byref(kind), ctypes.byref(flops)))
+    assert kind.value == 6 and flops.value == 2.0 * M * K * N
+    got = dn.conv2d(_dev(x), _dev(w), _dev(bias) if has_bias else None, _dev(res) if has_res else None, 1, 1, 1, relu,
+                    split_k=1)
+    _close(got.reshape(M, N), torch.from_numpy(ref), 1e-5, "few-row FC %s" % ((M, K, N),))
+    again = dn.conv2d(_dev(x), _dev(w), _dev(bias) if has_bias else None, _dev(res) if has_res else None, 1, 1, 1, relu,
+                      split_k=1)
+    assert torch.equal(got, again), "not deterministic"
+    lib.mpsr_debug_set_conv_pointwise(0)
+    try:
+        gemm = dn.conv2d(_dev(x), _dev(w), _dev(bias) if has_bias else None, _dev(res) if has_res else None, 1, 1, 1, relu,
+                         split_k=1)
+    finally:
+        lib.mpsr_debug_set_conv_pointwise(-1)
+    _close(got, gemm, 1e-5, "few-row FC vs implicit GEMM")
+
+
 @pytest.mark.parametrize("B,dil,C,N,has_bias,relu", [
     (8, 4, 64, 64, True, True), (3, 4, 32, 40, False, False), (1, 4, 16, 4, True, False), (5, 2, 48, 200, True, True),
     (64, 4, 256, 256, True, True), (7, 3, 16, 65, True, True), (33, 4, 128, 128, True, True)])
