@@ -70,10 +70,11 @@ class DeviceNet:
     # ------------------------------------------------------------------ single FC layers (output builder)
     def fully_connected(self, x, name, relu):
         """slim.fully_connected `name` on x (B, fin) through the HIP GEMM; the input is zero-padded to a multiple
-        of 4 channels (the kernel's 16-byte load granularity)."""
+        of 32 channels (what the fused heads entry point pads its concat rows to: the same few-row FC kernel then
+        serves both, csrc/pointwise.hip)."""
         if name not in self._fc_cache:
             w = self._weights[name + "/weights"]  # (in, out)
-            kpad = (w.shape[0] + 3) // 4 * 4
+            kpad = (w.shape[0] + 31) // 32 * 32
             w_ok = np.zeros((w.shape[1], kpad), np.float32)
             w_ok[:, :w.shape[0]] = w.T
             self._fc_cache[name] = (torch.from_numpy(w_ok).to(self.device),

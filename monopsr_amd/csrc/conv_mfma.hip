@@ -1119,15 +1119,15 @@ bool fc_rows_applies(long long M, int K, int N);
 int fc_rows(const float *x, long long M, int K, const float *w, const float *bias, const float *residual, int relu,
             float *y, int N, hipStream_t s);
 
-// True when conv2d() sends a 1x1 layer / FC with few rows to fc_rows_kernel (pointwise.hip): launches whose 64 x 64
-// tiles would cover less than half of the CUs (the heads' 256-row layers).
-bool conv2d_takes_fc_rows(long long M, int C, int N, int KH, int KW, int split_k)
+// True when conv2d() sends a fully-connected layer (H = W = 1: a row is an instance) with few rows to fc_rows_kernel
+// (pointwise.hip): the heads' layers, whose 64 x 64 tiles would cover a quarter of the CUs.  The rule looks at nothing
+// but "FC with at most 2048 rows": that kernel sums K in another order than the implicit GEMM, and an instance's
+// result must not depend on how a batch was cut into chunks (DeviceNet.MAX_CHUNK; test_chunked_batches_*).
+bool conv2d_takes_fc_rows(int H, int W, long long M, int C, int N, int KH, int KW, int split_k)
 {
     const int pw = pointwise_override();
-    if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || g_math.load() != MATH_FP32 || g_tile_override.load() >= 0 ||
-        g_sched_override.load() >= 0 || !fc_rows_applies(M, C, N))
-        return false;
-    return ((M + 63) / 64) * ((N + 63) / 64) <= 128;
+    return H == 1 && W == 1 && KH == 1 && KW == 1 && split_k <= 1 && pw != 0 && g_math.load() == MATH_FP32 &&
+           g_tile_override.load() < 0 && g_sched_override.load() < 0 && fc_rows_applies(M, C, N);
 }
 
 // True when conv2d() sends a 1x1 layer to the persistent pointwise kernel (pointwise.hip): the wide trunk layers, where
@@ -1184,6 +1184,21 @@ bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, 
            winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
 }
 
+// True when conv2d() sends a (residual-free) atrous 3x3 layer to the F(3x3,3x3) kernel (network.hip asks before it
+// transforms the filters of all such layers of a trunk in one launch).
+bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int split_k, const float *ws,
+                            size_t ws_floats)
+{
+    const int wino = g_wino_override.load();
+    const long long M64 = (long long)B * H * W;
+    const bool can3 = KH == 3 && KW == 3 && dilation > 1 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
+                      winograd3_applies(H, W, C, dilation) && ws_floats >= winograd3_scratch_floats(C, N) &&
+                      M64 * C * 4 < 0x7f000000LL;
+    const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
+                                     (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64);
+    return can3 && want3;
+}
+
 // Shared by the network-level entry points (network.hip).
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
            float *y, int N, int KH, int KW, int dilation, int relu, int split_k, float *ws, size_t ws_floats,
@@ -1209,15 +1224,8 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // atrous 3x3 layers whose pixel sub-grids are 3x3 (block3's conv2: 12x12 at dilation 4): every sub-grid is one
     // Winograd F(3x3,3x3) tile with an all-zero halo -- 25 products where the border-class implicit GEMM executes 49
     // (winograd3.hip).  fp32 mode only (the bf16x3 implicit GEMM is faster than fp32 Winograd there).
-    {
-        const int wino = g_wino_override.load();
-        const bool can3 = KH == 3 && KW == 3 && dilation > 1 && !residual && split_k == 0 && ws &&
-                          g_math.load() == MATH_FP32 && winograd3_applies(H, W, C, dilation) &&
-                          ws_floats >= winograd3_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
-        const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
-                                         (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64);
-        if (can3 && want3) return conv3x3_winograd3(x, B, H, W, C, w, bias, relu, y, N, dilation, ws, ws_floats, stream);
-    }
+    if (!residual && conv2d_takes_winograd3(B, H, W, C, N, KH, KW, dilation, split_k, ws, ws_floats))
+        return conv3x3_winograd3(x, B, H, W, C, w, bias, relu, y, N, dilation, ws, ws_floats, stream);
     // the big dense 3x3 layers (map decoder) go to a Winograd kernel when the caller leaves the schedule to the
     // library: F(4x4,3x3) (winograd4.hip, 4x fewer multiply-adds) where the map divides into 4x4 blocks, else
     // F(2x2,3x3) (winograd.hip, 2.25x fewer)
@@ -1238,7 +1246,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     }
     if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
         return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
-    if (conv2d_takes_fc_rows(M64, C, N, KH, KW, split_k))
+    if (conv2d_takes_fc_rows(H, W, M64, C, N, KH, KW, split_k))
         return fc_rows(x, M64, C, w, bias, residual, relu, y, N, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
@@ -1403,7 +1411,7 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
         *executed_flops = 2.0 * M * C * N;
         return MPSR_OK;
     }
-    if (mpsr::conv2d_takes_fc_rows((long long)B * H * W, C, N, KH, KW, 0)) {
+    if (mpsr::conv2d_takes_fc_rows(H, W, (long long)B * H * W, C, N, KH, KW, 0)) {
         *kind = 6;  // few-row FC kernel
         *executed_flops = 2.0 * M * C * N;
         return MPSR_OK;

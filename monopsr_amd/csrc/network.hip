@@ -124,7 +124,7 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
 
     int rc;
     if ((rc = mpsr_im2col_root(img, B, H, W, cols, root.cin, stream))) return rc;
-    if ((rc = run_layer(blob, root, cols, (int)Mr, 1, 1, nullptr, rootout, 0, sk, skn, s))) return rc;
+    if ((rc = run_layer(blob, root, cols, B, d.OH, d.OW, nullptr, rootout, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(rootout, B, d.OH, d.OW, root.cout, 3, 2, 1, pooled, stream))) return rc;
 
     const float *cur = pooled;
