@@ -158,7 +158,8 @@ int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int
  *            ~1e-6 relative (tests/test_net_gpu.py checks 1e-5 against fp64).
  * A fully-connected layer is H=W=KH=KW=1.
  * mpsr_conv2d_plan reports, for a layer left to the library (split_k = 0, scratch given), which kernel serves it
- * (*kind: 0 implicit GEMM, 1 Winograd, 2 direct narrow-N kernel) and the multiply-add FLOPs that kernel issues --
+ * (*kind: 0 implicit GEMM, 1 Winograd F(2x2,3x3), 2 direct narrow-N kernel, 3 Winograd F(4x4,3x3), 4 Winograd
+ * F(3x3,3x3) on the sub-grids of an atrous layer, 5 persistent pointwise kernel, 6 few-row fully-connected kernel) and the multiply-add FLOPs that kernel issues --
  * for throughput accounting (bench.py's roofline.executed), not needed to run anything. */
 size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N);
 int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
