@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wino3_filter.h"
 
 namespace mpsr {
 int conv2d(const float *x, int B, int H, int W, int C, const float *w, const float *bias, const float *residual,
@@ -18,6 +19,9 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
                       size_t part_floats);
 size_t winograd4_split_floats(int B, int H, int W, int N);
 extern std::atomic<int> g_wino4_split;
+bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int split_k, const float *ws,
+                            size_t ws_floats);
+bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k);
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s, int in_c8);
 int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
@@ -146,7 +150,17 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
                              c3.cin == c2.cout && (u == 0 || c3.cout == cur_c),
                          "trunk_fwd: records %d..%d do not form a bottleneck unit", li - 3, li - 1);
             float *dst = last ? out : (cur == ping ? pong : ping);
+            // when conv1 runs on the persistent pointwise kernel and conv2 on the F(3x3,3x3) kernel, conv2's filter
+            // transform rides on conv1's launch as a tail job (wino3_filter.h) instead of a launch of its own
+            if (mpsr::conv2d_takes_pointwise((long long)B * d.PH * d.PW, c1.cin, c1.cout, 1, 1, 0) &&
+                mpsr::conv2d_takes_winograd3(B, d.PH, d.PW, c2.cin, c2.cout, c2.kh, c2.kw, c2.dilation, 0, sk, skn)) {
+                mpsr::g_filter_tail_job.w = blob + c2.w_off;
+                mpsr::g_filter_tail_job.u = sk;
+                mpsr::g_filter_tail_job.N = c2.cout;
+                mpsr::g_filter_tail_job.C = c2.cin;
+            }
             if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 0, sk, skn, s))) return rc;
+            mpsr::g_filter_tail_job = mpsr::FilterTailJob();  // (not taken: conv2 transforms its filters itself)
             if ((rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 0, sk, skn, s))) return rc;
             if ((rc = run_layer(blob, c3, t2, B, d.PH, d.PW, residual, dst, 0, sk, skn, s))) return rc;
             cur = dst;

@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wino3_filter.h"
 
 namespace {
 
@@ -63,6 +64,10 @@ struct PwsParams {
     int rgroups, cblocks, ntiles;  // ntiles: padded to 8 x column blocks
     unsigned wbytes;
     unsigned long long *trace;  // -DPWS_TRACE builds: 16 stamps per wave (the workgroup's third tile)
+    // tail job: the F(3x3,3x3) filter transform of the 3x3 layer that follows (wino3_filter.h), shared by all workgroups
+    const float *fw;
+    float *fu;
+    int fN, fC;
 };
 
 // LONG: K >= 256 (eight or more stages: the stores of a tile are spread over the next tile's first eight); otherwise
@@ -342,6 +347,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     if (last & 1) finish(IC<1>{});  // block-uniform
     else finish(IC<0>{});
+    if (p.fw) {  // block-uniform
+        const long long total = (long long)p.fN * p.fC;
+        for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256)
+            mpsr::wino3_filter_one(p.fw, p.fN, p.fC, p.fu, i);
+    }
 #ifdef PWS_TRACE
     if (p.trace && lane == 0) {
         unsigned long long *dst = p.trace + ((size_t)blockIdx.x * 4 + wave) * 16;
@@ -478,6 +488,10 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
     if (grid < unit) grid = unit;
     if (grid > p.ntiles) grid = p.ntiles;
     p.trace = g_pw_trace;
+    // a pending filter-transform job rides on this launch
+    p.fw = g_filter_tail_job.w; p.fu = g_filter_tail_job.u; p.fN = g_filter_tail_job.N; p.fC = g_filter_tail_job.C;
+    if (p.fw) g_filter_tail_done = g_filter_tail_job;
+    g_filter_tail_job = FilterTailJob();
     const size_t lds_bytes = (size_t)LDS_B;
 #define MPSR_PW(RES_, LONG_)                                                                                          \
     do {                                                                                                              \

@@ -1,0 +1,56 @@
+// The filter transform of the F(3x3,3x3) atrous kernel (winograd3.hip) as a device function: winograd3.hip's own
+// launch uses it, and the persistent pointwise kernel (pointwise.hip) runs it as a tail job -- the filters of the 3x3
+// layer that FOLLOWS a 1x1 layer are transformed by that layer's workgroups when they have finished their tiles,
+// instead of by a 6-us launch of their own in front of every one of block3's 23 atrous layers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpsr {
+namespace f3f {
+constexpr int KC = 8, NP = 25;
+}
+
+// U[cb][pos][n][8] = (G' g G'^T)[pos], pos = 5 u + v, for filter g = w[n][(ky*3+kx)*C + c], c = cb*8 + j; i = n * C + c.
+__device__ __forceinline__ void wino3_filter_one(const float *__restrict__ w, int N, int C, float *__restrict__ u, long long i)
+{
+    const int n = (int)(i / C), c = (int)(i - (long long)n * C);
+    double g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(size_t)n * 9 * C + (size_t)(ky * 3 + kx) * C + c];
+    auto gcol = [](double a, double b, double c2, double *o) {  // G' (5x3) applied to one 3-vector
+        o[0] = a / 2.0;
+        o[1] = (a + b + c2) / 2.0;
+        o[2] = (a - b + c2) / 6.0;
+        o[3] = a / 6.0 + b / 3.0 + c2 * (2.0 / 3.0);
+        o[4] = c2;
+    };
+    double t[5][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        double o[5];
+        gcol(g[0][kx], g[1][kx], g[2][kx], o);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) t[r][kx] = o[r];
+    }
+    float *dst = u + ((size_t)(c / f3f::KC) * f3f::NP * N + n) * f3f::KC + (c % f3f::KC);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        double o[5];
+        gcol(t[r][0], t[r][1], t[r][2], o);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) dst[(size_t)(r * 5 + s) * N * f3f::KC] = (float)o[s];
+    }
+}
+
+// A filter-transform job handed from a network-level entry point (network.hip) to the next pointwise launch on this
+// thread, and the note that it was done, for conv3x3_winograd3 to find.
+struct FilterTailJob {
+    const float *w = nullptr;
+    float *u = nullptr;
+    int N = 0, C = 0;
+};
+extern thread_local FilterTailJob g_filter_tail_job;    // pending: consumed by conv1x1_pointwise
+extern thread_local FilterTailJob g_filter_tail_done;   // done by the last pointwise launch: consumed by conv3x3_winograd3
+}  // namespace mpsr

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wino3_filter.h"
 
 namespace {
 
@@ -44,40 +45,10 @@ struct Wino3Params {
     unsigned xbytes, ubytes;
 };
 
-// U[cb][pos][n][8] = (G' g G'^T)[pos], pos = 5 u + v, for filter g = w[n][(ky*3+kx)*C + c], c = cb*8 + j.
 __global__ __launch_bounds__(256) void wino3_filter_kernel(const float *__restrict__ w, int N, int C, float *__restrict__ u)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)N * C) return;
-    const int n = (int)(i / C), c = (int)(i - (long long)n * C);
-    double g[3][3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(size_t)n * 9 * C + (size_t)(ky * 3 + kx) * C + c];
-    auto gcol = [](double a, double b, double c2, double *o) {  // G' (5x3) applied to one 3-vector
-        o[0] = a / 2.0;
-        o[1] = (a + b + c2) / 2.0;
-        o[2] = (a - b + c2) / 6.0;
-        o[3] = a / 6.0 + b / 3.0 + c2 * (2.0 / 3.0);
-        o[4] = c2;
-    };
-    double t[5][3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        double o[5];
-        gcol(g[0][kx], g[1][kx], g[2][kx], o);
-#pragma unroll
-        for (int r = 0; r < 5; ++r) t[r][kx] = o[r];
-    }
-    float *dst = u + ((size_t)(c / f3::KC) * f3::NP * N + n) * f3::KC + (c % f3::KC);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        double o[5];
-        gcol(t[r][0], t[r][1], t[r][2], o);
-#pragma unroll
-        for (int s = 0; s < 5; ++s) dst[(size_t)(r * 5 + s) * N * f3::KC] = (float)o[s];
-    }
+    if (i < (long long)N * C) mpsr::wino3_filter_one(w, N, C, u, i);
 }
 
 // scaled B^T applied to (0, x0, x1, x2, 0): 7 operations
@@ -370,6 +341,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 namespace mpsr {
 
+thread_local FilterTailJob g_filter_tail_job;
+thread_local FilterTailJob g_filter_tail_done;
+
 size_t winograd3_scratch_floats(int C, int N) { return (size_t)f3::NP * N * C; }
 
 // 3x3, dilation d, H = W = 3 d (the sub-grids are 3x3), C % 16 == 0
@@ -391,7 +365,11 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
                  "conv3x3_winograd3: tensor exceeds the 2 GiB this kernel's offsets address; split the batch");
     MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino3_conv_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
-    {
+    // (the filters may already have been transformed into `ws` by the tail job of the preceding pointwise launch)
+    const bool ready = g_filter_tail_done.w == w && g_filter_tail_done.u == ws && g_filter_tail_done.N == N &&
+                       g_filter_tail_done.C == C;
+    g_filter_tail_done = FilterTailJob();
+    if (!ready) {
         const long long total = (long long)N * C;
         hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
         MPSR_CHECK_LAUNCH("wino3_filter_kernel");
