@@ -127,6 +127,13 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
                           workspace_bytes);
 
     int rc;
+    struct TailJobGuard {  // no filter-transform job (wino3_filter.h) outlives this call, whichever way it returns
+        ~TailJobGuard()
+        {
+            mpsr::g_filter_tail_job = mpsr::FilterTailJob();
+            mpsr::g_filter_tail_done = mpsr::FilterTailJob();
+        }
+    } tail_job_guard;
     if ((rc = mpsr_im2col_root(img, B, H, W, cols, root.cin, stream))) return rc;
     if ((rc = run_layer(blob, root, cols, B, d.OH, d.OW, nullptr, rootout, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(rootout, B, d.OH, d.OW, root.cout, 3, 2, 1, pooled, stream))) return rc;
