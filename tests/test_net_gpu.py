@@ -856,3 +856,28 @@ def test_conv2d_split_k_with_classes_and_auto(case, split):
         finally:
             _lib.lib().mpsr_debug_set_conv_classes(-1)
         _close(got, ref, 2e-6, "split %d classes %d %s" % (split, classes, case))
+
+@pytest.mark.parametrize("B", [43, 171])
+def test_network_with_and_without_the_pointwise_kernels(B):
+    """The persistent pointwise / few-row FC kernels (csrc/pointwise.hip) take different subsets of the 1x1 layers at
+    different batch sizes (>= 512 tiles per layer: conv3 from 43 crops on, conv1 from 171); the network's outputs must
+    agree with the implicit-GEMM-only run to summation-order accuracy at any of them."""
+    import bench
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    dev = torch.device("cuda", 0)
+    net = dn.DeviceNet(W.synthetic_weights(seed=0), device=dev)
+    inp, _ = bench.make_inputs(B, 256, 0, dev)
+    step = bench.Step(net, inp, 256)
+    lib = _lib.lib()
+    lib.mpsr_debug_set_conv_pointwise(0)
+    try:
+        xyz0, out0 = step.forward_net()
+        xyz0, cen0 = xyz0.clone(), out0["centroids"].clone()
+    finally:
+        lib.mpsr_debug_set_conv_pointwise(-1)
+    xyz1, out1 = step.forward_net()
+    _close(xyz1, xyz0, 5e-5, "xyz map, B = %d" % B)
+    _close(out1["centroids"], cen0, 5e-5, "centroids, B = %d" % B)
+    assert not torch.equal(xyz1, xyz0)  # it really took other kernels
