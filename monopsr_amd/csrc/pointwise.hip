@@ -95,11 +95,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unsigned lo, hi, left;
     };
     auto row_ref = [&](const float *base, int width, int row, bool live) __attribute__((always_inline)) {
-        const unsigned long long a = reinterpret_cast<unsigned long long>(base + (size_t)row * width);
+        const bool in = live && base && row >= 0 && row < p.M;  // (a dead reference points at row 0 with length 0)
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base + (size_t)(in ? row : 0) * width);
         RowRef r;
         r.lo = (unsigned)a;
         r.hi = (unsigned)(a >> 32);
-        r.left = (live && base && row < p.M) ? (unsigned)(p.M - row) * (unsigned)width * 4u : 0u;
+        r.left = in ? (unsigned)(p.M - row) * (unsigned)width * 4u : 0u;
         return r;
     };
     // descriptor `rows` rows further on.  max(left - off, 0) in the scalar ALU (hipcc picks the vector ALU's saturating
