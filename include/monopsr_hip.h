@@ -195,6 +195,14 @@ int mpsr_im2col_root(const float *x, int B, int H, int W, float *cols, int kpad,
  * tiles the kernel stages anyway; also pre-zeroed by the caller). */
 int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
                           int dilation, float *dw, float *db, mpsr_stream_t stream);
+/* The same with caller scratch: `ws` of at least mpsr_conv2d_wgrad_scratch_floats(...) floats (0 when the layer does
+ * not use any) lets the big dense 3x3 layers (the map decoder: stride 1, no dilation, H and W multiples of 4, C and N
+ * multiples of 32, B*H*W >= 65536) run in the Winograd F(4x4,3x3) domain -- 36 products per channel pair and 4x4
+ * block where the direct weight gradient has 144; results agree with mpsr_conv2d_wgrad_f32 to ~1e-4 of the
+ * gradient's scale.  ws = NULL or too small: exactly mpsr_conv2d_wgrad_f32. */
+size_t mpsr_conv2d_wgrad_scratch_floats(int B, int H, int W, int C, int N, int KH, int KW, int dilation);
+int mpsr_conv2d_wgrad_ws_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
+                             int dilation, float *dw, float *db, float *ws, size_t ws_floats, mpsr_stream_t stream);
 
 /* Weight re-layout for the data gradient: wd[c][((KH*KW-1-t)*N) + n] = w[n][t*C + c].  Then
  * dx = mpsr_conv2d_nhwc_f32(dy, ..., w = wd, N := C, C := N) with the same KH, KW, dilation. */

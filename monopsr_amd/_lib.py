@@ -73,6 +73,8 @@ SIGNATURES = {
     "mpsr_conv2d_plan": (c_i, [c_i] * 8 + [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
     "mpsr_conv2d_wgrad_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "mpsr_conv2d_wgrad_scratch_floats": (c_sz, [c_i] * 8),
+    "mpsr_conv2d_wgrad_ws_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_sz, c_f]),
     "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_act_bias_grad": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f]),
     "mpsr_bias_grad": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),

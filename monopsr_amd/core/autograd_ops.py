@@ -14,6 +14,7 @@ from monopsr_amd.core import device_net as dn
 
 # split_k argument of every forward / data-gradient convolution: 0 = the library schedules the launch (Winograd for
 # the decoder's dense 3x3 layers and their data gradients, stream-K for the long-K FC layers): 88 -> 81 ms per step
+_WGRAD_SCRATCH = {}
 _SCHED = 0
 
 
@@ -85,8 +86,18 @@ class Conv2dFn(torch.autograd.Function):
                 db4 = torch.zeros((N4,), dtype=torch.float32, device=x.device)
         else:
             dw4, w4 = L.dw, L.w
-        _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
-                                             _lib.ptr(dw4), _lib.ptr(db4), s))
+        # scratch for the layers that take the Winograd-domain weight gradient (the decoder's dense 3x3 layers), kept per
+        # (device, stream) like the forward scheduler's: launches on one stream are ordered
+        nws = lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N4, L.kh, L.kw, L.dilation)
+        ws = None
+        if nws:
+            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+            ws = _WGRAD_SCRATCH.get(key)
+            if ws is None or ws.numel() < nws:
+                ws = _WGRAD_SCRATCH[key] = torch.empty((nws,), dtype=torch.float32, device=x.device)
+        _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
+                                                _lib.ptr(dw4), _lib.ptr(db4), _lib.ptr(ws),
+                                                ws.numel() if ws is not None else 0, s))
         if pad and db4 is not None:
             L.db.add_(db4[:N])
         if pad:

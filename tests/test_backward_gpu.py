@@ -345,3 +345,48 @@ def test_clip_by_norm_segments_matches_per_tensor_clip():
     assert float((net.grads - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
     lo = (net.layers[3].dw.data_ptr() - base) // 4
     assert torch.equal(net.grads[lo:lo + net.layers[3].dw.numel()], before[lo:lo + net.layers[3].dw.numel()])
+
+
+def test_wgrad_winograd_domain_vs_direct_and_fp64():
+    """The Winograd F(4x4,3x3)-domain weight gradient of the decoder's dense 3x3 layers (csrc/winograd4_wgrad.hip:
+    dU = sum over tiles of (A dY A^T) (.) (B^T d B), dg = G^T dU G) against the direct kernel on a layer-sized problem
+    and against float64 autograd on a slice of its filters."""
+    import ctypes
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    B, H, W, C, N = 64, 48, 48, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, H, W, C), device="cuda", generator=g).clamp_(min=0)
+    dy = torch.randn((B, H, W, N), device="cuda", generator=g)
+    nws = lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N, 3, 3, 1)
+    assert nws == 36 * N * C
+    assert lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N, 3, 3, 2) == 0      # atrous: direct kernel
+    assert lib.mpsr_conv2d_wgrad_scratch_floats(B, H + 2, W, C, N, 3, 3, 1) == 0  # not 4x4 blocks
+    ws = torch.empty((nws,), device="cuda")
+    outs = []
+    for wino in (0, 1):
+        dw = torch.zeros((N, 9 * C), device="cuda")
+        db = torch.zeros((N,), device="cuda")
+        lib.mpsr_debug_set_wgrad_winograd(wino)
+        try:
+            _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(x.data_ptr(), dy.data_ptr(), B, H, W, C, N, 3, 3, 1, dw.data_ptr(),
+                                                    db.data_ptr(), ws.data_ptr(), nws, _lib.stream()))
+        finally:
+            lib.mpsr_debug_set_wgrad_winograd(1)
+        outs.append((dw, db))
+    scale = outs[0][0].abs().max().item()
+    assert (outs[1][0] - outs[0][0]).abs().max().item() <= 1e-4 * scale
+    assert not torch.equal(outs[1][0], outs[0][0])  # it really is the other evaluation
+    assert (outs[1][1] - outs[0][1]).abs().max().item() <= 1e-4 * outs[0][1].abs().max().item()
+    # float64 autograd for the first 4 filters
+    xd = x.double().permute(0, 3, 1, 2)
+    w = torch.zeros((4, C, 3, 3), dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv2d(xd, w, padding=1)
+    (y * dy[..., :4].double().permute(0, 3, 1, 2)).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(4, 9 * C)
+    assert (outs[1][0][:4].double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # scratch too small or absent: the direct kernel, same result as mpsr_conv2d_wgrad_f32
+    dw2 = torch.zeros((N, 9 * C), device="cuda")
+    _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(x.data_ptr(), dy.data_ptr(), B, H, W, C, N, 3, 3, 1, dw2.data_ptr(), None,
+                                            None, 0, _lib.stream()))
+    assert (dw2 - outs[0][0]).abs().max().item() <= 1e-5 * scale
