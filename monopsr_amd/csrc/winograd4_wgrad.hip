@@ -11,11 +11,11 @@
 // fp32 atomics and folded back by G^T . G in a second, tiny kernel.
 //
 // Workgroup = 512 threads = 8 waves, a 32 (n) x 32 (c) block of all 36 positions, a slice of the tiles; K step = 8
-// tiles.  Waves 0-3 produce Yh: thread = (n, tile of the step): 16 loads of its 4x4 dY block, 80 operations, 36
-// ds_write_b32; waves 4-7 produce V: thread = (c, tile): 36 loads of the 6x6 patch (out-of-image pixels by an
+// tiles.  Waves 0-3 produce Yh: thread = (tile of the step, n): 16 loads of its 4x4 dY block, 80 operations, 36
+// ds_write_b32; waves 4-7 produce V: thread = (tile, c): 36 loads of the 6x6 patch (out-of-image pixels by an
 // out-of-range offset), 144 operations, 36 stores -- every SIMD hosts one wave of each kind.  Both land in LDS as
-// [position][row n or c][8 tiles] (the 16-byte-half XOR swizzle of winograd4.hip), double buffered (2 x 74 KB); a wave
-// then multiplies its 5 (waves 0-3) or 4 (waves 4-7) positions: two ds_read_b128 per 4 MFMAs.  A thread transforms the
+// [position][8 tiles][32 rows n or c], double buffered (2 x 74 KB); a wave then multiplies its 5 (waves 0-3) or 4
+// (waves 4-7) positions: four ds_read2_b32 per 4 MFMAs.  A thread transforms the
 // patch it requested during the previous step, stores it for the next one, multiplies, and requests the patch after
 // next into the same registers: one barrier per step.
 #include "common.h"
@@ -75,9 +75,11 @@ __device__ __forceinline__ void w4g_body(const W4gParams &p, float *lds, int n0,
 {
     using namespace w4g;
     const int tid = threadIdx.x, lane = tid & 63;
-    // tile of the step and row (n or c) of the operand: a wave = 8 rows x the 8 tiles, tiles fastest -- its 64 stores
-    // of one position are 64 consecutive floats (rows fastest would put 32 lanes on 4 banks), its loads 8 x 32 bytes
-    const int lt = tid & 7, pc = (tid & 255) >> 3;
+    // tile of the step and row (n or c) of the operand: a wave = 2 tiles x all 32 rows, rows fastest -- every load is two
+    // whole 128-byte lines (8 rows x 8 tiles per wave made four waves fetch each line: the L2 -> L1 path, not the
+    // matrix pipe, then set the step time), and with the operands kept as [position][tile][row] in LDS its 64 stores
+    // of one position are 64 consecutive floats
+    const int lt = (tid & 255) >> 5, pc = tid & 31;
     const int tpi = p.th * p.tw;
     const unsigned shift = (unsigned)(p.W + 1) * (unsigned)p.C * 4u;  // x descriptor moved back by one row + one pixel
     char *xback = const_cast<char *>(reinterpret_cast<const char *>(p.x)) - shift;
@@ -123,8 +125,8 @@ __device__ __forceinline__ void w4g_body(const W4gParams &p, float *lds, int n0,
                         float, __builtin_amdgcn_raw_buffer_load_b32(rr, abase, (r * p.W + s) * p.N * 4, 0));
         }
     };
-    // [stage][operand][position][row][8 tiles], 16-byte halves swapped on odd 8-row blocks
-    float *wr = lds + (VPROD ? OPF : 0) + pc * 8 + 4 * ((lt >> 2) ^ ((pc >> 3) & 1)) + (lt & 3);
+    // [stage][operand][position][8 tiles][32 rows]
+    float *wr = lds + (VPROD ? OPF : 0) + lt * 32 + pc;
     auto transform_store = [&](int stage) __attribute__((always_inline)) {
         float *w0 = wr + stage * STAGEF;
         if constexpr (VPROD) {
@@ -151,7 +153,8 @@ __device__ __forceinline__ void w4g_body(const W4gParams &p, float *lds, int n0,
         }
     };
 
-    const float *rd = lds + pos0 * POSF + (lane & 31) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1));
+    // fragment of a lane = (row lane & 31, tiles 4 h .. 4 h + 3 of the step, h = lane >> 5): four floats 32 apart
+    const float *rd = lds + pos0 * POSF + (lane >> 5) * 128 + (lane & 31);
     f32x16 acc[NPOS];
 #pragma unroll
     for (int q = 0; q < NPOS; ++q)
@@ -160,8 +163,9 @@ __device__ __forceinline__ void w4g_body(const W4gParams &p, float *lds, int n0,
     auto multiply = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const float4 a = *reinterpret_cast<const float4 *>(rd + stage * STAGEF + q * POSF);
-            const float4 b = *reinterpret_cast<const float4 *>(rd + stage * STAGEF + OPF + q * POSF);
+            const float *ra = rd + stage * STAGEF + q * POSF, *rb = ra + OPF;
+            const float4 a = make_float4(ra[0], ra[32], ra[64], ra[96]);
+            const float4 b = make_float4(rb[0], rb[32], rb[64], rb[96]);
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[q], 0, 0, 0);
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[q], 0, 0, 0);
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[q], 0, 0, 0);
