@@ -89,12 +89,7 @@ class Conv2dFn(torch.autograd.Function):
         # scratch for the layers that take the Winograd-domain weight gradient (the decoder's dense 3x3 layers), kept per
         # (device, stream) like the forward scheduler's: launches on one stream are ordered
         nws = lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N4, L.kh, L.kw, L.dilation)
-        ws = None
-        if nws:
-            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-            ws = _WGRAD_SCRATCH.get(key)
-            if ws is None or ws.numel() < nws:
-                ws = _WGRAD_SCRATCH[key] = torch.empty((nws,), dtype=torch.float32, device=x.device)
+        ws = dn.stream_scratch(_WGRAD_SCRATCH, x.device, nws) if nws else None
         _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
                                                 _lib.ptr(dw4), _lib.ptr(db4), _lib.ptr(ws),
                                                 ws.numel() if ws is not None else 0, s))

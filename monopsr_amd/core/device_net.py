@@ -180,6 +180,22 @@ class DeviceNet:
 _SCHED_SCRATCH = {}
 
 
+def stream_scratch(cache, device, floats, keep=8):
+    """A float32 scratch of at least `floats` elements for the current stream of `device`, kept in `cache` per (device,
+    stream): launches on one stream are ordered, so they can share it.  At most `keep` streams are remembered (the
+    oldest entry goes first: its memory returns to the caching allocator once the launches using it have run), so
+    short-lived streams do not pin 100 MB each for the life of the process."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < floats:
+        cache.pop(key, None)
+        while len(cache) >= keep:
+            old = cache.pop(next(iter(cache)))
+            old.record_stream(torch.cuda.current_stream(device))
+        ws = cache[key] = torch.empty((floats,), dtype=torch.float32, device=device)
+    return ws
+
+
 def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1):
     """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C)."""
     x, w_ok = x.contiguous(), w_ok.contiguous()
@@ -191,10 +207,7 @@ def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False
     # hundreds of these calls from Python
     if split_k == 0:
         nws = _lib.lib().mpsr_conv2d_scratch_floats(B, H, Wd, N)
-        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-        ws = _SCHED_SCRATCH.get(key)
-        if ws is None or ws.numel() < nws:
-            ws = _SCHED_SCRATCH[key] = torch.empty((nws,), dtype=torch.float32, device=x.device)
+        ws = stream_scratch(_SCHED_SCRATCH, x.device, nws)
     else:
         nws = split_k * B * H * Wd * N if split_k > 1 else 0
         ws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
