@@ -1377,16 +1377,11 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
 {
     MPSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && kind && executed_flops, "conv2d_plan: bad arguments");
     const double M = (double)B * H * W;
-    {
-        const int wo = g_wino_override.load();
-        if (KH == 3 && KW == 3 && dilation > 1 && mpsr::winograd3_applies(H, W, C, dilation) && g_math.load() == MATH_FP32 &&
-            M * C * 4 < 0x7f000000LL &&
-            (wo == 3 || (wo < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
-                         (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64))) {
-            *kind = 4;  // 25 products per 3x3 sub-grid
-            *executed_flops = 2.0 * (double)B * dilation * dilation * 25.0 * C * N;
-            return MPSR_OK;
-        }
+    // (the same predicate conv2d() asks; the plan assumes the scratch is there)
+    if (mpsr::conv2d_takes_winograd3(B, H, W, C, N, KH, KW, dilation, 0, reinterpret_cast<const float *>(16), ~(size_t)0)) {
+        *kind = 4;  // 25 products per 3x3 sub-grid
+        *executed_flops = 2.0 * (double)B * dilation * dilation * 25.0 * C * N;
+        return MPSR_OK;
     }
     const bool wino_any = KH == 3 && KW == 3 && dilation == 1 && M >= 65536 && C >= 64 && N >= 64 &&
                           g_wino_override.load() != 0;
