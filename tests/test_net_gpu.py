@@ -881,3 +881,21 @@ def test_network_with_and_without_the_pointwise_kernels(B):
     _close(xyz1, xyz0, 5e-5, "xyz map, B = %d" % B)
     _close(out1["centroids"], cen0, 5e-5, "centroids, B = %d" % B)
     assert not torch.equal(xyz1, xyz0)  # it really took other kernels
+
+
+def test_scheduler_scratch_is_bounded_over_streams():
+    """The per-(device, stream) scratch of library-scheduled launches is kept for at most eight streams
+    (device_net.stream_scratch): short-lived streams must not pin ~100 MB each for the life of the process."""
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(3)
+    x = _dev(rng.standard_normal((2, 12, 12, 64)).astype(np.float32))
+    w = _dev((rng.standard_normal((64, 64)) / 8).astype(np.float32))
+    ref = dn.conv2d(x, w, None, None, 1, 1, 1, True, split_k=0)
+    for _ in range(12):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            got = dn.conv2d(x, w, None, None, 1, 1, 1, True, split_k=0)
+        st.synchronize()
+        assert torch.equal(got, ref)
+    assert len(dn._SCHED_SCRATCH) <= 8
