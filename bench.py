@@ -171,12 +171,12 @@ class Step:
         B = inp["crops"].shape[0]
         self.ones = torch.ones((B, npts), dtype=torch.float32, device=inp["crops"].device)
 
+    overlap_heads = False  # DeviceNet.forward_instances: True = the FC heads on a second stream next to the map decoder
+
     def forward_net(self):
         i = self.inp
-        crop_feat = self.net.trunk(i["crops"])
-        fb, _, xyz = self.net.squash_decoder(crop_feat, i["full_feat"], (48, 48), want_feat_map=False)
-        out = self.net.heads_fwd(fb, i["boxes"], i["cam_p"], i["view"], i["cls"], i["mean_lwh"], i["z_off"])
-        return xyz, out
+        return self.net.forward_instances(i["crops"], i["full_feat"], i["boxes"], i["cam_p"], i["view"], i["cls"],
+                                          i["mean_lwh"], i["z_off"], overlap_heads=self.overlap_heads)
 
     def __call__(self):
         xyz, out = self.forward_net()

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 typedef void *mpsr_stream_t; /* a hipStream_t; NULL = the null stream */
+typedef void *mpsr_event_t;  /* a hipEvent_t created by the caller */
 
 enum {
     MPSR_OK = 0,
@@ -333,6 +334,27 @@ typedef struct mpsr_layer {
     int64_t b_off; /* (cout) folded bias, or -1 */
 } mpsr_layer;
 
+/* Optional arguments of the *_ex network entry points (NULL = none; zero-initialise, then set what is wanted).
+ *  - filter_cache: the Winograd kernels (F(3x3,3x3) on block3's atrous layers, F(4x4,3x3) on the map decoder) multiply
+ *    by TRANSFORMED filters G g G^T.  Without a cache they are recomputed from `blob` by every call (a launch or a tail
+ *    job per layer).  With a caller-owned buffer of mpsr_filter_cache_floats() floats they are written there by the
+ *    first call (filter_cache_valid = 0) and only read by later calls that pass filter_cache_valid != 0 -- the caller
+ *    vouches that blob / layers / B / shape are the ones the cache was filled for (inference: weights never change;
+ *    a training loop passes 0 or no cache).  A cache that is too small is used for the layers that fit.
+ *  - ready_event (mpsr_squash_decoder_fwd_ex): recorded on `stream` as soon as feat_box3d is complete, so that the
+ *    caller can start the FC heads (mpsr_heads_fwd) on ANOTHER stream while the map decoder still runs -- the heads
+ *    are many small launches that fill the decoder kernels' partially occupied last rounds (reference graph: the two
+ *    branches of net_builder.py:68-89 / monopsr_output_builder.py:126-194 are independent). */
+typedef struct mpsr_net_opts {
+    float *filter_cache;
+    size_t filter_cache_floats;
+    int32_t filter_cache_valid;
+    mpsr_event_t ready_event;
+} mpsr_net_opts;
+
+/* Floats of filter cache that serve every 3x3 layer of `layers` (36 cout cin per dense layer, 25 per atrous one). */
+size_t mpsr_filter_cache_floats(const mpsr_layer *layers, int n_layers);
+
 #define MPSR_TRUNK_LAYERS 94 /* root + 30 bottleneck units x 3 + 3 projection shortcuts */
 
 /* Scratch bytes for mpsr_trunk_fwd on a (B,H,W,3) input. */
@@ -345,6 +367,10 @@ size_t mpsr_trunk_workspace_bytes(int B, int H, int W);
  * root(as 1x1 over im2col, cin=160), then per unit [shortcut?], conv1, conv2, conv3. */
 int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
                    int n_layers, float *out, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
+/* The same with options (filter cache; ready_event is ignored). */
+int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
+                      int n_layers, float *out, void *workspace, size_t workspace_bytes, const mpsr_net_opts *opts,
+                      mpsr_stream_t stream);
 
 #define MPSR_DECODER_LAYERS 7 /* squash 1x1 as two K-halves (crop, full), conv2 x2, conv3 x2, xyz 3x3 */
 
@@ -359,6 +385,11 @@ int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int 
                             const float *blob, const mpsr_layer *layers, int n_layers, float *feat_box3d,
                             float *feat_map, float *xyz_map, void *workspace, size_t workspace_bytes,
                             mpsr_stream_t stream);
+/* The same with options (filter cache; ready_event = feat_box3d complete). */
+int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh, int mw,
+                               const float *blob, const mpsr_layer *layers, int n_layers, float *feat_box3d,
+                               float *feat_map, float *xyz_map, void *workspace, size_t workspace_bytes,
+                               const mpsr_net_opts *opts, mpsr_stream_t stream);
 
 #define MPSR_HEAD_LAYERS 7 /* img_fc (both heads fused along N), prop fc0, fc1, lwh+alpha, reg fc0, fc1, cen_y+cen_z */
 

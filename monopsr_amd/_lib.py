@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPSR_LIB_PATH: development knob for A/B-ing two builds of the library inside one GPU session
 LIB_PATH = os.environ.get("MPSR_LIB_PATH") or os.path.join(_HERE, "libmonopsr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -46,6 +46,12 @@ class HeadOutputs(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ("lwh", "lwh_offs", "alpha_bins", "alpha_regs", "prop_cen_z", "cen_y", "cen_y_offs", "cen_z",
                  "cen_z_offs", "cen_x", "centroids")]
+
+
+class NetOpts(ctypes.Structure):
+    """struct mpsr_net_opts"""
+    _fields_ = [("filter_cache", ctypes.c_void_p), ("filter_cache_floats", ctypes.c_size_t),
+                ("filter_cache_valid", ctypes.c_int32), ("ready_event", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/monopsr_hip.h declares (tests/test_cabi.py checks).
@@ -101,6 +107,11 @@ SIGNATURES = {
                                 ctypes.c_float, c_f, c_f, c_f]),
     "mpsr_trunk_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
+    "mpsr_filter_cache_floats": (c_sz, [ctypes.POINTER(Layer), c_i]),
+    "mpsr_trunk_fwd_ex": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz,
+                                ctypes.POINTER(NetOpts), c_f]),
+    "mpsr_squash_decoder_fwd_ex": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f,
+                                         c_f, c_f, c_sz, ctypes.POINTER(NetOpts), c_f]),
     "mpsr_decoder_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "mpsr_squash_decoder_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f,
                                       c_f, c_f, c_sz, c_f]),

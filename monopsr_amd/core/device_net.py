@@ -23,6 +23,25 @@ class PackedPart:
         self.n = len(records)
 
 
+class FilterCache:
+    """Transformed Winograd filters of one weight blob kept across calls (mpsr_net_opts.filter_cache): filled by the
+    first native call, only read afterwards.  Valid for one (blob, batch, shape): a different key refills it."""
+
+    def __init__(self, part, device):
+        n = _lib.lib().mpsr_filter_cache_floats(part.layers, part.n)
+        self.buf = torch.empty((int(n),), dtype=torch.float32, device=device) if n else None
+        self.key = None
+
+    def opts(self, key, event=None):
+        o = _lib.NetOpts()
+        if self.buf is not None:
+            o.filter_cache, o.filter_cache_floats = self.buf.data_ptr(), self.buf.numel()
+            o.filter_cache_valid = 1 if self.key == key else 0
+            self.key = key
+        o.ready_event = event
+        return o
+
+
 class Workspace:
     """Grow-only scratch buffer on one device (allocation stays outside the C ABI)."""
 
@@ -56,6 +75,15 @@ class DeviceNet:
         self.ws_heads = Workspace(self.device)
         self._weights = weights
         self._fc_cache = {}
+        self.fcache = {}          # FilterCache per weight blob, created on first use
+        self.heads_stream = None  # second HIP stream of forward_instances (created on first use)
+
+    def _filter_cache(self, which, part):
+        """Weights of a DeviceNet never change after packing: the Winograd-transformed filters are computed once."""
+        d = self.__dict__.setdefault("fcache", {})
+        if d.get(which) is None:
+            d[which] = FilterCache(part, self.device)
+        return d[which]
 
     def clone_with_own_scratch(self):
         """Same device weights, separate workspaces: one clone per HIP stream when instance shards run
@@ -65,6 +93,8 @@ class DeviceNet:
         other.ws_trunk, other.ws_dec, other.ws_heads = Workspace(self.device), Workspace(self.device), \
             Workspace(self.device)
         other.ws_trunk_full, other.side_stream = Workspace(self.device), None
+        other.fcache = {}  # (a shared cache would be filled by two streams at once)
+        other.heads_stream = None
         return other
 
     # ------------------------------------------------------------------ single FC layers (output builder)
@@ -111,17 +141,24 @@ class DeviceNet:
         lib = _lib.lib()
         nbytes = lib.mpsr_trunk_workspace_bytes(B, H, Wd)
         ws = (self.ws_trunk if which == "crop" else self.ws_trunk_full).get(nbytes)
-        _lib.check(lib.mpsr_trunk_fwd(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
-                                      _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        opts = self._filter_cache(which, part).opts((B, H, Wd))
+        _lib.check(lib.mpsr_trunk_fwd_ex(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
+                                         _lib.ptr(out), _lib.ptr(ws), ws.numel(), ctypes.byref(opts), _lib.stream()))
         return out
 
     # ------------------------------------------------------------------ squash + decoder (+ xyz head)
-    def squash_decoder(self, crop_feat, full_feat, map_size=(48, 48), want_feat_map=True, want_xyz=True):
+    def squash_decoder(self, crop_feat, full_feat, map_size=(48, 48), want_feat_map=True, want_xyz=True,
+                       box3d_event=None):
+        """-> (features_for_box_3d, features_for_map or None, inst_xyz_map_local).  box3d_event: a recorded
+        torch.cuda.Event that the native call re-records on the current stream as soon as features_for_box_3d is
+        complete (single-chunk batches only) -- another stream may then run the heads next to the map decoder."""
         crop_feat, full_feat = crop_feat.contiguous(), full_feat.contiguous()
         B, fh, fw, _ = crop_feat.shape
         if B > self.MAX_CHUNK:
             parts = [self.squash_decoder(crop_feat[i:i + self.MAX_CHUNK], full_feat[i:i + self.MAX_CHUNK], map_size,
                                          want_feat_map, want_xyz) for i in range(0, B, self.MAX_CHUNK)]
+            if box3d_event is not None:
+                box3d_event.record()
             return tuple(torch.cat([p[k] for p in parts], 0) if parts[0][k] is not None else None for k in range(3))
         mh, mw = map_size
         recs = self.decoder.records
@@ -132,11 +169,43 @@ class DeviceNet:
         lib = _lib.lib()
         nbytes = lib.mpsr_decoder_workspace_bytes(B, fh, fw, mh, mw)
         ws = self.ws_dec.get(nbytes)
-        _lib.check(lib.mpsr_squash_decoder_fwd(_lib.ptr(crop_feat), _lib.ptr(full_feat), B, fh, fw, mh, mw,
-                                               _lib.ptr(self.decoder.blob), self.decoder.layers, self.decoder.n,
-                                               _lib.ptr(feat_box), _lib.ptr(feat_map), _lib.ptr(xyz), _lib.ptr(ws),
-                                               ws.numel(), _lib.stream()))
+        opts = self._filter_cache("dec", self.decoder).opts((B, fh, fw, mh, mw, want_feat_map),
+                                       box3d_event.cuda_event if box3d_event is not None else None)
+        _lib.check(lib.mpsr_squash_decoder_fwd_ex(_lib.ptr(crop_feat), _lib.ptr(full_feat), B, fh, fw, mh, mw,
+                                                  _lib.ptr(self.decoder.blob), self.decoder.layers, self.decoder.n,
+                                                  _lib.ptr(feat_box), _lib.ptr(feat_map), _lib.ptr(xyz), _lib.ptr(ws),
+                                                  ws.numel(), ctypes.byref(opts), _lib.stream()))
         return feat_box, feat_map, xyz
+
+    # ------------------------------------------------------------------ the whole instance path
+    def forward_instances(self, crops, full_feat, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset,
+                          map_size=(48, 48), overlap_heads=False, **head_kw):
+        """crops (B,48,48,3) + full-image feature crop (B,12,12,1024) + the box scalars -> (inst_xyz_map_local,
+        head outputs): trunk, squash + map decoder + xyz head, FC heads (net_builder.py:30-96 +
+        monopsr_output_builder.py:95-661).  The heads only need features_for_box_3d, which exists after the squash
+        layer's max-pool: with `overlap_heads` they run on a second HIP stream NEXT TO the map decoder (their ~10 small
+        launches fill the decoder kernels' partially occupied rounds) and the current stream waits for them at the
+        end; results are bit-identical to the one-stream order."""
+        crop_feat = self.trunk(crops)
+        if not overlap_heads:
+            fb, _, xyz = self.squash_decoder(crop_feat, full_feat, map_size, want_feat_map=False)
+            return xyz, self.heads_fwd(fb, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset, **head_kw)
+        main = torch.cuda.current_stream(self.device)
+        if self.heads_stream is None:
+            self.heads_stream = torch.cuda.Stream(self.device)
+            self._box3d_event = torch.cuda.Event()
+        ev = self._box3d_event
+        ev.record(main)  # (creates the native event on first use; the native call records it again, later)
+        fb, _, xyz = self.squash_decoder(crop_feat, full_feat, map_size, want_feat_map=False, box3d_event=ev)
+        side = self.heads_stream
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            out = self.heads_fwd(fb, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset, **head_kw)
+        fb.record_stream(side)
+        main.wait_stream(side)
+        for t in out.values():
+            t.record_stream(main)
+        return xyz, out
 
     # ------------------------------------------------------------------ heads
     def heads_fwd(self, feat_box3d, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset,

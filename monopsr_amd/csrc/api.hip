@@ -10,7 +10,7 @@ char *error_buffer()
 }  // namespace mpsr
 
 extern "C" const char *mpsr_last_error(void) { return mpsr::error_buffer(); }
-extern "C" int mpsr_abi_version(void) { return 3; }
+extern "C" int mpsr_abi_version(void) { return 4; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host.  Used by the TensorFlow
 // checkpoint reader/writer (core/tf_checkpoint.py) to verify block trailers and tensor payloads.

@@ -66,6 +66,48 @@ int run_layer(const float *blob, const mpsr_layer &L, const float *x, int B, int
 
 constexpr int kTrunkUnits[3] = {3, 4, 23};
 
+// floats of filter cache a 3x3 layer gets: F(4x4,3x3) keeps 36 values per filter, F(3x3,3x3) (atrous layers) 25
+inline size_t cache_floats_of(const mpsr_layer &L)
+{
+    if (L.kh != 3 || L.kw != 3) return 0;
+    return mpsr::align_up((size_t)(L.dilation > 1 ? 25 : 36) * (size_t)L.cout * (size_t)L.cin, 64);
+}
+
+// Walks the caller's filter cache (mpsr_net_opts) layer by layer in execution order: every 3x3 layer owns a fixed slice,
+// offered to the Winograd entry points through g_filter_cache_slot right before the layer runs.
+struct FilterCache {
+    float *base = nullptr;
+    size_t floats = 0, used = 0;
+    bool valid = false;
+    explicit FilterCache(const mpsr_net_opts *o)
+    {
+        if (o && o->filter_cache && o->filter_cache_floats) {
+            base = o->filter_cache;
+            floats = o->filter_cache_floats;
+            valid = o->filter_cache_valid != 0;
+        }
+    }
+    // slice of layer L (nullptr: no cache, or it is full); call once per 3x3 layer, in order
+    float *take(const mpsr_layer &L)
+    {
+        const size_t need = cache_floats_of(L);
+        if (!base || need == 0) return nullptr;
+        float *r = used + need <= floats ? base + used : nullptr;
+        used += need;
+        return r;
+    }
+    void offer(const float *w, float *slice, const mpsr_layer &L) const
+    {
+        mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot();
+        if (slice) {
+            mpsr::g_filter_cache_slot.w = w;
+            mpsr::g_filter_cache_slot.u = slice;
+            mpsr::g_filter_cache_slot.floats = cache_floats_of(L);
+            mpsr::g_filter_cache_slot.ready = valid;
+        }
+    }
+};
+
 struct TrunkDims {
     int OH, OW, PH, PW;
 };
@@ -94,8 +136,23 @@ extern "C" size_t mpsr_trunk_workspace_bytes(int B, int H, int W)
            fbytes(mpsr::conv_scratch_floats((long long)(Mr > Mp ? Mr : Mp), 1024));
 }
 
+extern "C" size_t mpsr_filter_cache_floats(const mpsr_layer *layers, int n_layers)
+{
+    size_t n = 0;
+    if (layers)
+        for (int i = 0; i < n_layers; ++i) n += cache_floats_of(layers[i]);
+    return n;
+}
+
 extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
                               int n_layers, float *out, void *workspace, size_t workspace_bytes, mpsr_stream_t stream)
+{
+    return mpsr_trunk_fwd_ex(img, B, H, W, blob, layers, n_layers, out, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const float *blob, const mpsr_layer *layers,
+                                 int n_layers, float *out, void *workspace, size_t workspace_bytes,
+                                 const mpsr_net_opts *opts, mpsr_stream_t stream)
 {
     MPSR_REQUIRE(B >= 0 && H >= 7 && W >= 7, "trunk_fwd: bad input shape (B=%d H=%d W=%d)", B, H, W);
     MPSR_REQUIRE(n_layers == MPSR_TRUNK_LAYERS, "trunk_fwd: expected %d layer records, got %d", MPSR_TRUNK_LAYERS,
@@ -132,8 +189,10 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
         {
             mpsr::g_filter_tail_job = mpsr::FilterTailJob();
             mpsr::g_filter_tail_done = mpsr::FilterTailJob();
+            mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot();
         }
     } tail_job_guard;
+    FilterCache cache(opts);
     if ((rc = mpsr_im2col_root(img, B, H, W, cols, root.cin, stream))) return rc;
     if ((rc = run_layer(blob, root, cols, B, d.OH, d.OW, nullptr, rootout, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(rootout, B, d.OH, d.OW, root.cout, 3, 2, 1, pooled, stream))) return rc;
@@ -159,16 +218,22 @@ extern "C" int mpsr_trunk_fwd(const float *img, int B, int H, int W, const float
             float *dst = last ? out : (cur == ping ? pong : ping);
             // when conv1 runs on the persistent pointwise kernel and conv2 on the F(3x3,3x3) kernel, conv2's filter
             // transform rides on conv1's launch as a tail job (wino3_filter.h) instead of a launch of its own
-            if (mpsr::conv2d_takes_pointwise((long long)B * d.PH * d.PW, c1.cin, c1.cout, 1, 1, 0) &&
+            // (with a VALID filter cache there is nothing to transform; with one being filled the job writes the slice)
+            float *uslice = cache.take(c2);
+            if (!(uslice && cache.valid) &&
+                mpsr::conv2d_takes_pointwise((long long)B * d.PH * d.PW, c1.cin, c1.cout, 1, 1, 0) &&
                 mpsr::conv2d_takes_winograd3(B, d.PH, d.PW, c2.cin, c2.cout, c2.kh, c2.kw, c2.dilation, 0, sk, skn)) {
                 mpsr::g_filter_tail_job.w = blob + c2.w_off;
-                mpsr::g_filter_tail_job.u = sk;
+                mpsr::g_filter_tail_job.u = uslice ? uslice : sk;
                 mpsr::g_filter_tail_job.N = c2.cout;
                 mpsr::g_filter_tail_job.C = c2.cin;
             }
             if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 0, sk, skn, s))) return rc;
             mpsr::g_filter_tail_job = mpsr::FilterTailJob();  // (not taken: conv2 transforms its filters itself)
-            if ((rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 0, sk, skn, s))) return rc;
+            cache.offer(blob + c2.w_off, uslice, c2);
+            rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 0, sk, skn, s);
+            mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot();
+            if (rc) return rc;
             if ((rc = run_layer(blob, c3, t2, B, d.PH, d.PW, residual, dst, 0, sk, skn, s))) return rc;
             cur = dst;
             cur_c = c3.cout;
@@ -194,6 +259,15 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
                                        int mw, const float *blob, const mpsr_layer *L, int n_layers,
                                        float *feat_box3d, float *feat_map, float *xyz_map, void *workspace,
                                        size_t workspace_bytes, mpsr_stream_t stream)
+{
+    return mpsr_squash_decoder_fwd_ex(crop_feat, full_feat, B, fh, fw, mh, mw, blob, L, n_layers, feat_box3d, feat_map,
+                                      xyz_map, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh,
+                                          int mw, const float *blob, const mpsr_layer *L, int n_layers,
+                                          float *feat_box3d, float *feat_map, float *xyz_map, void *workspace,
+                                          size_t workspace_bytes, const mpsr_net_opts *opts, mpsr_stream_t stream)
 {
     MPSR_REQUIRE(B >= 0 && fh >= 2 && fw >= 2 && mh >= 2 && mw >= 2 && mh % 2 == 0 && mw % 2 == 0,
                  "squash_decoder_fwd: bad shape");
@@ -239,6 +313,12 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
     if ((rc = run_layer(blob, L[0], crop_feat, B, fh, fw, nullptr, part, 0, sk, skn, s))) return rc;
     if ((rc = run_layer(blob, L[1], full_feat, B, fh, fw, part, sq, 0, sk, skn, s))) return rc;
     if ((rc = mpsr_max_pool(sq, B, fh, fw, csq, 2, 2, 0, feat_box3d, stream))) return rc;
+    // features_for_box_3d is complete: the caller's FC heads may start on another stream
+    if (opts && opts->ready_event) MPSR_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(opts->ready_event), s));
+    struct SlotGuard {
+        ~SlotGuard() { mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot(); }
+    } slot_guard;
+    FilterCache cache(opts);
     // Channel-blocked internal tensors ([C/8][H][W][8], "C8") when all four 3x3 layers run on the F(4x4,3x3) kernel: a
     // K step of that kernel then reads whole 128-byte lines instead of 32 bytes of every pixel's line (NHWC re-fetched
     // the lines from beyond L2: 1.87x the layers' own bytes, profiles/r03_*), and the xyz head's A loads become 1 KiB
@@ -255,6 +335,7 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
                     mpsr::conv2d_takes_winograd4(B, mh, mw, L[5].cin, L[5].cout, sk, skn);
     if (c8) {
         auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
+            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
             return mpsr::conv3x3_winograd4(x, B, H, W, Lr.cin, blob + Lr.w_off, Lr.b_off >= 0 ? blob + Lr.b_off : nullptr,
                                            Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8, partb, partn);
         };
@@ -275,11 +356,15 @@ extern "C" int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full
         return MPSR_OK;
     }
     if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
-    if ((rc = run_layer(blob, L[2], r1, B, hh, hw, nullptr, a, 0, sk, skn, s))) return rc;
-    if ((rc = run_layer(blob, L[3], a, B, hh, hw, nullptr, b, 0, sk, skn, s))) return rc;
+    auto cached = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y) {
+        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+        return run_layer(blob, Lr, x, B, H, W, nullptr, y, 0, sk, skn, s);
+    };
+    if ((rc = cached(L[2], r1, hh, hw, a))) return rc;
+    if ((rc = cached(L[3], a, hh, hw, b))) return rc;
     if ((rc = mpsr_resize_bilinear(b, B, hh, hw, c2, mh, mw, 1, r2, stream))) return rc;
-    if ((rc = run_layer(blob, L[4], r2, B, mh, mw, nullptr, c, 0, sk, skn, s))) return rc;
-    if ((rc = run_layer(blob, L[5], c, B, mh, mw, nullptr, fm, 0, sk, skn, s))) return rc;
+    if ((rc = cached(L[4], r2, mh, mw, c))) return rc;
+    if ((rc = cached(L[5], c, mh, mw, fm))) return rc;
     if (xyz_map && (rc = run_layer(blob, L[6], fm, B, mh, mw, nullptr, xyz_map, 1, nullptr, 0, s))) return rc;
     return MPSR_OK;
 }

@@ -45,7 +45,24 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// PWS_WIDE (A/B builds only, default 0): the MFMA operands swapped (the matrix pipe computes the TRANSPOSED 32 x 32 block,
+// W X^T), so that a lane's four consecutive accumulator registers are four consecutive output CHANNELS of one pixel
+// row: a tile leaves as 12 buffer_store_dwordx4 per lane instead of 48 buffer_store_dword and starts from the residual
+// copy with 12 ds_read_b128 instead of 48 ds_read_b32.  Same products, same K order: bit-identical results (tested).
+// Measured SLOWER (r04, whole step, interleaved on one board: 15.20 -> 15.47 ms; 15.42 with the stores spread thinner,
+// profiles/r04_pointwise_wide_stores.txt): a dword store writes 2 rows x 128 contiguous bytes = two full lines per
+// instruction, the 16-byte form 32 rows x 32 bytes = 32 partial lines -- four times the write requests for the same
+// bytes.  The guide's "widen the epilogue stores" applies to row-per-lane layouts, not to stores that are already
+// full lines.
+#ifndef PWS_WIDE
+#define PWS_WIDE 0
+#endif
+#ifndef PWS_WSTEP
+#define PWS_WSTEP 16  // wide form: MFMA slots between two stores of the previous tile (16: three per stage, four stages)
+#endif
+
 namespace pws {
+constexpr bool WIDE = PWS_WIDE != 0;
 constexpr int WT = 3, ROWS = 96, COLS = 128, KS = 32;
 constexpr int TILE_B = 32 * KS * 4;          // 4096
 constexpr int STAGE_B = WT * TILE_B;         // 12288
@@ -154,26 +171,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- residual staging: piece P = tid + 256 jj of the 96 x 128 tile (row-major, 32 pieces per row): row
     // (tid >> 5) + 8 jj, columns 4 (tid & 31) .. + 3
     const unsigned rvoff = ((unsigned)(tid >> 5) * (unsigned)p.N + (unsigned)(n0 + 4 * (tid & 31))) * 4u;
-    const unsigned rwoff = (unsigned)(RES_OFF + (tid >> 5) * 512 + (tid & 31) * 16);
+    // (wide form: the 16-byte pieces of a row are XOR-swizzled by row & 15 -- lanes of one ds_read_b128 group then hit
+    // 16 different bank quads although their rows are 512 bytes apart; row & 15 = (tid >> 5) + 8 (jj & 1))
+    const unsigned rwoff = WIDE ? (unsigned)(RES_OFF + (tid >> 5) * 512 + (((tid & 31) ^ (tid >> 5)) << 4))
+                                : (unsigned)(RES_OFF + (tid >> 5) * 512 + (tid & 31) * 16);
     float4 rst[6];
     auto load_r = [&](RowRef rr, int jj) __attribute__((always_inline)) {
         rst[jj % 6] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_at(rr, 8 * jj, p.N), rvoff, 0, 0));
     };
     auto store_r = [&](int jj) __attribute__((always_inline)) {
-        *reinterpret_cast<float4 *>(lds + rwoff + jj * 4096) = rst[jj % 6];
+        *reinterpret_cast<float4 *>(lds + ((WIDE && (jj & 1)) ? (rwoff ^ 128u) : rwoff) + jj * 4096) = rst[jj % 6];
     };
     // element (q, e) of a lane: row 32 q + (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile, column 32 wave + (lane & 31)
-    const unsigned rroff = (unsigned)(RES_OFF + (4 * (lane >> 5)) * 512 + (32 * wave + (lane & 31)) * 4);
-    const unsigned evoff = ((unsigned)(4 * (lane >> 5)) * (unsigned)p.N + (unsigned)ncol) * 4u;
+    // wide form: element (q, e) of a lane: row 32 q + (lane & 31), column 32 wave + 8 (e >> 2) + 4 (lane >> 5) + (e & 3);
+    // a register quad g = e >> 2 is piece 8 wave + 2 g + (lane >> 5) of the row (swizzled: ^ (row & 15) = ^ (lane & 15))
+    const unsigned rroff = WIDE ? (unsigned)(RES_OFF + (lane & 31) * 512 + (((8 * wave + (lane >> 5)) ^ (lane & 15)) << 4))
+                                : (unsigned)(RES_OFF + (4 * (lane >> 5)) * 512 + (32 * wave + (lane & 31)) * 4);
+    const unsigned evoff = WIDE ? ((unsigned)(lane & 31) * (unsigned)p.N + (unsigned)(n0 + 32 * wave + 4 * (lane >> 5))) * 4u
+                                : ((unsigned)(4 * (lane >> 5)) * (unsigned)p.N + (unsigned)ncol) * 4u;
 
     const float bias = (p.bias && wave_live) ? p.bias[ncol] : 0.f;
     const float one = lane < 32 ? 1.f : 0.f;
+    const float bias_k0 = lane < 32 ? bias : 0.f;  // wide form: the bias is the A operand (row index = channel), k = 0 only
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     f32x16 acc[2][WT];  // a tile accumulates in one set while the previous tile is stored from the other
 #pragma unroll
     for (int q = 0; q < WT; ++q)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[1][q][e] = 0.f;
+
+    // wide form: register quad idx = 4 q + g of accumulator set SET -> ReLU -> 16 bytes of row 32 q + (lane & 31)
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    auto store_quad = [&](auto set_c, int idx, RowRef yr) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        const int q = idx / 4, g = idx % 4;
+        u32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __builtin_bit_cast(unsigned, fmaxf(acc[SET][q][4 * g + c], relu_lo));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_at(yr, 32 * q, p.N), evoff, 32 * g, 0);
+    };
 
     // One stage = 4 units (kb) of 12 MFMAs on the three accumulators, k outermost.  Slot D = 12 kb + m carries: the next
     // unit's fragment reads (m = 0); the A staging of tile j (registers -> LDS at D = 4 + 12 j, the request two stages on
@@ -211,10 +247,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int m = 3 * k + j, D = 12 * kb + m;
                     const float av = k == 0 ? fa[set][j].x : k == 1 ? fa[set][j].y : k == 2 ? fa[set][j].z : fa[set][j].w;
                     const float bv = k == 0 ? fb[kb].x : k == 1 ? fb[kb].y : k == 2 ? fb[kb].z : fb[kb].w;
-                    acc[SET][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[SET][j], 0, 0, 0);
+                    acc[SET][j] = WIDE ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[SET][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[SET][j], 0, 0, 0);
                     if (m == 0 && kb < 3) read_a(buf, kb + 1, set ^ 1);
 #ifndef PWS_SKIP_STORE  // (timing experiments only: tools/README.md)
-                    if constexpr (SE0 >= 0) if (D % SSTEP == 1 && SE0 + D / SSTEP < 16 * WT) {
+                    if constexpr (SE0 >= 0 && WIDE) {
+                        if (D % SSTEP == 1 && SE0 + D / SSTEP < 4 * WT) store_quad(IC<SET ^ 1>{}, SE0 + D / SSTEP, yp);
+                    } else if constexpr (SE0 >= 0) if (D % SSTEP == 1 && SE0 + D / SSTEP < 16 * WT) {
                         const int q = (SE0 + D / SSTEP) / 16, e = (SE0 + D / SSTEP) % 16;
                         __builtin_amdgcn_raw_buffer_store_b32(
                             __builtin_bit_cast(unsigned, fmaxf(acc[SET ^ 1][q][e], relu_lo)),
@@ -281,19 +320,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const RowRef rn = row_ref(p.residual, p.N, r0n, nlive);
         const RowRef yp = row_ref(p.y, p.N, r0_of(i - 1), i > 0 && wave_live);
         // the accumulators start from the residual (its LDS copy) ...
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int q = 0; q < WT; ++q)
+            for (int q = 0; q < WT; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc[SET][q][e] = RES ? *reinterpret_cast<const float *>(lds + rroff + (32 * q + (e & 3) + 8 * (e >> 2)) * 512) : 0.f;
-        // ... + bias as one more k: A = (1, 0) over the lane halves, B = bias of the lane's column
+                for (int g = 0; g < 4; ++g) {
+                    const float4 r4 = RES ? *reinterpret_cast<const float4 *>(lds + (rroff ^ (unsigned)(32 * g)) + q * 16384)
+                                          : float4{0.f, 0.f, 0.f, 0.f};
+                    acc[SET][q][4 * g] = r4.x;
+                    acc[SET][q][4 * g + 1] = r4.y;
+                    acc[SET][q][4 * g + 2] = r4.z;
+                    acc[SET][q][4 * g + 3] = r4.w;
+                }
+            // ... + bias as one more k: A = bias of the lane's channel row (k = 0 only), B = 1
 #pragma unroll
-        for (int q = 0; q < WT; ++q) acc[SET][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(one, bias, acc[SET][q], 0, 0, 0);
+            for (int q = 0; q < WT; ++q) acc[SET][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_k0, 1.f, acc[SET][q], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < WT; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    acc[SET][q][e] = RES ? *reinterpret_cast<const float *>(lds + rroff + (32 * q + (e & 3) + 8 * (e >> 2)) * 512) : 0.f;
+            // ... + bias as one more k: A = (1, 0) over the lane halves, B = bias of the lane's column
+#pragma unroll
+            for (int q = 0; q < WT; ++q) acc[SET][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(one, bias, acc[SET][q], 0, 0, 0);
+        }
         // stage (s, buffer s & 1, residual duty, first stored element, slots per store)
 #define PWS_STAGE(S_, DUTY_, SE0_, SSTEP_)                                                                            \
     stage_body(IC<SET>{}, IC<(S_) & 1>{}, IC<DUTY_>{}, IC<SE0_>{}, IC<SSTEP_>{}, S_, xc, true, xn, nlive, rn, yp);    \
     __syncthreads()
-        if constexpr (LONG) {
+        if constexpr (WIDE) {
+            // 12 quad stores: PWS_WSTEP slots apart (48 / PWS_WSTEP per stage) over the first stages; the residual duties
+            // as before in stages 1-3.  (after stage 0's barrier every wave has read its part of the residual copy:
+            // the next tile's may be written)
+            constexpr int WS = (!LONG && PWS_WSTEP > 16) ? 16 : PWS_WSTEP;  // (short K: four stages carry the 12 stores)
+            constexpr int PS = 48 / WS;                                      // stores per stage
+            static_assert((LONG ? 8 : 4) * PS >= 4 * WT, "not enough store slots for a tile");
+            PWS_STAGE(0, 0, 0, WS);
+            PWS_STAGE(1, 1, PS, WS);
+            PWS_STAGE(2, 2, 2 * PS, WS);
+            PWS_STAGE(3, 3, 3 * PS, WS);
+            if constexpr (LONG) {
+                PWS_STAGE(4, 0, 4 * PS, WS);
+                PWS_STAGE(5, 0, 5 * PS, WS);
+                PWS_STAGE(6, 0, 6 * PS, WS);
+                PWS_STAGE(7, 0, 7 * PS, WS);
+            }
+            for (int s = LONG ? 8 : 4; s < nst; s += 2) {
+                stage_body(IC<SET>{}, IC<0>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+                stage_body(IC<SET>{}, IC<1>{}, IC<0>{}, IC<-1>{}, IC<1>{}, s + 1, xc, true, xn, nlive, rn, yp);
+                __syncthreads();
+            }
+        } else if constexpr (LONG) {
             PWS_STAGE(0, 0, 0, 8);  // (after this barrier every wave has read its part of the residual copy: the
             PWS_STAGE(1, 1, 6, 8);  //  next tile's may be written)
             PWS_STAGE(2, 2, 12, 8);
@@ -339,12 +418,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const RowRef yl = row_ref(p.y, p.N, r0s, wave_live);
     auto finish = [&](auto set_c) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value;
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int q = 0; q < WT; ++q)
+            for (int idx = 0; idx < 4 * WT; ++idx) store_quad(IC<SET>{}, idx, yl);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[SET][q][e], relu_lo)),
-                                                      rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+            for (int q = 0; q < WT; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[SET][q][e], relu_lo)),
+                                                          rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+        }
     };
     if (last & 1) finish(IC<1>{});  // block-uniform
     else finish(IC<0>{});

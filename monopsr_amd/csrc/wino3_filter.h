@@ -53,4 +53,15 @@ struct FilterTailJob {
 };
 extern thread_local FilterTailJob g_filter_tail_job;    // pending: consumed by conv1x1_pointwise
 extern thread_local FilterTailJob g_filter_tail_done;   // done by the last pointwise launch: consumed by conv3x3_winograd3
+
+// Where the transformed filters of the layer about to run live when the caller keeps them across calls
+// (mpsr_net_opts.filter_cache): set by the network entry points (network.hip) right before the layer, consumed by
+// conv3x3_winograd3 / conv3x3_winograd4, which then use `u` instead of their scratch and skip the transform if `ready`.
+struct FilterCacheSlot {
+    const float *w = nullptr;
+    float *u = nullptr;
+    size_t floats = 0;
+    bool ready = false;
+};
+extern thread_local FilterCacheSlot g_filter_cache_slot;
 }  // namespace mpsr

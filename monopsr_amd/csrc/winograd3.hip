@@ -343,6 +343,7 @@ namespace mpsr {
 
 thread_local FilterTailJob g_filter_tail_job;
 thread_local FilterTailJob g_filter_tail_done;
+thread_local FilterCacheSlot g_filter_cache_slot;
 
 size_t winograd3_scratch_floats(int C, int N) { return (size_t)f3::NP * N * C; }
 
@@ -365,17 +366,25 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
                  "conv3x3_winograd3: tensor exceeds the 2 GiB this kernel's offsets address; split the batch");
     MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino3_conv_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
-    // (the filters may already have been transformed into `ws` by the tail job of the preceding pointwise launch)
-    const bool ready = g_filter_tail_done.w == w && g_filter_tail_done.u == ws && g_filter_tail_done.N == N &&
-                       g_filter_tail_done.C == C;
+    // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer
+    float *u = ws;
+    bool ready = false;
+    if (g_filter_cache_slot.w == w && g_filter_cache_slot.u && g_filter_cache_slot.floats >= winograd3_scratch_floats(C, N)) {
+        u = g_filter_cache_slot.u;
+        ready = g_filter_cache_slot.ready;
+    }
+    g_filter_cache_slot = FilterCacheSlot();
+    // (or the filters were transformed into `u` by the tail job of the preceding pointwise launch)
+    ready = ready || (g_filter_tail_done.w == w && g_filter_tail_done.u == u && g_filter_tail_done.N == N &&
+                      g_filter_tail_done.C == C);
     g_filter_tail_done = FilterTailJob();
     if (!ready) {
         const long long total = (long long)N * C;
-        hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
+        hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
         MPSR_CHECK_LAUNCH("wino3_filter_kernel");
     }
     Wino3Params p;
-    p.x = x; p.u = ws; p.bias = bias; p.y = y;
+    p.x = x; p.u = u; p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
     p.T = B * dilation * dilation;
     p.cblocks = C / KC;

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wino3_filter.h"
 
 namespace {
 
@@ -956,13 +957,21 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
             split = false;
         }
     }
-    {
+    // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer
+    float *u = ws;
+    bool ready = false;
+    if (g_filter_cache_slot.w == w && g_filter_cache_slot.u && g_filter_cache_slot.floats >= winograd4_scratch_floats(C, N)) {
+        u = g_filter_cache_slot.u;
+        ready = g_filter_cache_slot.ready;
+    }
+    g_filter_cache_slot = FilterCacheSlot();
+    if (!ready) {
         const long long total = (long long)N * C;
-        hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
+        hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
         MPSR_CHECK_LAUNCH("wino4_filter_kernel");
     }
     Wino4Params p;
-    p.x = x; p.u = ws; p.bias = bias; p.y = y;
+    p.x = x; p.u = u; p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N;
     p.th = H / 4; p.tw = W / 4;
     p.T = B * p.th * p.tw;
