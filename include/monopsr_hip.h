@@ -180,6 +180,17 @@ enum { MPSR_MATH_FP32 = 0, MPSR_MATH_BF16X3 = 1 };
 int mpsr_set_conv_math(int mode);
 int mpsr_get_conv_math(void);
 
+/* tf.image.resize_bilinear (align_corners as given) followed by a 3x3 SAME slim.conv2d, as the map decoder applies
+ * them (monopsr/builders/net_builder.py:72-77, :81-85), WITHOUT forming the upsampled map: a 1x1 GEMM of the source
+ * map with 9 N outputs (channel mixing commutes with the per-channel upsampling) + a 9-tap x 4-corner gather
+ * (csrc/upconv.hip).  x (B,h,w,C) -> y (B,OH,OW,N) NHWC; weights (N, 9 C) as for mpsr_conv2d_nhwc_f32.  Needs
+ * N % 128 == 0, C % 64 == 0, C >= 128 (MPSR_ERR_UNSUPPORTED otherwise: use mpsr_resize_bilinear + mpsr_conv2d_nhwc_f32)
+ * and mpsr_conv3x3_upsampled_scratch_floats() floats of scratch.  fp32 arithmetic whatever mpsr_set_conv_math says. */
+size_t mpsr_conv3x3_upsampled_scratch_floats(int B, int h, int w, int C, int N);
+int mpsr_conv3x3_upsampled_f32(const float *x, int B, int h, int w, int C, int OH, int OW, int align_corners,
+                               const float *weights, const float *bias, int relu, float *y, int N, float *ws,
+                               size_t ws_floats, mpsr_stream_t stream);
+
 /* Explicit im2col for the ResNet root: explicit zero pad 3 + 7x7 stride-2 VALID (resnet_utils.py:115-122 via
  * resnet_v1.py:234).  x (B,H,W,3) -> cols (B*OH*OW, kpad) with OH=(H+6-7)/2+1; column (ky*7+kx)*3+c, columns
  * 147..kpad-1 zero.  kpad % 32 == 0, kpad >= 147. */

@@ -107,6 +107,8 @@ SIGNATURES = {
                                 ctypes.c_float, c_f, c_f, c_f]),
     "mpsr_trunk_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
+    "mpsr_conv3x3_upsampled_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "mpsr_conv3x3_upsampled_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_sz, c_f]),
     "mpsr_filter_cache_floats": (c_sz, [ctypes.POINTER(Layer), c_i]),
     "mpsr_trunk_fwd_ex": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz,
                                 ctypes.POINTER(NetOpts), c_f]),

@@ -310,6 +310,22 @@ def resize_bilinear(x, size, align_corners=False):
     return out
 
 
+def conv3x3_upsampled(x, size, w_ok, bias=None, relu=False, align_corners=True):
+    """tf.image.resize_bilinear(x, size, align_corners) -> 3x3 SAME conv (weights (N, 9 C) as for conv2d), without
+    forming the upsampled map (csrc/upconv.hip; net_builder.py:72-77).  x (B,h,w,C) -> (B,size[0],size[1],N)."""
+    x = x.contiguous()
+    B, h, w, C = x.shape
+    N = w_ok.shape[0]
+    lib = _lib.lib()
+    nws = lib.mpsr_conv3x3_upsampled_scratch_floats(B, h, w, C, N)
+    ws = torch.empty((nws,), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, size[0], size[1], N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpsr_conv3x3_upsampled_f32(_lib.ptr(x), B, h, w, C, size[0], size[1], int(align_corners),
+                                              _lib.ptr(w_ok.contiguous()), _lib.ptr(bias), int(relu), _lib.ptr(out), N,
+                                              _lib.ptr(ws), ws.numel(), _lib.stream()))
+    return out
+
+
 def max_pool(x, k, s, padding="VALID"):
     x = x.contiguous()
     B, H, Wd, C = x.shape

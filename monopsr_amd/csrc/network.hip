@@ -26,6 +26,13 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
                    int N, hipStream_t s, int in_c8);
 int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
                        hipStream_t s);
+// upconv.hip: 3x3 convolution of a bilinearly upsampled map as a low-resolution tap GEMM + gather
+bool upconv_applies(int B, int h, int w, int C, int OH, int OW, int N);
+size_t upconv_z_floats(long long Msrc, int N);
+size_t upconv_weight_floats(int C, int N);
+int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW, int align_corners, const float *g,
+                      const float *bias, int relu, float *y, int N, int out_c8, float *z, size_t z_floats, float *ws,
+                      size_t ws_floats, hipStream_t s);
 }
 
 #include <atomic>
@@ -33,6 +40,10 @@ int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int 
 // F(4x4,3x3) kernel; 0: NHWC throughout (tests compare the two bit for bit)
 static std::atomic<int> g_decoder_c8{1};
 extern "C" void mpsr_debug_set_decoder_c8(int on) { g_decoder_c8 = on; }
+// 1 (default): the decoder's two convolutions that follow an upsampling (conv2_1, conv3_1) run as a tap GEMM on the
+// source map + gather (upconv.hip) inside the channel-blocked chain; 0: resize + F(4x4,3x3) as in round 3
+static std::atomic<int> g_decoder_upconv{1};
+extern "C" void mpsr_debug_set_decoder_upconv(int on) { g_decoder_upconv = on; }
 
 namespace {
 
@@ -251,7 +262,9 @@ extern "C" size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, in
     // (+ with the opt-in position-split Winograd kernel enabled, the partial outputs it parks: the larger map size)
     const size_t parth = mpsr::winograd4_split_floats(B, mh / 2, mw / 2, 256), partm = mpsr::winograd4_split_floats(B, mh, mw, 128);
     const size_t part = mpsr::g_wino4_split.load() != 0 ? fbytes((parth > partm ? parth : partm) + 64) : 0;
-    return 2 * fbytes(Mf * 512) + fbytes(Mh * 512) + 2 * fbytes(Mh * 256) + fbytes(Mm * 256) + 2 * fbytes(Mm * 128) +
+    // (the two upsampled maps' slots also hold the tap GEMMs' outputs, 9 x 256 / 9 x 128 columns at the source size)
+    const size_t r1 = Mh * 512 > Mf * 9 * 256 ? Mh * 512 : Mf * 9 * 256, r2 = Mm * 256 > Mh * 9 * 128 ? Mm * 256 : Mh * 9 * 128;
+    return 2 * fbytes(Mf * 512) + fbytes(r1) + 2 * fbytes(Mh * 256) + fbytes(r2) + 2 * fbytes(Mm * 128) +
            fbytes(mpsr::conv_scratch_floats((long long)Mm, 512)) + part;
 }
 
@@ -285,8 +298,12 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
                  "squash_decoder_fwd: layer records are not squash_a, squash_b, conv2_1, conv2_2, conv3_1, conv3_2, xyz");
     Arena ar(workspace, workspace_bytes);
     float *part = ar.floats(Mf * csq), *sq = ar.floats(Mf * csq);
-    float *r1 = ar.floats(Mh * csq), *a = ar.floats(Mh * c2), *b = ar.floats(Mh * c2);
-    float *r2 = ar.floats(Mm * c2), *c = ar.floats(Mm * c3);
+    // r1 / r2: the upsampled maps, or -- same slots -- the tap GEMMs' outputs z when the upsampled convolutions run on
+    // upconv.hip (9 x cout columns at the SOURCE resolution)
+    const size_t r1n = Mh * csq > Mf * 9 * (size_t)c2 ? Mh * csq : Mf * 9 * (size_t)c2;
+    const size_t r2n = Mm * c2 > Mh * 9 * (size_t)c3 ? Mm * c2 : Mh * 9 * (size_t)c3;
+    float *r1 = ar.floats(r1n), *a = ar.floats(Mh * c2), *b = ar.floats(Mh * c2);
+    float *r2 = ar.floats(r2n), *c = ar.floats(Mm * c3);
     float *fm = feat_map ? feat_map : ar.floats(Mm * c3);
     int cwide = csq;
     for (int i = 2; i < n_layers; ++i) cwide = L[i].cout > cwide ? L[i].cout : cwide;
@@ -326,12 +343,17 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
     // Same kernels, same arithmetic order: bit-identical to the NHWC chain (tests/test_net_gpu.py).
     const bool xyz_c8 = !feat_map && xyz_map && L[6].cout <= 3 && L[6].cin % 8 == 0 && L[6].cin >= 32 && L[6].cin <= 128 &&
                         (size_t)10 * mw * 27 * sizeof(float) <= 64 * 1024 && L[6].kh == 3 && L[6].dilation == 1;
-    const bool c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 &&
-                    L[2].kh == 3 && L[3].kh == 3 && L[4].kh == 3 && L[5].kh == 3 && L[2].dilation == 1 &&
-                    L[3].dilation == 1 && L[4].dilation == 1 && L[5].dilation == 1 &&
-                    mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn) &&
+    const bool k3 = L[2].kh == 3 && L[3].kh == 3 && L[4].kh == 3 && L[5].kh == 3 && L[2].kw == 3 && L[3].kw == 3 &&
+                    L[4].kw == 3 && L[5].kw == 3 && L[2].dilation == 1 && L[3].dilation == 1 && L[4].dilation == 1 &&
+                    L[5].dilation == 1;
+    // conv2_1 / conv3_1 read an upsampled map: tap GEMM on the source map + gather (fp32 arithmetic only)
+    const bool upok = g_decoder_upconv.load() != 0 && k3 && mpsr_get_conv_math() == MPSR_MATH_FP32;
+    const bool up1 = upok && mpsr::upconv_applies(B, fh, fw, csq, hh, hw, c2) && skn >= mpsr::upconv_weight_floats(csq, c2);
+    const bool up2 = upok && mpsr::upconv_applies(B, hh, hw, c2, mh, mw, c3) && skn >= mpsr::upconv_weight_floats(c2, c3);
+    const bool c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 && k3 &&
+                    (up1 || mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn)) &&
                     mpsr::conv2d_takes_winograd4(B, hh, hw, L[3].cin, L[3].cout, sk, skn) &&
-                    mpsr::conv2d_takes_winograd4(B, mh, mw, L[4].cin, L[4].cout, sk, skn) &&
+                    (up2 || mpsr::conv2d_takes_winograd4(B, mh, mw, L[4].cin, L[4].cout, sk, skn)) &&
                     mpsr::conv2d_takes_winograd4(B, mh, mw, L[5].cin, L[5].cout, sk, skn);
     if (c8) {
         auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
@@ -339,11 +361,26 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
             return mpsr::conv3x3_winograd4(x, B, H, W, Lr.cin, blob + Lr.w_off, Lr.b_off >= 0 ? blob + Lr.b_off : nullptr,
                                            Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8, partb, partn);
         };
-        if ((rc = mpsr::resize_bilinear_c8(sq, B, fh, fw, csq, hh, hw, 1, r1, s))) return rc;
-        if ((rc = wino(L[2], r1, hh, hw, a, 1, 1))) return rc;
+        // upsampling + 3x3 convolution in one: x (NHWC, source size) -> y (channel-blocked, output size); z = r1 / r2
+        auto upconv = [&](const mpsr_layer &Lr, const float *x, int h, int w, int H, int W, float *y, float *z, size_t zn) {
+            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+            return mpsr::conv3x3_upsampled(x, B, h, w, Lr.cin, H, W, 1, blob + Lr.w_off,
+                                           Lr.b_off >= 0 ? blob + Lr.b_off : nullptr, Lr.relu, y, Lr.cout, 1, z, zn, sk,
+                                           skn, s);
+        };
+        if (up1) {
+            if ((rc = upconv(L[2], sq, fh, fw, hh, hw, a, r1, r1n))) return rc;
+        } else {
+            if ((rc = mpsr::resize_bilinear_c8(sq, B, fh, fw, csq, hh, hw, 1, r1, s))) return rc;
+            if ((rc = wino(L[2], r1, hh, hw, a, 1, 1))) return rc;
+        }
         if ((rc = wino(L[3], a, hh, hw, b, 1, 0))) return rc;
-        if ((rc = mpsr::resize_bilinear_c8(b, B, hh, hw, c2, mh, mw, 1, r2, s))) return rc;
-        if ((rc = wino(L[4], r2, mh, mw, c, 1, 1))) return rc;
+        if (up2) {
+            if ((rc = upconv(L[4], b, hh, hw, mh, mw, c, r2, r2n))) return rc;
+        } else {
+            if ((rc = mpsr::resize_bilinear_c8(b, B, hh, hw, c2, mh, mw, 1, r2, s))) return rc;
+            if ((rc = wino(L[4], r2, mh, mw, c, 1, 1))) return rc;
+        }
         if ((rc = wino(L[5], c, mh, mw, fm, 1, xyz_c8 ? 1 : 0))) return rc;
         if (xyz_map) {
             if (xyz_c8)

@@ -158,15 +158,51 @@ def test_decoder_channel_blocked_layout_is_bit_identical(want_feat_map):
     crop = torch.randn((B, 12, 12, 512), device="cuda", generator=g).clamp_(min=0)
     full = torch.randn((B, 12, 12, 512), device="cuda", generator=g).clamp_(min=0)
     outs = {}
-    for on in (1, 0):
-        lib.mpsr_debug_set_decoder_c8(on)
-        try:
-            outs[on] = [t.clone() if t is not None else None
-                        for t in net.squash_decoder(crop, full, (48, 48), want_feat_map=want_feat_map)]
-        finally:
-            lib.mpsr_debug_set_decoder_c8(1)
+    lib.mpsr_debug_set_decoder_upconv(0)  # (like with like: the upsampled layers on resize + F(4x4,3x3) in both runs)
+    try:
+        for on in (1, 0):
+            lib.mpsr_debug_set_decoder_c8(on)
+            try:
+                outs[on] = [t.clone() if t is not None else None
+                            for t in net.squash_decoder(crop, full, (48, 48), want_feat_map=want_feat_map)]
+            finally:
+                lib.mpsr_debug_set_decoder_c8(1)
+    finally:
+        lib.mpsr_debug_set_decoder_upconv(1)
     for a, b in zip(outs[1], outs[0]):
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.equal(a, b)
+    assert float(outs[1][2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("width_div,B", [(1, 64), (2, 128)])
+def test_decoder_upsampled_convs_as_tap_gemm_vs_resize_winograd(width_div, B):
+    """conv2_1 / conv3_1 read a bilinearly upsampled map (net_builder.py:72-77, :81-85).  Default: tap GEMM on the source
+    map + gather (csrc/upconv.hip), no upsampled tensor; mpsr_debug_set_decoder_upconv(0): resize + F(4x4,3x3) as in
+    round 3.  Same operator, different arithmetic order: every output within 1e-4 of the tensor scale (measured ~2e-5,
+    the F(4x4) side's error), deterministic, and the filter cache (second call) changes nothing.  width_div 2: only
+    conv2_1 qualifies (conv3_1 has 64 outputs), the chain mixes both forms."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    lib = _lib.lib()
+    net = dn.DeviceNet(W.synthetic_weights(seed=5, width_div=width_div), width_div=width_div)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    c = 1024 // width_div
+    crop = torch.randn((B, 12, 12, c), device="cuda", generator=g).clamp_(min=0)
+    full = torch.randn((B, 12, 12, c), device="cuda", generator=g).clamp_(min=0)
+    outs = {}
+    for on in (1, 0):
+        lib.mpsr_debug_set_decoder_upconv(on)
+        try:
+            net.fcache = {}
+            first = [t.clone() for t in net.squash_decoder(crop, full, (48, 48), want_feat_map=True)]
+            outs[on] = [t.clone() for t in net.squash_decoder(crop, full, (48, 48), want_feat_map=True)]  # cache valid
+            for a, b in zip(first, outs[on]):
+                assert torch.equal(a, b)
+        finally:
+            lib.mpsr_debug_set_decoder_upconv(1)
+    for name, a, b in zip(("features_for_box_3d", "features_for_map", "inst_xyz_map_local"), outs[1], outs[0]):
+        assert _rel(a, b) < 1e-4, (name, _rel(a, b))
     assert float(outs[1][2].abs().max()) > 0

@@ -232,6 +232,55 @@ def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu, waves):
     assert not torch.equal(got, direct) or C * N < 1024  # it really is a different evaluation
 
 
+UPCONV_CASES = [
+    # B, h, w, C, OH, OW, N, align_corners, bias, relu
+    (2, 12, 12, 128, 24, 24, 128, True, True, True),    # the decoder's 2x align-corners upsampling, narrow
+    (3, 6, 6, 192, 12, 12, 256, True, True, False),     # two GEMM parts, C not a power of two
+    (2, 5, 7, 128, 11, 16, 128, True, False, True),     # uneven scales, odd sizes, bands with a ragged tail
+    (2, 5, 7, 128, 11, 16, 128, False, True, True),     # legacy scale in / out
+    (1, 12, 12, 512, 24, 24, 256, True, True, True),    # conv2_1's real layer shape
+    (1, 24, 24, 256, 48, 48, 128, True, True, True),    # conv3_1's real layer shape
+    (2, 9, 4, 128, 9, 4, 128, True, True, True),        # no resizing at all: a plain 3x3 convolution
+]
+
+
+@pytest.mark.parametrize("B,h,w,C,OH,OW,N,align,has_bias,relu", UPCONV_CASES)
+def test_conv3x3_upsampled_vs_fp64(B, h, w, C, OH, OW, N, align, has_bias, relu):
+    """tf.image.resize_bilinear -> 3x3 SAME conv as ONE operator (csrc/upconv.hip: tap GEMM on the source map + gather;
+    reference net_builder.py:72-77, :81-85) against the two TF-1.8 operators of oracle/net.py in float64: <= 1e-5 of
+    the tensor scale (plain fp32 GEMM error; F(4x4,3x3) on the upsampled map is held to 1e-4), deterministic."""
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    rng = np.random.default_rng(B * 1000 + C + N + OH)
+    x = rng.standard_normal((B, h, w, C)).astype(np.float32)
+    wgt = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    up = onet.tf_resize_bilinear(torch.from_numpy(x).double(), OH, OW, align)
+    ref = onet.tf_conv2d(up, torch.from_numpy(wgt).double())
+    if has_bias:
+        ref = ref + torch.from_numpy(bias).double()
+    if relu:
+        ref = torch.relu(ref)
+    w_ok, _ = W.fold_conv(wgt)
+    args = (_dev(x), (OH, OW), _dev(w_ok), _dev(bias) if has_bias else None, relu, align)
+    got = dn.conv3x3_upsampled(*args)
+    again = dn.conv3x3_upsampled(*args)
+    _close(got, ref, 1e-5, "upsampled 3x3 conv %s" % ((B, h, w, C, OH, OW, N),))
+    assert torch.equal(got, again), "not deterministic"
+    # and against the library's own two-operator chain in fp32
+    two = dn.conv2d(dn.resize_bilinear(_dev(x), (OH, OW), align), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3,
+                    1, relu)
+    _close(got, two, 1e-5, "upsampled 3x3 conv vs resize + conv2d")
+
+
+def test_conv3x3_upsampled_refuses_what_it_does_not_take():
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    x = torch.zeros((1, 6, 6, 128), device="cuda")
+    with pytest.raises(_lib.MpsrError):
+        dn.conv3x3_upsampled(x, (12, 12), torch.zeros((64, 9 * 128), device="cuda"))  # N not a multiple of 128
+
+
 @pytest.mark.parametrize("B,H,Wd,C,N,has_bias,relu", [
     (2, 24, 24, 64, 64, True, True), (1, 48, 48, 32, 128, True, True), (3, 12, 8, 16, 40, False, False),
     (1, 4, 4, 16, 4, True, False), (5, 12, 12, 48, 200, True, True), (4, 48, 48, 256, 128, True, True),

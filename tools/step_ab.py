@@ -33,6 +33,7 @@ samples = {v: [] for v in values}
 for _ in range(args.rounds):
     for v in values:
         knob(v)
+        net.fcache = {}  # (transformed filters kept across calls belong to one setting of the knobs)
         step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
