@@ -27,7 +27,7 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
 int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
                        hipStream_t s);
 // upconv.hip: 3x3 convolution of a bilinearly upsampled map as a low-resolution tap GEMM + gather
-bool upconv_applies(int B, int h, int w, int C, int OH, int OW, int N);
+bool upconv_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners);
 size_t upconv_z_floats(long long Msrc, int N);
 size_t upconv_weight_floats(int C, int N);
 int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW, int align_corners, const float *g,
@@ -348,8 +348,8 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
                     L[5].dilation == 1;
     // conv2_1 / conv3_1 read an upsampled map: tap GEMM on the source map + gather (fp32 arithmetic only)
     const bool upok = g_decoder_upconv.load() != 0 && k3 && mpsr_get_conv_math() == MPSR_MATH_FP32;
-    const bool up1 = upok && mpsr::upconv_applies(B, fh, fw, csq, hh, hw, c2) && skn >= mpsr::upconv_weight_floats(csq, c2);
-    const bool up2 = upok && mpsr::upconv_applies(B, hh, hw, c2, mh, mw, c3) && skn >= mpsr::upconv_weight_floats(c2, c3);
+    const bool up1 = upok && mpsr::upconv_applies(B, fh, fw, csq, hh, hw, c2, 1) && skn >= mpsr::upconv_weight_floats(csq, c2);
+    const bool up2 = upok && mpsr::upconv_applies(B, hh, hw, c2, mh, mw, c3, 1) && skn >= mpsr::upconv_weight_floats(c2, c3);
     const bool c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 && k3 &&
                     (up1 || mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn)) &&
                     mpsr::conv2d_takes_winograd4(B, hh, hw, L[3].cin, L[3].cout, sk, skn) &&

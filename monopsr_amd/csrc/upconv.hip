@@ -11,10 +11,10 @@
 // the same 1/4 of the direct form's multiply-adds that F(4x4,3x3) on the upsampled map issues (a quarter of the pixels,
 // nine times the columns), but with no input / output transforms, no patch gathers, exact-fp32 GEMM error (1e-6 instead
 // of F(4x4)'s 1.5e-5), and the two resize launches (0.9 GB written and re-read per step) are gone.  Stage 2
-// (upconv_gather_kernel) is the 9-tap x 4-corner weighted sum above: one workgroup per (image, band of output rows,
-// 8-channel block) stages the z rows its band reaches in LDS once and every thread then sums 36 float4 for an output
-// pixel's 4 channels -- LDS / vector-ALU work on 1/9 of the GEMM's flops, writing the layer's output once (channel-
-// blocked for the F(4x4,3x3) layer that follows, or NHWC).
+// (upconv_gather_kernel) is the 9-tap x 4-corner weighted sum above: one workgroup per (image, 8-channel block) rolls a
+// window of z rows through LDS and every thread sums 36 float4 for an output pixel's 4 channels -- LDS / vector-ALU work
+// on 1/9 of the GEMM's flops, reading z once and writing the layer's output once (channel-blocked for the F(4x4,3x3)
+// layer that follows, or NHWC).
 //
 // Column order of z (ours to choose): j = (n / 8) * 72 + t * 8 + (n % 8) -- the nine taps of an 8-channel block are 288
 // contiguous bytes per source pixel.  The GEMM's weight matrix W'[j][c] = g[n][t][c] is a re-ordering of the filter
@@ -32,8 +32,10 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
 
 namespace {
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int PART = 1152;  // z columns per GEMM launch = 16 channel blocks x 9 taps x 8 channels
-constexpr size_t kGatherLdsBytes = 80 * 1024;
+constexpr size_t kGatherLdsBytes = 80 * 1024;  // most LDS a gather workgroup takes (two per CU)
 
 // W'[j][c] = g[n][t*C + c], j = (n / 8) * 72 + t * 8 + (n % 8).  One thread per float4 of W'.
 __global__ __launch_bounds__(256) void upconv_weights_kernel(const float *__restrict__ g, int N, int C, float *__restrict__ wp)
@@ -50,120 +52,229 @@ struct UpcParams {
     const float *z, *bias;
     float *y;
     size_t part_stride;  // floats between the z parts (source pixels x 1152)
-    int h, w, H, W, N, relu, RB;
+    int B, h, w, H, W, N, relu;
+    int RB, cap;         // output rows per band; source rows the LDS ring holds (>= the rows one band reaches)
+    mpsr::FastDiv capdiv;  // r % cap by multiply-high (common.h)
     float hscale, wscale;
 };
 
-// grid (N / 8, bands of RB output rows, images).  LDS: [source row][source column][tap][8 channels] as float4 pairs.
+constexpr int kPf = 8;  // float4 registers per thread that carry source pixels on their way into LDS
+
+// One workgroup per (8-channel block, image) walks the image in bands of RB output rows.  LDS is a ring of `cap` source
+// rows, [row % cap][column][tap][8 channels]; while a band is summed the source rows the NEXT band adds are already on
+// their way into registers, and move into the ring between two barriers -- every z row is read exactly once, and the
+// loads overlap the arithmetic inside the workgroup.  Two things measured on the way (r04): an integer division costs
+// hipcc ~35 vector instructions -- a version with index decodes per item / per load ran 1.5x longer than its arithmetic
+// -- so nothing in the loops divides: thread = (row of a pass, output column x, half of the 8 channels) with blockDim.x =
+// rpp * 2 W (a thread's column, its three tap columns, their LDS offsets and weights never change) and, as a loader,
+// (pixel group, 16-byte piece of a pixel's 288 bytes) walking pixels by addition.  And a load -> LDS-store loop waits for
+// every load in turn (12 round trips per workgroup were 3/4 of the first version's time): loads are issued kPf at a time
+// into registers, then stored.
 template <bool OUT_C8>
-__global__ __launch_bounds__(256) void upconv_gather_kernel(const UpcParams p)
+__global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 src4[];
-    const int tid = threadIdx.x;
-    const int blk = blockIdx.x, y0 = blockIdx.y * p.RB, b = blockIdx.z;
-    const int ylast = min(y0 + p.RB, p.H) - 1;
-    // source rows the band's taps (output rows y0 - 1 .. ylast + 1, clamped) interpolate between
-    const int r_lo = (int)floorf((float)max(y0 - 1, 0) * p.hscale);
-    const int r_hi = min((int)floorf((float)min(ylast + 1, p.H - 1) * p.hscale) + 1, p.h - 1);
-    const int nrows = r_hi - r_lo + 1;
-    {
-        const float *zp = p.z + (size_t)(blk >> 4) * p.part_stride + (size_t)(blk & 15) * 72;
-        const size_t pix0 = ((size_t)b * p.h + r_lo) * p.w;
-        const int total4 = nrows * p.w * 18;
-        for (int i = tid; i < total4; i += 256) {
-            const int px = i / 18, q = i - px * 18;
-            src4[i] = *reinterpret_cast<const float4 *>(zp + (pix0 + px) * PART + 4 * q);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    // Workgroup i runs on XCD i % 8 (speed only): XCD x takes the images x, x + 8, ... and the N / 8 channel blocks of an
+    // image back to back.  A block's 288-byte slice of a pixel straddles cache lines it shares with its neighbours, and
+    // an image's z slab (0.7 - 2.7 MB) is read by all its blocks: one L2 then fetches every line once (with the blocks
+    // of an image spread over the eight L2s the same bytes came in 1.44 times).
+    const int nblk = p.N >> 3;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int bq = jx / nblk, blk = jx - bq * nblk, b = bq * 8 + xcd;
+    if (b >= p.B) return;  // block-uniform
+    const int lpr = 2 * p.W, rpp = nthr / lpr;
+    const int rr = tid / lpr, l = tid - rr * lpr, x = l >> 1, half = l & 1;
+    const int n0 = blk * 8;
+    const int rowf4 = p.w * 18;  // float4 per source row
+    auto slot = [&](int r) __attribute__((always_inline)) { return r - p.cap * mpsr::fdiv(r, p.capdiv); };  // r % cap
+    const float *zp = p.z + (size_t)(blk >> 4) * p.part_stride + (size_t)(blk & 15) * 72 + (size_t)b * p.h * p.w * PART;
+    // loader role: piece `lpiece` of the pixels lgrp, lgrp + lgroups, ... of a block of whole rows (row-major, rows are
+    // contiguous in z); (lrow0, lcol0) = this thread's first pixel, (drow, dcol) = the step of lgroups pixels
+    const int lgroups = nthr / 18, lgrp = tid / 18, lpiece = tid - lgrp * 18;
+    const bool loader = lgrp < lgroups;
+    const int lrow0 = lgrp / p.w, lcol0 = lgrp - lrow0 * p.w;
+    const int drow = lgroups / p.w, dcol = lgroups - drow * p.w;
+    f32x4 pf[kPf];
+    // pixels [first, first + kPf * lgroups) of the block of rows that starts at row ra, npix pixels long
+    auto issue = [&](int ra, int npix, int first) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kPf; ++j) {
+            // (an unconditional load through a selected address -- unused slots re-read one cached line; a conditional
+            // load, or HIP's float4 struct as the element type, sends the register array to scratch memory)
+            const int pix = first + lgrp + j * lgroups;
+            const bool live = loader && pix < npix;
+            pf[j] = *reinterpret_cast<const f32x4 *>(live ? zp + ((size_t)ra * p.w + pix) * PART + 4 * lpiece : zp);
+        }
+    };
+    // (row, col) = position of this thread's pixel `first + lgrp` relative to row ra, kept by the caller
+    auto commit = [&](int ra, int npix, int first, int &row, int &col) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kPf; ++j) {
+            const int pix = first + lgrp + j * lgroups;
+            if (loader && pix < npix)
+                reinterpret_cast<f32x4 *>(src4)[slot(ra + row) * rowf4 + col * 18 + lpiece] = pf[j];
+            row += drow;
+            col += dcol;
+            if (col >= p.w) {
+                col -= p.w;
+                ++row;
+            }
+        }
+    };
+
+    // source rows band k's taps (output rows k RB - 1 .. (k + 1) RB, clamped) interpolate between
+    auto band_rows = [&](int k, int &lo, int &hi) __attribute__((always_inline)) {
+        const int y0 = k * p.RB, yl = min(y0 + p.RB, p.H) - 1;
+        lo = (int)floorf((float)max(y0 - 1, 0) * p.hscale);
+        hi = min((int)floorf((float)min(yl + 1, p.H - 1) * p.hscale) + 1, p.h - 1);
+    };
+    // tap column d - 1 of this thread's output column: LDS offsets of the two source columns and their weights (zero
+    // when the tap falls outside the upsampled image: the convolution's SAME padding)
+    int co[3][2];
+    float wx[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int qx = x + d - 1;
+        const bool vx = qx >= 0 && qx < p.W;
+        const float sx = (float)min(max(qx, 0), p.W - 1) * p.wscale;
+        const int c0 = (int)floorf(sx), c1 = min(c0 + 1, p.w - 1);
+        const float lx = sx - (float)c0;
+        co[d][0] = c0 * 18 + half;
+        co[d][1] = c1 * 18 + half;
+        wx[d][0] = vx ? 1.f - lx : 0.f;
+        wx[d][1] = vx ? lx : 0.f;
+    }
+    const float4 bias4 = p.bias ? *reinterpret_cast<const float4 *>(p.bias + n0 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int nbands = (p.H + p.RB - 1) / p.RB;
+    int lo, hi;
+    band_rows(0, lo, hi);
+    {  // the first band's rows
+        const int npix = (hi - lo + 1) * p.w;
+        int row = lrow0, col = lcol0;
+        for (int first = 0; first < npix; first += kPf * lgroups) {
+            issue(lo, npix, first);
+            commit(lo, npix, first, row, col);
         }
     }
     __syncthreads();
-    const int nitems = (ylast - y0 + 1) * p.W * 2;  // (output pixel, half of the 8 channels)
-    const int n0 = blk * 8;
-    for (int it = tid; it < nitems; it += 256) {
-        const int half = it & 1, px = it >> 1;
-        const int yy = px / p.W, x = px - yy * p.W, y = y0 + yy;
-        // tap row / column d - 1: the two source rows (columns) it interpolates between, as LDS offsets, and their
-        // weights -- zero when the tap falls outside the upsampled image (the convolution's SAME padding)
-        int ro[3][2], co[3][2];
-        float wy[3][2], wx[3][2];
+    for (int k = 0; k < nbands; ++k) {
+        // rows the next band adds: (hi, nhi] -- at most kPf * lgroups pixels (gather_geometry)
+        int nlo = 0, nhi = hi;
+        if (k + 1 < nbands) band_rows(k + 1, nlo, nhi);
+        const int nnew = (nhi - hi) * p.w;
+        issue(hi + 1, nnew, 0);
+        const int y0 = k * p.RB, ylast = min(y0 + p.RB, p.H) - 1;
+        for (int y = y0 + rr; y <= ylast; y += rpp) {
+            int ro[3][2];
+            float wy[3][2];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int qy = y + d - 1, qx = x + d - 1;
-            const bool vy = qy >= 0 && qy < p.H, vx = qx >= 0 && qx < p.W;
-            const float sy = (float)min(max(qy, 0), p.H - 1) * p.hscale, sx = (float)min(max(qx, 0), p.W - 1) * p.wscale;
-            const int r0 = (int)floorf(sy), c0 = (int)floorf(sx);
-            const int r1 = min(r0 + 1, p.h - 1), c1 = min(c0 + 1, p.w - 1);
-            const float ly = sy - (float)r0, lx = sx - (float)c0;
-            ro[d][0] = (r0 - r_lo) * p.w * 18;
-            ro[d][1] = (r1 - r_lo) * p.w * 18;
-            co[d][0] = c0 * 18 + half;
-            co[d][1] = c1 * 18 + half;
-            wy[d][0] = vy ? 1.f - ly : 0.f;
-            wy[d][1] = vy ? ly : 0.f;
-            wx[d][0] = vx ? 1.f - lx : 0.f;
-            wx[d][1] = vx ? lx : 0.f;
-        }
-        float4 acc = p.bias ? *reinterpret_cast<const float4 *>(p.bias + n0 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int t2 = 2 * (dy * 3 + dx);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float wgt = wy[dy][a] * wx[dx][c];
-                        const float4 v = src4[ro[dy][a] + co[dx][c] + t2];
-                        acc.x = fmaf(wgt, v.x, acc.x);
-                        acc.y = fmaf(wgt, v.y, acc.y);
-                        acc.z = fmaf(wgt, v.z, acc.z);
-                        acc.w = fmaf(wgt, v.w, acc.w);
-                    }
+            for (int d = 0; d < 3; ++d) {
+                const int qy = y + d - 1;
+                const bool vy = qy >= 0 && qy < p.H;
+                const float sy = (float)min(max(qy, 0), p.H - 1) * p.hscale;
+                const int r0 = (int)floorf(sy), r1 = min(r0 + 1, p.h - 1);
+                const float ly = sy - (float)r0;
+                ro[d][0] = slot(r0) * rowf4;
+                ro[d][1] = slot(r1) * rowf4;
+                wy[d][0] = vy ? 1.f - ly : 0.f;
+                wy[d][1] = vy ? ly : 0.f;
             }
-        if (p.relu) {
-            acc.x = fmaxf(acc.x, 0.f);
-            acc.y = fmaxf(acc.y, 0.f);
-            acc.z = fmaxf(acc.z, 0.f);
-            acc.w = fmaxf(acc.w, 0.f);
+            f32x2 a01 = {bias4.x, bias4.y}, a23 = {bias4.z, bias4.w};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int t2 = 2 * (dy * 3 + dx);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float wgt = wy[dy][a] * wx[dx][c];
+                            const float4 v = src4[ro[dy][a] + co[dx][c] + t2];
+                            const f32x2 w2 = {wgt, wgt};
+                            a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
+                            a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+                        }
+                }
+            float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+            if (p.relu) {
+                acc.x = fmaxf(acc.x, 0.f);
+                acc.y = fmaxf(acc.y, 0.f);
+                acc.z = fmaxf(acc.z, 0.f);
+                acc.w = fmaxf(acc.w, 0.f);
+            }
+            float *o = OUT_C8 ? p.y + ((((size_t)b * (p.N / 8) + blk) * p.H + y) * p.W + x) * 8 + 4 * half
+                              : p.y + (((size_t)b * p.H + y) * p.W + x) * p.N + n0 + 4 * half;
+            *reinterpret_cast<float4 *>(o) = acc;
         }
-        float *o = OUT_C8 ? p.y + ((((size_t)b * (p.N / 8) + blk) * p.H + y) * p.W + x) * 8 + 4 * half
-                          : p.y + (((size_t)b * p.H + y) * p.W + x) * p.N + n0 + 4 * half;
-        *reinterpret_cast<float4 *>(o) = acc;
+        if (k + 1 == nbands) break;
+        __syncthreads();  // every thread has finished reading this band's rows: the ring may be overwritten
+        {
+            int row = lrow0, col = lcol0;
+            commit(hi + 1, nnew, 0, row, col);
+        }
+        __syncthreads();
+        hi = nhi;
     }
 }
 
-// output rows per band: the largest divisor-free choice whose source rows fit the LDS budget
-int gather_band_rows(int w, int H, float hscale, int *rows_bound)
+// Launch geometry of the gather: threads = rpp x 2 W (rows of a pass x (column, channel half)), rpp a power of two with
+// at most 512 threads; RB = output rows per band (8, or rpp if larger); cap = the ring's rows, a power of two >= the rows
+// any band reaches; the rows a band ADDS must fit the prefetch registers.  false: the map is too wide for this kernel.
+bool gather_geometry(int h, int w, int H, int W, float hscale, int *threads, int *RB, int *cap)
 {
-    int best = 1, bound = 3;
-    for (int rb = 1; rb <= H; ++rb) {
-        const int rows = (int)floorf((float)(rb + 1) * hscale) + 3;
-        if ((size_t)rows * w * 288 > kGatherLdsBytes) break;
-        best = rb;
-        bound = rows;
+    if (2 * W > 512 || w < 1) return false;
+    int rpp = 1;
+    while (rpp * 2 <= 16 && rpp * 2 * 2 * W <= 512) rpp *= 2;
+    const int nthr = rpp * 2 * W;
+    if (nthr < 18) return false;
+    // a map whose source rows all fit a third of the LDS is ONE band (three workgroups per CU overlap each other's load
+    // and arithmetic phases); otherwise bands of 8 rows (or one pass) with the next band's rows prefetched
+    int rb = rpp > 8 ? rpp : 8;
+    if ((size_t)h * w * 288 <= kGatherLdsBytes * 3 / 5) rb = (H + rpp - 1) / rpp * rpp;
+    // the kernel's own band arithmetic: the most rows a band reaches, the most a further band adds
+    int rows = 0, add = 0, prev_hi = -1;
+    for (int k = 0; k * rb < H; ++k) {
+        const int y0 = k * rb, yl = (y0 + rb < H ? y0 + rb : H) - 1;
+        const int lo = (int)floorf((float)(y0 - 1 > 0 ? y0 - 1 : 0) * hscale);
+        int hi = (int)floorf((float)(yl + 1 < H - 1 ? yl + 1 : H - 1) * hscale) + 1;
+        if (hi > h - 1) hi = h - 1;
+        if (hi - lo + 1 > rows) rows = hi - lo + 1;
+        if (k > 0 && hi - prev_hi > add) add = hi - prev_hi;
+        prev_hi = hi;
     }
-    // even bands: the last one is not a sliver
-    const int bands = mpsr::ceil_div(H, best);
-    best = mpsr::ceil_div(H, bands);
-    bound = (int)floorf((float)(best + 1) * hscale) + 3;
-    *rows_bound = bound;
-    return best;
+    if (add * w > kPf * (nthr / 18)) return false;  // the rows a band adds travel through the prefetch registers
+    const int c = rows;
+    if ((size_t)c * w * 288 > kGatherLdsBytes) return false;
+    *threads = nthr;
+    *RB = rb;
+    *cap = c;
+    return true;
 }
 
 }  // namespace
 
 namespace mpsr {
 
+static bool upconv_geometry_ok(int h, int w, int OH, int OW, int align_corners)
+{
+    int t, rb, cap;
+    const float hs = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
+    return gather_geometry(h, w, OH, OW, hs, &t, &rb, &cap);
+}
+
 size_t upconv_weight_floats(int C, int N) { return (size_t)9 * N * C; }
 size_t upconv_z_floats(long long Msrc, int N) { return (size_t)Msrc * 9 * (size_t)N; }
 
 // x (B,h,w,C) NHWC, 3x3 filter (N, 9 C), output (B,OH,OW,N): N a multiple of 128 (whole GEMM parts), the source map a
 // shape the pointwise kernel takes, 32-bit byte offsets inside z parts
-bool upconv_applies(int B, int h, int w, int C, int OH, int OW, int N)
+bool upconv_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners)
 {
     const long long M = (long long)B * h * w;
     return B > 0 && h >= 1 && w >= 1 && OH >= 1 && OW >= 1 && N >= 128 && N % 128 == 0 && C % 4 == 0 &&
-           pointwise_applies(M, C, PART) && (size_t)3 * w * 288 <= kGatherLdsBytes && B <= 65535 && N / 8 <= 65535 &&
+           pointwise_applies(M, C, PART) && upconv_geometry_ok(h, w, OH, OW, align_corners) && B <= 65535 &&
            (long long)B * OH * OW * N * 4 < 0x7fffffffffLL;
 }
 
@@ -171,7 +282,7 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
                       const float *bias, int relu, float *y, int N, int out_c8, float *z, size_t z_floats, float *ws,
                       size_t ws_floats, hipStream_t s)
 {
-    MPSR_REQUIRE(upconv_applies(B, h, w, C, OH, OW, N), "conv3x3_upsampled: unsupported shape (B=%d %dx%dx%d -> %dx%dx%d)",
+    MPSR_REQUIRE(upconv_applies(B, h, w, C, OH, OW, N, align_corners), "conv3x3_upsampled: unsupported shape (B=%d %dx%dx%d -> %dx%dx%d)",
                  B, h, w, C, OH, OW, N);
     const long long M = (long long)B * h * w;
     if (!z || z_floats < upconv_z_floats(M, N))
@@ -203,21 +314,23 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
     UpcParams p;
     p.z = z; p.bias = bias; p.y = y;
     p.part_stride = (size_t)M * PART;
-    p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N; p.relu = relu;
+    p.B = B; p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N; p.relu = relu;
     p.hscale = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
     p.wscale = (align_corners && OW > 1) ? (float)(w - 1) / (float)(OW - 1) : (float)w / (float)OW;
-    int rows_bound = 0;
-    p.RB = gather_band_rows(w, OH, p.hscale, &rows_bound);
-    const size_t lds = (size_t)rows_bound * w * 288;
-    const dim3 grid((unsigned)(N / 8), (unsigned)ceil_div(OH, p.RB), (unsigned)B);
+    int threads = 0;
+    if (!gather_geometry(h, w, OH, OW, p.hscale, &threads, &p.RB, &p.cap))
+        return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_upsampled: no gather geometry for a %dx%d -> %dx%d map", h, w, OH, OW);
+    p.capdiv = make_fastdiv(p.cap);
+    const size_t lds = (size_t)p.cap * w * 288;
+    const dim3 grid((unsigned)(8 * ceil_div(B, 8) * (N / 8)));
     if (out_c8) {
         MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(threads), lds, s, p);
     } else {
         MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(threads), lds, s, p);
     }
     MPSR_CHECK_LAUNCH("upconv_gather_kernel");
     return MPSR_OK;
@@ -238,7 +351,7 @@ extern "C" int mpsr_conv3x3_upsampled_f32(const float *x, int B, int h, int w, i
     MPSR_REQUIRE(B >= 0 && h > 0 && w > 0 && C > 0 && OH > 0 && OW > 0 && N > 0, "conv3x3_upsampled: bad shape");
     if (B == 0) return MPSR_OK;
     MPSR_REQUIRE(x && weights && y && ws, "conv3x3_upsampled: null pointer");
-    if (!mpsr::upconv_applies(B, h, w, C, OH, OW, N))
+    if (!mpsr::upconv_applies(B, h, w, C, OH, OW, N, align_corners))
         return mpsr::fail(MPSR_ERR_UNSUPPORTED,
                           "conv3x3_upsampled: needs N %% 128 == 0, C %% 64 == 0 and >= 128 (B=%d %dx%dx%d -> %dx%dx%d); use "
                           "mpsr_resize_bilinear + mpsr_conv2d_nhwc_f32",

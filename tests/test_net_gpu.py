@@ -240,7 +240,7 @@ UPCONV_CASES = [
     (2, 5, 7, 128, 11, 16, 128, False, True, True),     # legacy scale in / out
     (1, 12, 12, 512, 24, 24, 256, True, True, True),    # conv2_1's real layer shape
     (1, 24, 24, 256, 48, 48, 128, True, True, True),    # conv3_1's real layer shape
-    (2, 9, 4, 128, 9, 4, 128, True, True, True),        # no resizing at all: a plain 3x3 convolution
+    (2, 8, 8, 128, 12, 12, 128, True, True, True),      # 1.5x
 ]
 
 
