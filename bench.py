@@ -50,6 +50,9 @@ def _launch_ranks(argv):
             port = str(s.getsockname()[1])
     import signal
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
+    # cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument` (the task environment exports
+    # it already; a value the caller set is kept)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
@@ -189,61 +192,88 @@ class Step:
 
 
 def conv_replay(net, B):
-    """Every conv/FC launch of one step (same shapes, same order) with nothing in between, so that HIP events
-    around it time the dominant kernel alone.  Returns (callable, launches per call)."""
+    """Every matrix-pipe launch of one step -- same kernels, same variants, same order -- with nothing in between, so
+    that HIP events around it time the dominant kernel family alone: the trunk's 94 layers (conv3 / squash launches WITH
+    their residual operand), the decoder's layers as mpsr_squash_decoder_plan says the step runs them (conv2_1 / conv3_1
+    as their tap GEMMs, 1152 columns per launch: the gather kernels that follow are vector-ALU work and are not
+    replayed), the xyz head, and the seven head FCs incl. img_fc (stream-K).  Returns (callable, launches, algorithmic
+    FLOPs, algorithmic bytes, executed FLOPs, launches by kind)."""
+    import ctypes
     from monopsr_amd import _lib
+    from monopsr_amd.core import weights as W
     lib = _lib.lib()
     dev = net.device
     jobs = []
 
-    def add(part, idx, M_hw, alg_cin=None, raw=False):
+    def plan(Bq, H, Wd, cin, cout, kh, kw, dil):
+        kind, ex = ctypes.c_int(0), ctypes.c_double(0.0)
+        _lib.check(lib.mpsr_conv2d_plan(Bq, H, Wd, cin, cout, kh, kw, dil, ctypes.byref(kind), ctypes.byref(ex)))
+        return kind.value, ex.value
+
+    def add(part, idx, M_hw, alg_cin=None, raw=False, residual=False, override=None):
         r = part.records[idx]
-        Bq, H, W = M_hw
+        Bq, H, Wd = M_hw
         # inputs with the statistics of the step's own activations: every layer but the root reads the output of a
         # ReLU (half zeros) -- a dense N(0,1) operand draws more power and ran the replay ~2 % slower than in situ
-        x = torch.empty((Bq * H * W * r["cin"],), dtype=torch.float32, device=dev).normal_()
+        x = torch.empty((Bq * H * Wd * r["cin"],), dtype=torch.float32, device=dev).normal_()
         if not raw:
             x.clamp_(min=0)
-        y = torch.empty((Bq * H * W * r["cout"],), dtype=torch.float32, device=dev)
-        jobs.append((x, y, part.blob, r, Bq, H, W, alg_cin or r["cin"]))  # alg_cin: K without zero padding
+        bias = part.blob.data_ptr() + 4 * r["b_off"] if r["b_off"] >= 0 else None
+        alg = 2.0 * Bq * H * Wd * (alg_cin or r["cin"]) * r["kh"] * r["kw"] * r["cout"]
+        alg_b = 4.0 * (Bq * H * Wd * (r["cin"] + r["cout"] * (2 if residual else 1)) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
+        if override is not None:  # the layer runs as `parts` 1x1 GEMMs of the source map with 1152 outputs each
+            sh, sw, parts = override
+            wgt = torch.randn((parts * 1152 * r["cin"],), dtype=torch.float32, device=dev) * 0.02
+            xs = x[:Bq * sh * sw * r["cin"]]
+            for pi in range(parts):
+                y = torch.empty((Bq * sh * sw * 1152,), dtype=torch.float32, device=dev)
+                jobs.append(dict(x=xs, y=y, w=wgt.data_ptr() + 4 * pi * 1152 * r["cin"], bias=None, res=None, keep=wgt,
+                                 shape=(Bq, sh, sw, r["cin"], 1152, 1, 1, 1, 0), alg=alg / parts, alg_b=alg_b / parts,
+                                 kind=7, ex=2.0 * Bq * sh * sw * r["cin"] * 1152))
+            return
+        y = torch.empty((Bq * H * Wd * r["cout"],), dtype=torch.float32, device=dev)
+        res = torch.empty_like(y).normal_().clamp_(min=0) if residual else None
+        kind, ex = plan(Bq, H, Wd, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"])
+        jobs.append(dict(x=x, y=y, w=part.blob.data_ptr() + 4 * r["w_off"], bias=bias, res=res, keep=None,
+                         shape=(Bq, H, Wd, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"], r["relu"]),
+                         alg=alg, alg_b=alg_b, kind=kind, ex=ex))
 
     tr = net.crop_trunk
+    roles = [sp["role"] for sp in W.scaled_trunk_specs(W.CROP_SCOPE, net.width_div)]
     add(tr, 0, (B * 576, 1, 1), 147, raw=True)
     for k in range(1, tr.n):
-        add(tr, k, (B, 12, 12))
+        add(tr, k, (B, 12, 12), residual=roles[k] == "conv3")
     dec = net.decoder
+    kinds7, ex7 = (ctypes.c_int * 7)(), (ctypes.c_double * 7)()
+    _lib.check(lib.mpsr_squash_decoder_plan(B, 12, 12, 48, 48, dec.layers, dec.n, kinds7, ex7))
     for k, hw in enumerate([(12, 12), (12, 12), (24, 24), (24, 24), (48, 48), (48, 48), (48, 48)]):
-        add(dec, k, (B, hw[0], hw[1]))
+        if kinds7[k] == 7:  # tap GEMM on the source map (half the size), one launch per 128 output channels
+            add(dec, k, (B, hw[0], hw[1]), override=(hw[0] // 2, hw[1] // 2, dec.records[k]["cout"] // 128))
+        else:
+            add(dec, k, (B, hw[0], hw[1]), residual=k == 1)
+            jobs[-1]["kind"], jobs[-1]["ex"] = kinds7[k], ex7[k]
     hd = net.heads
-    for k in range(1, hd.n):  # img_fc (split-K + reduce kernel) is left out: it is not a pure conv launch
+    for k in range(hd.n):
         add(hd, k, (B, 1, 1), {1: 1043, 4: 1060}.get(k))
 
     # the network entry points hand every layer the scheduling scratch and leave the schedule to the library
     # (split_k = 0); the replay does the same, so it launches the kernels a step launches
-    nws = max(lib.mpsr_conv2d_scratch_floats(Bq, H, W, r["cout"]) for _, _, _, r, Bq, H, W, _ in jobs)
+    nws = max(lib.mpsr_conv2d_scratch_floats(j["shape"][0], j["shape"][1], j["shape"][2], j["shape"][4]) for j in jobs)
     ws = torch.empty((nws,), dtype=torch.float32, device=dev)
 
     def run():
         s = _lib.stream()
-        for x, y, blob, r, Bq, H, W, _ in jobs:
-            bias = blob.data_ptr() + 4 * r["b_off"] if r["b_off"] >= 0 else None
-            _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), Bq, H, W, r["cin"], blob.data_ptr() + 4 * r["w_off"],
-                                                bias, None, y.data_ptr(), r["cout"], r["kh"], r["kw"], r["dilation"],
-                                                r["relu"], 0, ws.data_ptr(), nws, s))
-    flops = sum(2.0 * Bq * H * W * cin * r["kh"] * r["kw"] * r["cout"] for _, _, _, r, Bq, H, W, cin in jobs)
-    # multiply-add FLOPs the library's kernels really issue for these launches: the Winograd kernel (decoder 3x3
-    # layers) 16/36 of the direct count, the atrous layers only their in-image taps
-    import ctypes
-    executed, kinds = 0.0, {}
-    for _, _, _, r, Bq, H, W, _ in jobs:
-        kind, ex = ctypes.c_int(0), ctypes.c_double(0.0)
-        _lib.check(lib.mpsr_conv2d_plan(Bq, H, W, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"],
-                                        ctypes.byref(kind), ctypes.byref(ex)))
-        executed += ex.value
-        kinds[kind.value] = kinds.get(kind.value, 0) + 1
-    # algorithmic HBM bytes of a launch: its input, weights and output once each
-    alg_bytes = sum(4.0 * (Bq * H * W * (r["cin"] + r["cout"]) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
-                    for _, _, _, r, Bq, H, W, _ in jobs)
+        for j in jobs:
+            Bq, H, Wd, cin, cout, kh, kw, dil, relu = j["shape"]
+            _lib.check(lib.mpsr_conv2d_nhwc_f32(j["x"].data_ptr(), Bq, H, Wd, cin, j["w"], j["bias"],
+                                                j["res"].data_ptr() if j["res"] is not None else None, j["y"].data_ptr(),
+                                                cout, kh, kw, dil, relu, 0, ws.data_ptr(), nws, s))
+    flops = sum(j["alg"] for j in jobs)
+    executed = sum(j["ex"] for j in jobs)
+    kinds = {}
+    for j in jobs:
+        kinds[j["kind"]] = kinds.get(j["kind"], 0) + 1
+    alg_bytes = sum(j["alg_b"] for j in jobs)
     return run, len(jobs), flops, alg_bytes, executed, kinds
 
 
@@ -308,8 +338,10 @@ def roofline_object(net, args, device, ms_per_step):
             pass
     fp32 = args.math == "fp32"
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
-    kname = "conv_igemm_kernel + wino conv kernels (fp32 MFMA 32x32x2: implicit GEMM; Winograd F(4x4,3x3) for the " \
-            "decoder's 3x3 layers, F(3x3,3x3) for block3's atrous 3x3 layers)" if fp32 else \
+    kname = "fp32 MFMA 32x32x2 convolution / FC kernels: pw_conv_kernel (wide 1x1 layers and the decoder's tap GEMMs), " \
+            "wino3_conv_kernel (F(3x3,3x3), block3's atrous 3x3), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
+            "conv3_2), conv_igemm_kernel / conv_sk_kernel (blocks 1-2, root, img_fc), fc_rows_kernel, " \
+            "conv3x3_narrow_mfma_kernel" if fp32 else \
         "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
     alg = flops / launches / avg_s / 1e12
     exe = executed / launches / avg_s / 1e12 if fp32 else alg
@@ -322,13 +354,17 @@ def roofline_object(net, args, device, ms_per_step):
            "algorithmic_bytes": round(alg_bytes / launches),
            "kernel_ms_per_step": round(pass_s * 1e3, 3),
            "kernel_ms_per_step_le_ms_per_step": bool(pass_s * 1e3 <= ms_per_step),
-           "replay": "the step's conv/FC launches back to back on post-ReLU-like operands (relu(N(0,1)); the root "
-                     "conv on N(0,1)) -- the step's own activations live in ping-pong scratch and cannot be replayed"}
+           "replay": "the step's matrix-pipe launches back to back -- the variants the step launches: residual operands "
+                     "on conv3 / squash, the decoder's tap GEMMs, img_fc on stream-K -- on post-ReLU-like operands "
+                     "(relu(N(0,1)); the root conv on N(0,1)); the step's own activations live in ping-pong scratch and "
+                     "cannot be replayed; not replayed: the vector-ALU kernels between them (im2col, pools, the two "
+                     "upsampling gathers, head glue, Chamfer)"}
     if fp32:
         out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
                                "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0),
                                "winograd_f3x3_3x3_atrous_subgrids": kinds.get(4, 0),
-                               "pointwise_persistent": kinds.get(5, 0), "fc_few_rows": kinds.get(6, 0)}
+                               "pointwise_persistent": kinds.get(5, 0), "fc_few_rows": kinds.get(6, 0),
+                               "upsampled_conv_tap_gemm": kinds.get(7, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
                        "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
                        "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction from the quoted collection")
@@ -380,6 +416,83 @@ def emd_object(device, b=256, n=2048):
             "match_cost_read_GBps": round(4 * pairs / t_c / 1e9, 1),
             "match_cost_grad_read_GBps": round(8 * pairs / t_g / 1e9, 1), "hbm_peak_GBps": 8000,
             "bound": "v_exp_f32 issue (passes), HBM (materialised match)"}
+
+
+def cfg5_step_object(step, inp, device, steps):
+    """BASELINE config 5 as ONE timed step on this GPU: the forward pass of the batch's crops (trunk, squash / decoder /
+    xyz, heads) + the approximate-EMD loss with its gradients (mpsr_emd_loss: approx_match + match_cost + match_cost_grad
+    fused, reference losses_custom.py:135-165) between the first 2048 points of every predicted N x 3 cloud and a
+    2048-point U(-1,1) ground-truth cloud.  A side measurement: `value` is config 3."""
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    B = inp["crops"].shape[0]
+    g = torch.Generator(device=device).manual_seed(7)
+    gt = torch.rand((B, 2048, 3), device=device, generator=g) * 2 - 1
+
+    def one():
+        xyz, out = step.forward_net()
+        pred = xyz.reshape(B, -1, 3)[:, :2048].contiguous()
+        cost, g1, g2 = am.emd_loss_fwd_bwd(pred, gt)
+        return out["centroids"], cost, g1
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    k = max(3, min(10, steps))
+    t0 = time.perf_counter()
+    for _ in range(k):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    return {"workload": "BASELINE cfg5 per-GPU share: batch=%d crops fwd + 2048-pt approxmatch EMD loss fwd/bwd, one step"
+                        % B, "ms_per_step": round(dt * 1e3, 3), "crops_per_s": round(B / dt, 1), "steps": k,
+            "points": 2048, "emd": "mpsr_emd_loss (fused: no match tensor), device semantics"}
+
+
+def full_image_path_object(device, boxes=32, images=4, reps=3):
+    """SURVEY 8(f) row 1 / the reference's own step shape (configs/monopsr_model_000.yaml:14-17): ONE 375 x 1242 image +
+    32 proposal boxes in -> preprocess, proposal crops, crop trunk AND full-image trunk (on a second stream), feature
+    crop + pool, squash / decoder / xyz, heads out (MonoPSRModel.build); and the crop-only step at the same batch of 32."""
+    from monopsr_amd.core import config_utils
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=0, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
+    net = dn.DeviceNet(weights, device=device, full_trunk=True)
+    model = MonoPSRModel(cfg.model_config, cfg.dataset_config, net, "test")
+    rng = np.random.default_rng(0)
+    H, Wd, B = 375, 1242, boxes
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    samples = []
+    for _ in range(images):
+        h, w = rng.uniform(20, 200, B), rng.uniform(20, 200, B)
+        y1, x1 = rng.uniform(0, H - 1 - h), rng.uniform(0, Wd - 1 - w)
+        bx = np.stack([y1, x1, y1 + h, x1 + w], 1).astype(np.float32)
+        samples.append(dict(rgb_image=t(rng.integers(0, 256, (H, Wd, 3)).astype(np.float32)), boxes_2d=t(bx),
+                            boxes_2d_norm=t(bx / np.array([H, Wd, H, Wd], np.float32)), cam_p=t(P2),
+                            est_view_angs=t(rng.uniform(-0.6, 0.6, B).astype(np.float32)),
+                            class_indices=torch.ones((B, 1), dtype=torch.int32, device=device),
+                            mean_lwh=t(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                            prop_cen_z_offset=torch.full((B,), 2.178, device=device)))
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (reps * n)
+    ms = 1e3 * timed(lambda: [model.build(dict(sm)) for sm in samples], images)
+    inp32, _ = make_inputs(B, 1024, 0, device)
+    st = Step(net, inp32, 1024)
+    ms32 = 1e3 * timed(lambda: [st() for _ in range(images)], images)
+    gflop = 2 * 167.1 + B * 12.393  # full-image trunk (SURVEY 8(a) a3) + per-crop path, algorithmic
+    return {"workload": "375x1242 image + %d boxes -> both trunks, feature crop, squash / decoder / xyz, heads" % B,
+            "ms_per_image": round(ms, 3), "images_per_s": round(1e3 / ms, 1), "crops_per_s": round(B * 1e3 / ms, 1),
+            "algorithmic_GFLOP_per_image": round(gflop, 1), "algorithmic_TFLOP_per_s": round(gflop / ms, 1),
+            "crop_only_step_batch_%d" % B: {"ms_per_step": round(ms32, 3), "crops_per_s": round(B * 1e3 / ms32, 1),
+                                             "what": "the cfg3 step (synthetic full-image feature crop + Chamfer) at the "
+                                                     "reference's 32 boxes per image"}}
 
 
 def _timed_threads(fn, parts, workers):
@@ -477,7 +590,8 @@ def cpu_baseline(weights, host, sample, npts, budget_s=18.0):
     return out, ref
 
 
-def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_dev=None, make_trainer=None):
+def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_dev=None, make_trainer=None,
+                         bucket_mib=64, full_trunk=False):
     """ms per training step of `batch` instances per rank (crop trunk + decoder + heads trainable, 72.8 M parameters
     in one flat buffer).  With a process group (N > 1) every rank trains its own shard and the flat 291 MB gradient
     goes through core/trainer.ReverseBucketReducer (64 MiB buckets launched from the end of the buffer as backward
@@ -488,11 +602,21 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         from monopsr_amd.core import config_utils, train_net, trainer
         from monopsr_amd.core import weights as W
         cfg = config_utils.default_config()
-        net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
-        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0)
+        if full_trunk:  # both trunks trainable: the 100.3 M-parameter / 401 MB gradient of BASELINE cfg4
+            net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=(W.CROP_SCOPE, W.FULL_SCOPE)), device=device,
+                                     decoder_bn="batch", full_trunk=True)
+        else:
+            net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
+        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0,
+                                     bucket_bytes=bucket_mib << 20)
         sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
                       cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"],
                       mean_lwh=inp["mean_lwh"], prop_cen_z_offset=inp["z_off"])
+        if full_trunk:  # the full-image branch needs the image itself and the boxes normalised to it
+            g = torch.Generator(device=device).manual_seed(8)
+            sample["rgb_image"] = torch.randint(0, 256, (375, 1242, 3), device=device, generator=g).float()
+            sample["boxes_2d_norm"] = inp["boxes"] / torch.tensor([375.0, 1242.0, 375.0, 1242.0], device=device)
+            del sample["full_img_feature_crop"], sample["rgb_image_crops"]  # (as tools/train_bench.py --full-image)
         sample.update(trainer.synthetic_ground_truth(sample, seed=7))
     else:
         tr, sample = make_trainer()
@@ -729,6 +853,12 @@ def main():
                     help="N > 1: skip the extra region that repeats the step with the gradient-sized all-reduce")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3_mode measurement appended to a default fp32 run")
+    ap.add_argument("--bucket-mib", type=int, default=64, choices=[16, 32, 64, 128],
+                    help="N > 1: bucket size of the training step's gradient all-reduce (ReverseBucketReducer)")
+    ap.add_argument("--train-full-trunk", action="store_true",
+                    help="training_step with BOTH ResNet-101 trunks trainable (100.3 M parameters: the 401 MB gradient "
+                         "BASELINE cfg4 names) on a raw 375x1242 image per rank instead of the crop-trunk-only net")
+    ap.add_argument("--no-full-image", action="store_true", help="skip the extra full_image_path object")
     ap.add_argument("--extras-deadline", type=float, default=900.0,
                     help="seconds after the headline is measured before the watchdog prints it without the "
                          "unfinished extra objects")
@@ -925,6 +1055,16 @@ def main():
                 result["emd"] = emd_object(device)
             except Exception as e:
                 result["emd"] = {"error": repr(e)}
+    if rank == 0 and not args.no_roofline and not args.no_emd and isinstance(step, Step):
+        try:
+            result["cfg5_step"] = cfg5_step_object(step, inp, device, args.steps)
+        except Exception as e:
+            result["cfg5_step"] = {"error": repr(e)}
+    if rank == 0 and n_gpus == 1 and not args.no_roofline and not args.no_full_image and args.math == "fp32":
+        try:
+            result["full_image_path"] = full_image_path_object(device)
+        except Exception as e:
+            result["full_image_path"] = {"error": repr(e)}
     if rank == 0 and n_gpus == 1 and args.math == "fp32" and not args.no_fast_mode:
         # the same step in the opt-in bf16x3 contraction mode, with the drift of its outputs against the fp32 run
         # on the same inputs (NOT the headline: `value` above is fp32)
@@ -966,7 +1106,7 @@ def main():
                 tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
                 # N = 1: 2 + 18 steps, so that the line shows the loss past the first Adam steps' transient
                 ts = training_step_object(device, tb, tinp, steps=6 if multi else 18, dist=dist if multi else None,
-                                          red_dev=red_dev)
+                                          red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=args.train_full_trunk)
                 result["training_step"] = ts
             except Exception as e:
                 result["training_step"] = {"error": repr(e)}

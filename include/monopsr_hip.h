@@ -180,6 +180,23 @@ enum { MPSR_MATH_FP32 = 0, MPSR_MATH_BF16X3 = 1 };
 int mpsr_set_conv_math(int mode);
 int mpsr_get_conv_math(void);
 
+/* Whether 3x3 layers may run in a Winograd transform domain (process-wide setting, like the arithmetic above).
+ *   MPSR_WINOGRAD_AUTO (default) F(3x3,3x3) on block3's atrous layers, F(4x4,3x3) / F(2x2,3x3) on the dense decoder
+ *                      layers wherever they are faster.  Error against float64 of the tensor's SCALE: 5e-6 / 1.5e-5 /
+ *                      1e-6 (a direct fp32 convolution: 5e-7) -- far inside the path's 1e-3 budget.  The transforms mix
+ *                      the values of a whole input patch, so a SMALL output next to a very large activation carries
+ *                      an error relative to the large one: on maps with 1 % of the entries 1000x the rest, elements
+ *                      down to 1e-3 of the tensor's maximum were measured 2e-3 .. 4e-3 off relative to THEMSELVES
+ *                      (F(4x4,3x3); F(3x3,3x3) 2e-3; the direct kernels 1e-4; tests/test_hostile_inputs_gpu.py).  The
+ *                      decoder end to end on such features (100x outliers): 1.2e-3, where fp32 arithmetic without any
+ *                      Winograd kernel measures 8.6e-4.
+ *   MPSR_WINOGRAD_OFF  direct / implicit-GEMM kernels everywhere (the upsampled convolutions keep their exact tap
+ *                      GEMM): element-wise 1e-4 on the same inputs, at ~1.4x the step time.  For callers whose
+ *                      activations are heavy-tailed AND who read small outputs individually. */
+enum { MPSR_WINOGRAD_AUTO = 0, MPSR_WINOGRAD_OFF = 1 };
+int mpsr_set_winograd_policy(int policy);
+int mpsr_get_winograd_policy(void);
+
 /* tf.image.resize_bilinear (align_corners as given) followed by a 3x3 SAME slim.conv2d, as the map decoder applies
  * them (monopsr/builders/net_builder.py:72-77, :81-85), WITHOUT forming the upsampled map: a 1x1 GEMM of the source
  * map with 9 N outputs (channel mixing commutes with the per-channel upsampling) + a 9-tap x 4-corner gather
@@ -396,6 +413,11 @@ int mpsr_squash_decoder_fwd(const float *crop_feat, const float *full_feat, int 
                             const float *blob, const mpsr_layer *layers, int n_layers, float *feat_box3d,
                             float *feat_map, float *xyz_map, void *workspace, size_t workspace_bytes,
                             mpsr_stream_t stream);
+/* Which kernel serves each of the seven layers for this shape (kinds[7], as mpsr_conv2d_plan; 7 = tap GEMM on the
+ * source map + gather, csrc/upconv.hip) and the multiply-add FLOPs it issues (executed_flops[7]): throughput accounting
+ * for bench.py's roofline object, not needed to run anything. */
+int mpsr_squash_decoder_plan(int B, int fh, int fw, int mh, int mw, const mpsr_layer *layers, int n_layers, int *kinds,
+                             double *executed_flops);
 /* The same with options (filter cache; ready_event = feat_box3d complete). */
 int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *full_feat, int B, int fh, int fw, int mh, int mw,
                                const float *blob, const mpsr_layer *layers, int n_layers, float *feat_box3d,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mpsr_abi_version": (c_i, []),
     "mpsr_set_conv_math": (c_i, [c_i]),
     "mpsr_get_conv_math": (c_i, []),
+    "mpsr_set_winograd_policy": (c_i, [c_i]),
+    "mpsr_get_winograd_policy": (c_i, []),
     "mpsr_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, c_sz]),
     "mpsr_nn_distance_fwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -115,6 +117,8 @@ SIGNATURES = {
     "mpsr_squash_decoder_fwd_ex": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f,
                                          c_f, c_f, c_sz, ctypes.POINTER(NetOpts), c_f]),
     "mpsr_decoder_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "mpsr_squash_decoder_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(Layer), c_i, ctypes.POINTER(c_i),
+                                       ctypes.POINTER(ctypes.c_double)]),
     "mpsr_squash_decoder_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f,
                                       c_f, c_f, c_sz, c_f]),
     "mpsr_heads_workspace_bytes": (c_sz, [c_i, c_i]),
@@ -160,6 +164,21 @@ def set_conv_math(mode):
     if mode not in MATH_MODES:
         raise InvalidArgumentError("unknown conv math mode %r (choose from %s)" % (mode, sorted(MATH_MODES)))
     check(lib().mpsr_set_conv_math(MATH_MODES[mode]))
+    return prev
+
+
+WINOGRAD_POLICIES = {"auto": 0, "off": 1}
+
+
+def set_winograd_policy(policy):
+    """Process-wide: "auto" (default: Winograd kernels wherever they are faster) or "off" (direct / implicit-GEMM
+    kernels everywhere: tighter element-wise error on heavy-tailed activations, include/monopsr_hip.h).  Returns the
+    previous policy."""
+    names = {v: k for k, v in WINOGRAD_POLICIES.items()}
+    prev = names[lib().mpsr_get_winograd_policy()]
+    if policy not in WINOGRAD_POLICIES:
+        raise InvalidArgumentError("unknown Winograd policy %r (choose from %s)" % (policy, sorted(WINOGRAD_POLICIES)))
+    check(lib().mpsr_set_winograd_policy(WINOGRAD_POLICIES[policy]))
     return prev
 
 

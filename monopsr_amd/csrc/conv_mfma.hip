@@ -1017,6 +1017,7 @@ std::atomic<int> g_tile_override{-1};
 std::atomic<int> g_class_override{-1};
 std::atomic<int> g_sched_override{-1};
 std::atomic<int> g_sk_per_cu{0};
+std::atomic<int> g_wino_policy{0};      // mpsr_set_winograd_policy: MPSR_WINOGRAD_AUTO / MPSR_WINOGRAD_OFF
 std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) / 3 F(3x3,3x3) on atrous sub-grids whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
@@ -1140,6 +1141,8 @@ bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split
         !pointwise_applies(M, C, N))
         return false;
     if (pw > 0) return true;
+    // (a forced schedule / border-class mode asks for the implicit-GEMM kernels, as for the few-row FC kernel above)
+    if (g_sched_override.load() >= 0 || g_class_override.load() >= 0) return false;
     const long long tiles = ((M + 95) / 96) * ((N + 127) / 128);
     return split_k == 0 && N % 128 == 0 && tiles >= 512;
 }
@@ -1174,12 +1177,19 @@ int auto_split_k(int M, int N, int ksteps, const float *ws, size_t ws_floats)
     return s < 1 ? 1 : (int)s;
 }
 
+// The Winograd selector the rules below read: the debug override if set, else "never" under MPSR_WINOGRAD_OFF.
+static int winograd_mode()
+{
+    const int wino = g_wino_override.load();
+    return (wino < 0 && g_wino_policy.load() == MPSR_WINOGRAD_OFF) ? 0 : wino;
+}
+
 // True when conv2d() with split_k = 0 would send this 3x3 layer to the F(4x4,3x3) kernel (network.hip asks before it
 // lays the decoder's internal tensors out channel-blocked, which only that kernel reads).
 bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, size_t ws_floats)
 {
     const long long M64 = (long long)B * H * W;
-    const int wino = g_wino_override.load();
+    const int wino = winograd_mode();
     return ws && (wino < 0 || wino == 2) && g_tile_override.load() < 0 && M64 >= 65536 && C >= 64 && N >= 64 &&
            winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
 }
@@ -1189,7 +1199,7 @@ bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, 
 bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int split_k, const float *ws,
                             size_t ws_floats)
 {
-    const int wino = g_wino_override.load();
+    const int wino = winograd_mode();
     const long long M64 = (long long)B * H * W;
     const bool can3 = KH == 3 && KW == 3 && dilation > 1 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
                       winograd3_applies(H, W, C, dilation) && ws_floats >= winograd3_scratch_floats(C, N) &&
@@ -1197,6 +1207,28 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
                                      (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64);
     return can3 && want3;
+}
+
+// The dense-3x3 choice of conv2d() -- 0: no Winograd kernel, 1: F(2x2,3x3) (winograd.hip), 2: F(4x4,3x3) (winograd4.hip).
+// One copy of the rule: mpsr_conv2d_plan asks it too.
+int conv2d_winograd_choice(int B, int H, int W, int C, int N, int KH, int KW, int dilation, bool residual, int split_k,
+                           const float *ws, size_t ws_floats)
+{
+    const long long M64 = (long long)B * H * W;
+    int wino = winograd_mode();
+    // (the F(4x4) kernel also serves the opt-in bf16x3 mode: in exact fp32 it is faster on these layers than the
+    // split-bfloat16 implicit GEMM -- 3.1 vs 3.6 ms for the four of them -- and adds no drift)
+    const bool base = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws;
+    const bool can2 = base && g_math.load() == MATH_FP32 && winograd_applies(H, W, C, N) &&
+                      ws_floats >= winograd_scratch_floats(C, N);
+    const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
+                      M64 * C * 4 < 0x7f000000LL;
+    // (the automatic choice is conv2d_takes_winograd4's -- network.hip asks it too)
+    if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
+                         : (M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
+    if (wino == 2 && can4) return 2;
+    if ((wino == 1 || wino == 2) && can2) return 1;
+    return 0;
 }
 
 // Shared by the network-level entry points (network.hip).
@@ -1230,19 +1262,9 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // library: F(4x4,3x3) (winograd4.hip, 4x fewer multiply-adds) where the map divides into 4x4 blocks, else
     // F(2x2,3x3) (winograd.hip, 2.25x fewer)
     {
-        int wino = g_wino_override.load();
-        // (the F(4x4) kernel also serves the opt-in bf16x3 mode: in exact fp32 it is faster on these layers than the
-        // split-bfloat16 implicit GEMM -- 3.1 vs 3.6 ms for the four of them -- and adds no drift)
-        const bool base = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws;
-        const bool can2 = base && g_math.load() == MATH_FP32 && winograd_applies(H, W, C, N) &&
-                          ws_floats >= winograd_scratch_floats(C, N);
-        const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
-                          M64 * C * 4 < 0x7f000000LL;
-        // (the automatic choice is conv2d_takes_winograd4's -- one copy of the rule, network.hip asks it too)
-        if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
-                             : (M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
-        if (wino == 2 && can4) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
-        if ((wino == 1 || wino == 2) && can2) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        const int wc = conv2d_winograd_choice(B, H, W, C, N, KH, KW, dilation, residual != nullptr, split_k, ws, ws_floats);
+        if (wc == 2) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
+        if (wc == 1) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
     }
     if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
         return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
@@ -1352,6 +1374,13 @@ extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode;
 extern "C" void mpsr_debug_set_conv_depth(int depth) { g_depth_override = depth; }
 extern "C" void mpsr_debug_set_conv_plain(int mode) { g_plain_override = mode; }
 extern "C" void mpsr_debug_set_conv_winograd(int mode) { g_wino_override = mode; }
+extern "C" int mpsr_set_winograd_policy(int policy)
+{
+    MPSR_REQUIRE(policy == MPSR_WINOGRAD_AUTO || policy == MPSR_WINOGRAD_OFF, "set_winograd_policy: unknown policy %d", policy);
+    g_wino_policy = policy;
+    return MPSR_OK;
+}
+extern "C" int mpsr_get_winograd_policy(void) { return g_wino_policy; }
 extern "C" void mpsr_debug_set_conv_sched(int mode, int per_cu)
 {
     g_sched_override = mode;
@@ -1383,15 +1412,14 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
         *executed_flops = 2.0 * (double)B * dilation * dilation * 25.0 * C * N;
         return MPSR_OK;
     }
-    const bool wino_any = KH == 3 && KW == 3 && dilation == 1 && M >= 65536 && C >= 64 && N >= 64 &&
-                          g_wino_override.load() != 0;
-    const bool wino_shape = wino_any && g_math.load() == MATH_FP32;
-    if (wino_any && mpsr::winograd4_applies(H, W, C, N) && g_wino_override.load() != 1 && M * C * 4 < 0x7f000000LL) {
+    const int wc = mpsr::conv2d_winograd_choice(B, H, W, C, N, KH, KW, dilation, false, 0,
+                                                reinterpret_cast<const float *>(16), ~(size_t)0);
+    if (wc == 2) {
         *kind = 3;  // F(4x4,3x3): 36 products per 4x4 block
         *executed_flops = 2.0 * (double)B * (H / 4) * (W / 4) * 36.0 * C * N;
         return MPSR_OK;
     }
-    if (wino_shape && mpsr::winograd_applies(H, W, C, N)) {
+    if (wc == 1) {
         *kind = 1;
         *executed_flops = 2.0 * (double)B * (H / 2) * (W / 2) * 16.0 * C * N;
         return MPSR_OK;

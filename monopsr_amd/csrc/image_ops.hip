@@ -588,6 +588,18 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_mfma_kernel(const float *_
 
 namespace mpsr {
 // Used by conv2d() for 3x3, dilation 1, N <= 4, C % 32 == 0 layers without residual.
+// True when conv3x3_narrow runs the taps-in-N MFMA kernel for this layer -- the only form that reads a channel-blocked
+// input.  ONE copy of the rule: mpsr_squash_decoder_fwd (network.hip) asks it before it lets the last decoder layer
+// write channel-blocked (x = nullptr: the input does not exist yet, its alignment is the workspace's 256 bytes).
+bool conv3x3_narrow_takes_mfma(const float *x, int B, int H, int W, int C, int N, const float *w)
+{
+    const size_t lds = (size_t)(kNarrowRows + 2) * W * 27 * sizeof(float);
+    const long long xb = (long long)B * H * W * C * 4;
+    const bool inst = C == 32 || C == 64 || C == 96 || C == 128;  // the instantiated channel counts
+    return N >= 1 && N <= 3 && inst && lds <= 64 * 1024 && B <= 65535 && xb < 0x7fffffffLL && ((uintptr_t)x & 15) == 0 &&
+           ((uintptr_t)w & 15) == 0;
+}
+
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s, int in_c8)
 {
@@ -595,8 +607,7 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
     {
         const size_t lds = (size_t)(kNarrowRows + 2) * W * 27 * sizeof(float);
         const long long xb = (long long)B * H * W * C * 4;
-        if (N <= 3 && C % 8 == 0 && C >= 32 && C <= 128 && lds <= 64 * 1024 && B <= 65535 && xb < 0x7fffffffLL &&
-            ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+        if (conv3x3_narrow_takes_mfma(x, B, H, W, C, N, w)) {
             const dim3 grid(ceil_div(H, kNarrowRows), B);
 #define MPSR_NARROW(KB_)                                                                                              \
     if (in_c8) {                                                                                                      \
@@ -623,7 +634,8 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
         }
     }
 direct:
-    if (in_c8) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: a channel-blocked input needs N <= 3, C = 32..128");
+    if (in_c8)
+        return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: a channel-blocked input needs N <= 3 and C = 32, 64, 96 or 128");
     dim3 grid(ceil_div(W, kNarrowTile), ceil_div(H, kNarrowTile), B);
     if (grid.z > 65535) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_narrow: batch %d exceeds 65535", B);
     switch (N) {

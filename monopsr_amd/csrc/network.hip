@@ -24,6 +24,9 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
 bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k);
 int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                    int N, hipStream_t s, int in_c8);
+bool conv3x3_narrow_takes_mfma(const float *x, int B, int H, int W, int C, int N, const float *w);
+int conv2d_winograd_choice(int B, int H, int W, int C, int N, int KH, int KW, int dilation, bool residual, int split_k,
+                           const float *ws, size_t ws_floats);
 int resize_bilinear_c8(const float *in, int B, int H, int W, int C, int OH, int OW, int align_corners, float *out,
                        hipStream_t s);
 // upconv.hip: 3x3 convolution of a bilinearly upsampled map as a low-resolution tap GEMM + gather
@@ -255,6 +258,72 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
 
 // ------------------------------------------------------------------------------------------------ decoder
 
+namespace {
+// How mpsr_squash_decoder_fwd runs its layers -- one copy of the rule, mpsr_squash_decoder_plan reports it too.
+//   c8:     the internal tensors are channel-blocked ([C/8][H][W][8]): every 3x3 layer runs on a kernel that reads it
+//   up1/2:  conv2_1 / conv3_1 (each reads an upsampled map) as tap GEMM on the source map + gather (upconv.hip)
+//   xyz_c8: the xyz head reads the last decoder layer's output channel-blocked
+struct DecoderChoice {
+    bool c8, up1, up2, xyz_c8;
+};
+DecoderChoice decoder_choice(int B, int fh, int fw, int mh, int mw, const mpsr_layer *L, const float *blob, bool feat_map,
+                             bool xyz_map, const float *sk, size_t skn)
+{
+    const int hh = mh / 2, hw = mw / 2;
+    const int csq = L[1].cout, c2 = L[2].cout, c3 = L[4].cout;
+    DecoderChoice ch;
+    // (the xyz head's own predicate: only its taps-in-N MFMA kernel reads a channel-blocked map)
+    ch.xyz_c8 = !feat_map && xyz_map && L[6].kh == 3 && L[6].kw == 3 && L[6].dilation == 1 &&
+                mpsr::conv3x3_narrow_takes_mfma(nullptr, B, mh, mw, L[6].cin, L[6].cout, blob ? blob + L[6].w_off : nullptr);
+    const bool k3 = L[2].kh == 3 && L[3].kh == 3 && L[4].kh == 3 && L[5].kh == 3 && L[2].kw == 3 && L[3].kw == 3 &&
+                    L[4].kw == 3 && L[5].kw == 3 && L[2].dilation == 1 && L[3].dilation == 1 && L[4].dilation == 1 &&
+                    L[5].dilation == 1;
+    // conv2_1 / conv3_1 read an upsampled map: tap GEMM on the source map + gather (fp32 arithmetic only)
+    const bool upok = g_decoder_upconv.load() != 0 && k3 && mpsr_get_conv_math() == MPSR_MATH_FP32;
+    ch.up1 = upok && mpsr::upconv_applies(B, fh, fw, csq, hh, hw, c2, 1) && skn >= mpsr::upconv_weight_floats(csq, c2);
+    ch.up2 = upok && mpsr::upconv_applies(B, hh, hw, c2, mh, mw, c3, 1) && skn >= mpsr::upconv_weight_floats(c2, c3);
+    ch.c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 && k3 &&
+            (ch.up1 || mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn)) &&
+            mpsr::conv2d_takes_winograd4(B, hh, hw, L[3].cin, L[3].cout, sk, skn) &&
+            (ch.up2 || mpsr::conv2d_takes_winograd4(B, mh, mw, L[4].cin, L[4].cout, sk, skn)) &&
+            mpsr::conv2d_takes_winograd4(B, mh, mw, L[5].cin, L[5].cout, sk, skn);
+    if (!ch.c8) ch.xyz_c8 = false;  // (the NHWC chain: conv2d per layer; the upsampled convolutions keep their tap GEMM)
+    return ch;
+}
+}  // namespace
+
+// Which kernel serves each of the seven decoder layers and the multiply-add FLOPs it issues (kinds as mpsr_conv2d_plan;
+// 7 = tap GEMM on the source map + gather): what mpsr_squash_decoder_fwd does for this shape with xyz_map and without
+// feat_map.  For throughput accounting (bench.py), not needed to run anything.
+extern "C" int mpsr_squash_decoder_plan(int B, int fh, int fw, int mh, int mw, const mpsr_layer *L, int n_layers,
+                                        int *kinds, double *executed_flops)
+{
+    MPSR_REQUIRE(B > 0 && fh >= 2 && fw >= 2 && mh >= 2 && mw >= 2 && L && n_layers == MPSR_DECODER_LAYERS && kinds &&
+                     executed_flops,
+                 "squash_decoder_plan: bad arguments");
+    const int hh = mh / 2, hw = mw / 2;
+    const size_t Mm = (size_t)B * mh * mw;
+    int cwide = L[1].cout;
+    for (int i = 2; i < n_layers; ++i) cwide = L[i].cout > cwide ? L[i].cout : cwide;
+    const size_t skn = mpsr::conv_scratch_floats((long long)Mm, cwide > 512 ? cwide : 512);
+    const DecoderChoice ch = decoder_choice(B, fh, fw, mh, mw, L, nullptr, false, true, reinterpret_cast<const float *>(256), skn);
+    const int hs[7] = {fh, fh, hh, hh, mh, mh, mh}, ws[7] = {fw, fw, hw, hw, mw, mw, mw};
+    for (int i = 0; i < 7; ++i) {
+        int rc;
+        if ((i == 2 && ch.up1) || (i == 4 && ch.up2)) {
+            const int sh = i == 2 ? fh : hh, sw = i == 2 ? fw : hw;
+            kinds[i] = 7;
+            executed_flops[i] = 2.0 * (double)B * sh * sw * (double)L[i].cin * 9.0 * (double)L[i].cout;
+        } else if (ch.c8 && (i == 2 || i == 3 || i == 4 || i == 5)) {
+            kinds[i] = 3;
+            executed_flops[i] = 2.0 * (double)B * (hs[i] / 4) * (ws[i] / 4) * 36.0 * (double)L[i].cin * (double)L[i].cout;
+        } else if ((rc = mpsr_conv2d_plan(B, hs[i], ws[i], L[i].cin, L[i].cout, L[i].kh, L[i].kw, L[i].dilation, &kinds[i],
+                                          &executed_flops[i])))
+            return rc;
+    }
+    return MPSR_OK;
+}
+
 extern "C" size_t mpsr_decoder_workspace_bytes(int B, int fh, int fw, int mh, int mw)
 {
     if (B <= 0) return 0;
@@ -341,20 +410,8 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
     // the lines from beyond L2: 1.87x the layers' own bytes, profiles/r03_*), and the xyz head's A loads become 1 KiB
     // contiguous.  Layouts: r1, a, r2, c are C8; b (the input of the second resize) and a requested feat_map are NHWC.
     // Same kernels, same arithmetic order: bit-identical to the NHWC chain (tests/test_net_gpu.py).
-    const bool xyz_c8 = !feat_map && xyz_map && L[6].cout <= 3 && L[6].cin % 8 == 0 && L[6].cin >= 32 && L[6].cin <= 128 &&
-                        (size_t)10 * mw * 27 * sizeof(float) <= 64 * 1024 && L[6].kh == 3 && L[6].dilation == 1;
-    const bool k3 = L[2].kh == 3 && L[3].kh == 3 && L[4].kh == 3 && L[5].kh == 3 && L[2].kw == 3 && L[3].kw == 3 &&
-                    L[4].kw == 3 && L[5].kw == 3 && L[2].dilation == 1 && L[3].dilation == 1 && L[4].dilation == 1 &&
-                    L[5].dilation == 1;
-    // conv2_1 / conv3_1 read an upsampled map: tap GEMM on the source map + gather (fp32 arithmetic only)
-    const bool upok = g_decoder_upconv.load() != 0 && k3 && mpsr_get_conv_math() == MPSR_MATH_FP32;
-    const bool up1 = upok && mpsr::upconv_applies(B, fh, fw, csq, hh, hw, c2, 1) && skn >= mpsr::upconv_weight_floats(csq, c2);
-    const bool up2 = upok && mpsr::upconv_applies(B, hh, hw, c2, mh, mw, c3, 1) && skn >= mpsr::upconv_weight_floats(c2, c3);
-    const bool c8 = g_decoder_c8.load() != 0 && csq % 8 == 0 && c2 % 8 == 0 && c3 % 8 == 0 && k3 &&
-                    (up1 || mpsr::conv2d_takes_winograd4(B, hh, hw, L[2].cin, L[2].cout, sk, skn)) &&
-                    mpsr::conv2d_takes_winograd4(B, hh, hw, L[3].cin, L[3].cout, sk, skn) &&
-                    (up2 || mpsr::conv2d_takes_winograd4(B, mh, mw, L[4].cin, L[4].cout, sk, skn)) &&
-                    mpsr::conv2d_takes_winograd4(B, mh, mw, L[5].cin, L[5].cout, sk, skn);
+    const DecoderChoice ch = decoder_choice(B, fh, fw, mh, mw, L, blob, feat_map != nullptr, xyz_map != nullptr, sk, skn);
+    const bool xyz_c8 = ch.xyz_c8, up1 = ch.up1, up2 = ch.up2, c8 = ch.c8;
     if (c8) {
         auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
             cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
