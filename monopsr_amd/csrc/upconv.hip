@@ -21,6 +21,8 @@
 // rows (upconv_weights_kernel; kept in the caller's filter cache when there is one).  9 N columns are cut into parts of
 // 1152 = 9 column blocks of the pointwise kernel (its persistent grid then fills the chip: 504 of 512 workgroup slots),
 // i.e. one part per 128 output channels.
+#include <atomic>
+
 #include "common.h"
 #include "wino3_filter.h"
 
@@ -256,6 +258,10 @@ bool gather_geometry(int h, int w, int H, int W, float hscale, int *threads, int
 
 }  // namespace
 
+// images per GEMM + gather round, as MB of z (0 = the whole batch at once); see conv3x3_upsampled
+static std::atomic<int> g_upconv_chunk_mb{0};
+extern "C" void mpsr_debug_set_upconv_chunk_mb(int mb) { g_upconv_chunk_mb = mb > 0 ? mb : 0; }
+
 namespace mpsr {
 
 static bool upconv_geometry_ok(int h, int w, int OH, int OW, int align_corners)
@@ -306,15 +312,10 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
         MPSR_CHECK_LAUNCH("upconv_weights_kernel");
     }
     const int parts = N / 128;
-    for (int pidx = 0; pidx < parts; ++pidx) {
-        const int rc = conv1x1_pointwise(x, M, C, wp + (size_t)pidx * PART * C, nullptr, nullptr, 0,
-                                         z + (size_t)pidx * M * PART, PART, s);
-        if (rc) return rc;
-    }
     UpcParams p;
-    p.z = z; p.bias = bias; p.y = y;
+    p.bias = bias;
     p.part_stride = (size_t)M * PART;
-    p.B = B; p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N; p.relu = relu;
+    p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N; p.relu = relu;
     p.hscale = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
     p.wscale = (align_corners && OW > 1) ? (float)(w - 1) / (float)(OW - 1) : (float)w / (float)OW;
     int threads = 0;
@@ -322,17 +323,41 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
         return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_upsampled: no gather geometry for a %dx%d -> %dx%d map", h, w, OH, OW);
     p.capdiv = make_fastdiv(p.cap);
     const size_t lds = (size_t)p.cap * w * 288;
-    const dim3 grid((unsigned)(8 * ceil_div(B, 8) * (N / 8)));
-    if (out_c8) {
-        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(threads), lds, s, p);
-    } else {
-        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(threads), lds, s, p);
+    // Images in chunks: GEMM of a chunk, then its gather -- with the chunk's z (images x h w x 9 N floats) no larger than
+    // the Infinity Cache holds next to the other operands, the gather finds most of what the GEMM just wrote still on
+    // the die instead of in HBM (g_upconv_chunk_mb; 0 = the whole batch at once)
+    const int chunk_mb = g_upconv_chunk_mb.load();
+    int bc = B;
+    if (chunk_mb > 0) {
+        const double per_image = (double)h * w * 9.0 * N * 4.0;
+        bc = (int)((double)chunk_mb * 1048576.0 / per_image);
+        bc = bc < 8 ? 8 : bc / 8 * 8;
+        const int nch = ceil_div(B, bc);
+        bc = ceil_div(ceil_div(B, nch), 8) * 8;  // even chunks, whole groups of 8 images (one per XCD)
     }
-    MPSR_CHECK_LAUNCH("upconv_gather_kernel");
+    for (int b0 = 0; b0 < B; b0 += bc) {
+        const int nb = B - b0 < bc ? B - b0 : bc;
+        const size_t pix0 = (size_t)b0 * h * w;
+        for (int pidx = 0; pidx < parts; ++pidx) {
+            const int rc = conv1x1_pointwise(x + pix0 * C, (long long)nb * h * w, C, wp + (size_t)pidx * PART * C, nullptr,
+                                             nullptr, 0, z + (size_t)pidx * M * PART + pix0 * PART, PART, s);
+            if (rc) return rc;
+        }
+        p.z = z + pix0 * PART;
+        p.y = y + (size_t)b0 * OH * OW * N;
+        p.B = nb;
+        const dim3 grid((unsigned)(8 * ceil_div(nb, 8) * (N / 8)));
+        if (out_c8) {
+            MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(threads), lds, s, p);
+        } else {
+            MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(threads), lds, s, p);
+        }
+        MPSR_CHECK_LAUNCH("upconv_gather_kernel");
+    }
     return MPSR_OK;
 }
 
