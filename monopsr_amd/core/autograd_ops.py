@@ -63,49 +63,113 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = ctx.layer
         x, y = ctx.saved_tensors
-        g = dy.contiguous()
-        lib = _lib.lib()
-        B, H, W, C = x.shape
-        N = L.cout
-        s = _lib.stream()
-        bn = L.batch_norm is not None
-        if L.relu and not bn:
-            # ReLU mask in one streaming pass; the bias gradient rides in the weight-gradient kernel below
-            gm = torch.empty_like(g)
-            _lib.check(lib.mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), None, B * H * W, N, s))
-            g = gm
-        # the kernels read rows of N floats with 16-byte loads: pad a narrow output (the 3-channel xyz head) to 4
-        pad = (-N) % 4
-        g4 = F.pad(g, (0, pad)) if pad else g
-        N4 = N + pad
-        db4 = None if bn else L.db  # with BatchNorm, db is the beta gradient and BatchNormReluFn deposits it
-        if pad:
-            dw4 = torch.zeros((N4, L.w.shape[1]), dtype=torch.float32, device=x.device)
-            w4 = F.pad(L.w, (0, 0, 0, pad))
-            if db4 is not None:
-                db4 = torch.zeros((N4,), dtype=torch.float32, device=x.device)
-        else:
-            dw4, w4 = L.dw, L.w
-        # scratch for the layers that take the Winograd-domain weight gradient (the decoder's dense 3x3 layers), kept per
-        # (device, stream) like the forward scheduler's: launches on one stream are ordered
-        nws = lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N4, L.kh, L.kw, L.dilation)
-        ws = dn.stream_scratch(_WGRAD_SCRATCH, x.device, nws) if nws else None
-        _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
-                                                _lib.ptr(dw4), _lib.ptr(db4), _lib.ptr(ws),
-                                                ws.numel() if ws is not None else 0, s))
-        if pad and db4 is not None:
-            L.db.add_(db4[:N])
-        if pad:
-            L.dw.add_(dw4[:N])
-        ready = getattr(L, "on_grad_ready", None)
-        if ready is not None:
-            ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=x.device)
-            _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd), s))
-            dx = dn.conv2d(g4, wd, None, None, L.kh, L.kw, L.dilation, False, split_k=_SCHED)
+        g = _masked_grad(L, dy, y)
+        _deposit_weight_grad(L, x, g)
+        dx = _data_grad(L, g, x.shape[3]) if ctx.needs_input_grad[0] else None
         return dx, (g if ctx.has_res else None), None, None
+
+
+def _masked_grad(L, dy, y):
+    """dy through the layer's own ReLU (one streaming pass; the bias gradient rides in the weight-gradient kernel)."""
+    g = dy.contiguous()
+    if L.relu and L.batch_norm is None:
+        gm = torch.empty_like(g)
+        _lib.check(_lib.lib().mpsr_act_bias_grad(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), None, g.numel() // L.cout,
+                                                 L.cout, _lib.stream()))
+        g = gm
+    return g
+
+
+def _pad4(L, g):
+    """The kernels read rows of N floats with 16-byte loads: a narrow output (the 3-channel xyz head) is padded to 4."""
+    pad = (-L.cout) % 4
+    return (F.pad(g, (0, pad)) if pad else g), pad
+
+
+def _deposit_weight_grad(L, x, g):
+    """dW (and db) of one layer from its input x and the gradient g at its pre-activation output, accumulated into the
+    layer's slices of the flat gradient buffer; then the layer's `on_grad_ready` hook (the data-parallel reducer)."""
+    lib = _lib.lib()
+    s = _lib.stream()
+    B, H, W, C = x.shape
+    N = L.cout
+    bn = L.batch_norm is not None
+    g4, pad = _pad4(L, g)
+    N4 = N + pad
+    db4 = None if bn else L.db  # with BatchNorm, db is the beta gradient and BatchNormReluFn deposits it
+    if pad:
+        dw4 = torch.zeros((N4, L.w.shape[1]), dtype=torch.float32, device=x.device)
+        if db4 is not None:
+            db4 = torch.zeros((N4,), dtype=torch.float32, device=x.device)
+    else:
+        dw4 = L.dw
+    # scratch for the layers that take the Winograd-domain weight gradient (the decoder's dense 3x3 layers), kept per
+    # (device, stream) like the forward scheduler's: launches on one stream are ordered
+    nws = lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N4, L.kh, L.kw, L.dilation)
+    ws = dn.stream_scratch(_WGRAD_SCRATCH, x.device, nws) if nws else None
+    _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(_lib.ptr(x), _lib.ptr(g4), B, H, W, C, N4, L.kh, L.kw, L.dilation,
+                                            _lib.ptr(dw4), _lib.ptr(db4), _lib.ptr(ws),
+                                            ws.numel() if ws is not None else 0, s))
+    if pad and db4 is not None:
+        L.db.add_(db4[:N])
+    if pad:
+        L.dw.add_(dw4[:N])
+    ready = getattr(L, "on_grad_ready", None)
+    if ready is not None:
+        ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete
+
+
+def _data_grad(L, g, C, residual=None):
+    """dX of one layer = the forward convolution of g with the taps flipped and the channel roles swapped
+    (mpsr_conv2d_dgrad_pack); `residual` (same shape as dX) is added in that convolution's epilogue -- the gradient of
+    another branch that read the same tensor, for free instead of by an elementwise launch."""
+    g4, pad = _pad4(L, g)
+    N4 = L.cout + pad
+    w4 = F.pad(L.w, (0, 0, 0, pad)) if pad else L.w
+    wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.lib().mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd),
+                                                 _lib.stream()))
+    return dn.conv2d(g4, wd, None, residual, L.kh, L.kw, L.dilation, False, split_k=_SCHED)
+
+
+class BottleneckFn(torch.autograd.Function):
+    """One ResNet-v1 bottleneck unit (object_detection/nets/resnet_v1.py:79-139) as ONE autograd node:
+    y = relu(conv3(conv2(conv1(x))) + shortcut(x)), shortcut = x or a 1x1 projection.  Layer by layer, autograd has to
+    SUM the two gradients that reach x (through conv1 and through the shortcut) with an elementwise launch per unit
+    (30 per trunk and step, 1.9 ms); here the shortcut branch's gradient is the `residual` operand of conv1's
+    data-gradient convolution and is added in its epilogue.  Same kernels otherwise, gradients deposited in the same
+    order (conv3, conv2, conv1, projection)."""
+
+    @staticmethod
+    def forward(ctx, x, c1, c2, c3, sc, token):
+        x = x.contiguous()
+        res = dn.conv2d(x, sc.w, sc.b, None, sc.kh, sc.kw, sc.dilation, sc.relu, split_k=_SCHED) if sc is not None else x
+        t1 = dn.conv2d(x, c1.w, c1.b, None, c1.kh, c1.kw, c1.dilation, c1.relu, split_k=_SCHED)
+        t2 = dn.conv2d(t1, c2.w, c2.b, None, c2.kh, c2.kw, c2.dilation, c2.relu, split_k=_SCHED)
+        y = dn.conv2d(t2, c3.w, c3.b, res, c3.kh, c3.kw, c3.dilation, c3.relu, split_k=_SCHED)
+        ctx.layers = (c1, c2, c3, sc)
+        ctx.save_for_backward(x, t1, t2, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, c2, c3, sc = ctx.layers
+        x, t1, t2, y = ctx.saved_tensors
+        g3 = _masked_grad(c3, dy, y)  # also the gradient that enters the shortcut branch
+        _deposit_weight_grad(c3, t2, g3)
+        g2 = _masked_grad(c2, _data_grad(c3, g3, t2.shape[3]), t2)
+        _deposit_weight_grad(c2, t1, g2)
+        g1 = _masked_grad(c1, _data_grad(c2, g2, t1.shape[3]), t1)
+        _deposit_weight_grad(c1, x, g1)
+        dx = None
+        if sc is not None:
+            gs = _masked_grad(sc, g3, None)  # (a projection shortcut has no activation)
+            _deposit_weight_grad(sc, x, gs)
+            if ctx.needs_input_grad[0]:
+                dx = _data_grad(c1, g1, x.shape[3], residual=_data_grad(sc, gs, x.shape[3]))
+        elif ctx.needs_input_grad[0]:
+            dx = _data_grad(c1, g1, x.shape[3], residual=g3)
+        return dx, None, None, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -234,6 +298,14 @@ def conv2d(x, layer, residual=None):
     if layer.batch_norm is not None:
         y = BatchNormReluFn.apply(y, layer, _token(x.device))
     return y
+
+
+def bottleneck(x, c1, c2, c3, shortcut=None):
+    """One bottleneck unit of frozen-BatchNorm (folded) layers as a single autograd node (BottleneckFn)."""
+    for L in (c1, c2, c3, shortcut):
+        if L is not None and L.batch_norm is not None:
+            raise _lib.InvalidArgumentError("bottleneck(): the trunk's layers are trained in BatchNorm-folded form")
+    return BottleneckFn.apply(x, c1, c2, c3, shortcut, _token(x.device))
 
 
 def max_pool(x, k, s, padding):

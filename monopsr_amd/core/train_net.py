@@ -104,6 +104,8 @@ class TrainNet:
                                                   t(weights[name + "/BatchNorm/moving_variance"]), W.DECODER_BN_EPS)
 
     # ------------------------------------------------------------------ forward pieces
+    fused_units = True  # trunk(): bottleneck units as single autograd nodes (ops.BottleneckFn); False = layer by layer
+
     def trunk(self, img, scope='crop'):
         if scope == 'crop':
             L = self.layers
@@ -119,13 +121,17 @@ class TrainNet:
         li = 1
         for blk, units in enumerate((3, 4, 23)):
             for u in range(units):
-                residual = x
+                shortcut = None
                 if u == 0:
-                    residual = ops.conv2d(x, L[li])
+                    shortcut = L[li]
                     li += 1
-                t = ops.conv2d(x, L[li])
-                t = ops.conv2d(t, L[li + 1])
-                x = ops.conv2d(t, L[li + 2], residual=residual)
+                if self.fused_units:  # one autograd node per unit: the two gradients of its input meet in a conv epilogue
+                    x = ops.bottleneck(x, L[li], L[li + 1], L[li + 2], shortcut)
+                else:
+                    residual = ops.conv2d(x, shortcut) if shortcut is not None else x
+                    t = ops.conv2d(x, L[li])
+                    t = ops.conv2d(t, L[li + 1])
+                    x = ops.conv2d(t, L[li + 2], residual=residual)
                 li += 3
         return x
 

@@ -280,6 +280,36 @@ def test_network_training_gradients_end_to_end():
     assert float((net.params - before).abs().max()) > 0
 
 
+def test_bottleneck_units_as_one_autograd_node_give_the_same_gradients():
+    """TrainNet.trunk runs every bottleneck unit as ONE autograd node (autograd_ops.BottleneckFn: the two gradients of
+    the unit's input meet in the epilogue of conv1's data-gradient convolution instead of in an elementwise launch).
+    Same kernels, and a + b == b + a: every parameter gradient must equal the layer-by-layer graph's.  (wgrad slices
+    meet in fp32 atomics whose order is free, so "equal" is 1e-5 of each layer's scale; the forward is bit-identical.)"""
+    from monopsr_amd.core import train_net
+    from monopsr_amd.core import weights as W
+    B, div = 3, 4
+    weights = W.synthetic_weights(seed=71, width_div=div, heads=False)
+    net = train_net.TrainNet(weights, width_div=div, with_heads=False)
+    rng = np.random.default_rng(72)
+    crops = _dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32))
+    out = {}
+    for fused in (True, False):
+        net.fused_units = fused
+        net.zero_grad()
+        feat = net.trunk(crops)
+        (feat * feat).sum().backward()
+        torch.cuda.synchronize()
+        out[fused] = (feat.detach().clone(), net.grads.clone())
+    net.fused_units = True
+    assert torch.equal(out[True][0], out[False][0])
+    g1, g0 = out[True][1], out[False][1]
+    assert float(g0.abs().max()) > 0
+    for n, L in enumerate(net.layers[:net.n_trunk]):  # L.dw is a view into net.grads: compare the same slice of both
+        lo = (L.dw.data_ptr() - net.grads.data_ptr()) // 4
+        a, b_ = g1[lo:lo + L.dw.numel()], g0[lo:lo + L.dw.numel()]
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max() + 1e-30), n
+
+
 def test_instance_trainer_step_reduces_loss():
     """Full training step on a 1/4-width copy: heads included (method-by-method output builder over differentiable
     FC layers), the reference's configured loss set (monopsr_model.py:554-958), per-variable clip, Adam; the loss
