@@ -37,6 +37,7 @@
 //   * Scratch: (n+m) * (1 + levels) state words per cloud.  With only the reference shell's (n+m)*2 floats
 //     (tf_approxmatch.cpp:168) the DEVICE path still works: ratios of one level at a time, match accumulated level by
 //     level (the reference's own traffic pattern; bit-identical result, ~2x slower).
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -142,7 +143,7 @@ struct State {
 template <bool HOST, int MODE>
 __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2, void *temp, int lev,
-                                                            int slots, size_t cstride)
+                                                            int slots, size_t cstride, int skip)
 {
     using S = typename Sem<HOST>::S;
     constexpr bool kDo3 = MODE != 0, kDo1 = MODE != 2;
@@ -193,15 +194,63 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
         a3[v] = f32x2{0.f, 0.f};
     }
 
+    // DEVICE: receivers whose capacity is used up carry weight 0 in BOTH sweeps (remR == 0 and, one level behind, ratR
+    // == 0) -- exactly, because sweep 2 clamps with max(0, .) -- and a term e * 0 adds +0 to a non-negative sum: leaving
+    // those receivers out of the staged tile, in order, gives the same bits.  On uniform clouds 42 / 66 / 79 / 88 / 93 /
+    // 97 / 99 % of the receivers are gone in the passes of level 3 .. -1, zero and the final sweep 3
+    // (profiles/r04_emd_zero_capacity.txt).
+    __shared__ int kept_cnt[kTile / kThreads][kThreads / 64];
     for (int o0 = 0; o0 < m; o0 += kTile) {
-        const int cnt = min(kTile, m - o0);
+        int cnt = min(kTile, m - o0);
         __syncthreads();
-        for (int q = tid; q < cnt; q += kThreads) {
-            const float *s = p2 + (size_t)(o0 + q) * 3;
-            const S w3 = kDo3 ? ratR_prev[o0 + q] : (S)0;
-            tile[q] = make_float4(s[0], s[1], s[2], HOST ? 0.f : (float)w3);
-            if (HOST) w3s[q] = w3;
-            if (kDo1) w1s[q] = first ? multiR : st.remR[o0 + q];
+        if constexpr (HOST) {
+            for (int q = tid; q < cnt; q += kThreads) {
+                const float *s = p2 + (size_t)(o0 + q) * 3;
+                const S w3 = kDo3 ? ratR_prev[o0 + q] : (S)0;
+                tile[q] = make_float4(s[0], s[1], s[2], 0.f);
+                w3s[q] = w3;
+                if (kDo1) w1s[q] = first ? multiR : st.remR[o0 + q];
+            }
+        } else {
+            constexpr int R = kTile / kThreads;
+            const int lane = tid & 63, wave = tid >> 6;
+            float4 ent[R];
+            float w1v[R];
+            int rank[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int q = r * kThreads + tid;
+                const bool valid = q < cnt;
+                const float *s = p2 + (size_t)(o0 + (valid ? q : 0)) * 3;
+                const float w3 = (kDo3 && valid) ? (float)ratR_prev[o0 + q] : 0.f;
+                w1v[r] = (kDo1 && valid) ? (first ? (float)multiR : (float)st.remR[o0 + q]) : 0.f;
+                ent[r] = make_float4(s[0], s[1], s[2], w3);
+                const bool keep = valid && (!skip || w3 != 0.f || w1v[r] != 0.f);
+                const unsigned long long mask = __ballot(keep);
+                rank[r] = keep ? __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+                if (lane == 0) kept_cnt[r][wave] = __popcll(mask);
+            }
+            __syncthreads();
+            int total = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int w = 0; w < kThreads / 64; ++w) {
+                    const int c = kept_cnt[r][w];
+                    // entries of (round r, wave w) come before this thread's round-r entry iff w < wave; before its
+                    // round-r' entries for r' > r always
+#pragma unroll
+                    for (int r2 = 0; r2 < R; ++r2)
+                        if (rank[r2] >= 0 && (r < r2 || (r == r2 && w < wave))) rank[r2] += c;
+                    total += c;
+                }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rank[r] >= 0) {
+                    tile[rank[r]] = ent[r];
+                    if (kDo1) w1s[rank[r]] = w1v[r];
+                }
+            cnt = total;  // block-uniform
         }
         __syncthreads();
         if constexpr (HOST) {
@@ -280,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
 template <bool HOST>
 __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                                const float *__restrict__ xyz2, void *temp, int lev,
-                                                               int slots, size_t cstride)
+                                                               int slots, size_t cstride, int skip)
 {
     using S = typename Sem<HOST>::S;
     __shared__ float4 tile[kTile];
@@ -298,11 +347,88 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
     const float c = lv * kLog2e;
 
     const int base = blockIdx.x * (kThreads * kPT);
+    // DEVICE, after the first level: a receiver whose capacity is used up (remR == 0 exactly: sweep 2 clamps with
+    // max(0, .)) gets ratR = min(0 / 1e-9, 1) * 0 = 0 and keeps remR = 0 whatever its sum t is -- its 2 x n pair
+    // evaluations are skipped.  remR itself is rewritten by this very launch (another workgroup may already have
+    // finished), so "used up" is read from the PREVIOUS level's ratio, which no workgroup of this launch writes:
+    // ratR_prev == 0  <=>  remR was 0 before the previous level (one level late, never wrong).  The live receivers of
+    // the cloud are compacted (in order) over the workgroups: this one takes live receivers number base .. base + 511;
+    // workgroups past the live count only write the zeros of their original chunk.  Same sums in the same order for
+    // every live receiver: the same bits.  On uniform clouds 92 / 58 / 34 / 21 / 12 / 7.5 / 3 % of the receivers are
+    // live by that test at level 4 .. -1 and the zero level.  (Needs the per-level ratio slots: not in the compact
+    // scratch form, where the previous level's ratios are being overwritten.)
+    // skip >= 2 (default) also SPLITS the giver loop when few receivers are live: a wave runs at a quarter of the SIMD's
+    // rate when it is alone on it (one pass takes 217 us with one workgroup per cloud and 229 us with four), so with
+    // the live receivers in NBW blocks of 128 (= one wave: two points per lane) and W waves per cloud, S = 4 or 2 waves
+    // (of one workgroup) share a block, each summing a quarter / half of the givers; the block's first wave adds the
+    // partial sums in wave order.  Deterministic; differs from the unsplit sum in rounding only (the one place where
+    // skipping is not bit-identical: tests hold it to 2e-5 of the evaluate-everything result).
+    __shared__ int own_idx[kThreads * kPT];
+    __shared__ int live_cnt[kThreads / 64];
+    __shared__ f32x2 part[kThreads / 64][64];
+    static_assert(kPT == 2, "the compacted receiver pass maps one 128-receiver block to a wave");
+    int oi[kPT];  // index of own point u, or -1
+    int nsplit = 1, seg = 0;       // waves sharing this wave's block of receivers, and this wave's part of the givers
+    bool wave_active = true;
+    if (HOST || first || slots <= 1 || !skip) {
+#pragma unroll
+        for (int u = 0; u < kPT; ++u) {
+            const int i = base + u * kThreads + tid;
+            oi[u] = i < m ? i : -1;
+        }
+    } else {
+        const int lane = tid & 63, wave = tid >> 6;
+        const S *ratR_prev = st.ratR + (size_t)(lev - 1) * m;
+        // two scans of the cloud's receivers (m / 256 rounds of a ballot each): the live count, which decides the
+        // split, then the indices of the live receivers this workgroup's waves own
+        int rank_lo = 0, rank_hi = 0, run = 0;
+        for (int phase = 0; phase < 2; ++phase) {
+            run = 0;  // live receivers before this round (block-uniform)
+            for (int r0 = 0; r0 < m; r0 += kThreads) {
+                const int i = r0 + tid;
+                const bool live = i < m && (float)ratR_prev[i] != 0.f;
+                // the dead receivers of this workgroup's ORIGINAL chunk get their (zero) ratio here
+                if (phase == 0 && i < m && !live && i >= base && i < base + kThreads * kPT) ratR_cur[i] = 0;
+                const unsigned long long mask = __ballot(live);
+                if (lane == 0) live_cnt[wave] = __popcll(mask);
+                __syncthreads();
+                int before = run, total = 0;
+#pragma unroll
+                for (int w = 0; w < kThreads / 64; ++w) {
+                    const int c = live_cnt[w];
+                    if (w < wave) before += c;
+                    total += c;
+                }
+                const int rank = before + __popcll(mask & ((1ull << lane) - 1ull));
+                if (phase == 1 && live && rank >= rank_lo && rank < rank_hi) own_idx[rank - rank_lo] = i;
+                run += total;
+                __syncthreads();
+            }
+            if (phase == 0) {
+                const int nbw = (run + 127) >> 7, waves = (int)gridDim.x * (kThreads / 64);
+                nsplit = skip >= 2 ? (nbw * 4 <= waves ? 4 : (nbw * 2 <= waves ? 2 : 1)) : 1;
+                const int blk_lo = (int)blockIdx.x * (kThreads / 64) / nsplit;  // first receiver block of this workgroup
+                if (blk_lo >= nbw) return;  // block-uniform: no live receiver left for this workgroup
+                rank_lo = blk_lo << 7;
+                rank_hi = rank_lo + ((kThreads / 64) / nsplit << 7);
+            }
+        }
+        const int v = (int)blockIdx.x * (kThreads / 64) + wave;
+        const int blk = v / nsplit;
+        seg = v - blk * nsplit;
+        const int r0 = blk << 7;
+        wave_active = r0 < run;
+#pragma unroll
+        for (int u = 0; u < kPT; ++u) {
+            const int rank = r0 + u * 64 + lane;
+            oi[u] = rank < run ? own_idx[rank - rank_lo] : -1;
+        }
+    }
     float ox[kPT], oy[kPT], oz[kPT];
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kThreads + tid;
-        const bool live = i < m;
+        const bool live = oi[u] >= 0;
+        const int i = live ? oi[u] : 0;
         ox[u] = live ? p2[3 * i] : 0.f;
         oy[u] = live ? p2[3 * i + 1] : 0.f;
         oz[u] = live ? p2[3 * i + 2] : 0.f;
@@ -337,8 +463,9 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
                     t_[u] += (double)host_exp((double)lv, sqdist_d(t.x, t.y, t.z, ox[u], oy[u], oz[u])) * w;
             }
         } else {
+            const int o_begin = wave_active ? cnt * seg / nsplit : 0, o_end = wave_active ? cnt * (seg + 1) / nsplit : 0;
 #pragma unroll 4
-            for (int o = 0; o < cnt; ++o) {
+            for (int o = o_begin; o < o_end; ++o) {
                 const float4 t = tile[o];
 #pragma unroll
                 for (int v = 0; v < kPV; ++v) {
@@ -353,13 +480,20 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
         }
     }
     if constexpr (!HOST) {
+        if (nsplit > 1) {  // block-uniform: the block's first wave adds the partial sums in wave order
+            const int lane = tid & 63, wave = tid >> 6;
+            part[wave][lane] = acc[0];
+            __syncthreads();
+            if (seg != 0) return;
+            for (int w = 1; w < nsplit; ++w) acc[0] += part[wave + w][lane];
+        }
 #pragma unroll
         for (int u = 0; u < kPT; ++u) t_[u] = acc[u / 2][u % 2];
     }
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kThreads + tid;
-        if (i >= m) continue;
+        const int i = oi[u];
+        if (i < 0) continue;
         const S rem = first ? multiR : st.remR[i];
         if constexpr (HOST) {
             const double colsum = 1e-9 + rem * t_[u];
@@ -832,6 +966,11 @@ __global__ __launch_bounds__(256) void match_cost_grad2_kernel(int n, int m, con
     }
 }
 
+// 0: every pair is evaluated, as in round 3; 1: the passes leave receivers with no capacity left out of their loops
+// (bit-identical results); 2 (default): and the receiver pass splits its giver loop over the waves when few receivers
+// are live (same terms, another summation order).  Tests compare the three.
+std::atomic<int> g_emd_skip{2};
+
 int check_emd_args(const char *op, int b, int n, int m)
 {
     MPSR_REQUIRE(b >= 0 && n >= 0 && m >= 0, "%s: negative size (b=%d n=%d m=%d)", op, b, n, m);
@@ -854,14 +993,16 @@ int run_passes(int b, int n, int m, const float *xyz1, const float *xyz2, void *
 {
     constexpr int L = Sem<HOST>::levels;
     const dim3 gl(mpsr::ceil_div(n, kThreads * kPT), b), gr(mpsr::ceil_div(m, kThreads * kPT), b);
-    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots, cstride);
+    const int skip = g_emd_skip.load();  // 1: leave exhausted receivers out (exact), 2: and split short receiver passes
+    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots, cstride,
+                       skip);
     for (int lev = 0; lev < L; ++lev) {
         hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots,
-                           cstride);
+                           cstride, skip);
         if (int rc = between(lev)) return rc;
         if (lev + 1 < L)
             hipLaunchKernelGGL((emd_giver_kernel<HOST, 1>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev + 1,
-                               slots, cstride);
+                               slots, cstride, skip);
         // the giver capacity after the last level is never read: no trailing sweep 3
     }
     MPSR_CHECK_LAUNCH("emd passes");
@@ -1027,3 +1168,5 @@ extern "C" int mpsr_match_cost_grad(int b, int n, int m, const float *xyz1, cons
     MPSR_CHECK_LAUNCH("match_cost_grad2_kernel");
     return MPSR_OK;
 }
+
+extern "C" void mpsr_debug_set_emd_skip(int on) { g_emd_skip = on; }

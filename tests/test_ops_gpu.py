@@ -259,9 +259,18 @@ def test_emd_compact_scratch_is_bit_identical(b, n, m):
     rng = np.random.default_rng(n + m)
     a = _dev(rng.uniform(-1, 1, (b, n, 3)).astype(np.float32))
     b_ = _dev(rng.uniform(-1, 1, (b, m, 3)).astype(np.float32))
-    full = am.approx_match(a, b_)
-    compact = am.approx_match(a, b_, temp_floats=b * (n + m) * 2)
+    # the level-by-level fallback keeps no per-level ratios, so its receiver passes cannot split their giver loops the
+    # way the default mode does (csrc/approxmatch.hip, g_emd_skip): bit for bit without that split, 2e-5 with it
+    lib = _lib.lib()
+    lib.mpsr_debug_set_emd_skip(1)
+    try:
+        full = am.approx_match(a, b_)
+        compact = am.approx_match(a, b_, temp_floats=b * (n + m) * 2)
+    finally:
+        lib.mpsr_debug_set_emd_skip(2)
     assert torch.equal(full, compact)
+    torch.testing.assert_close(am.approx_match(a, b_, temp_floats=b * (n + m) * 2), am.approx_match(a, b_), rtol=0,
+                               atol=2e-5 * float(full.abs().max()))
     with pytest.raises(_lib.MpsrError, match="needs"):
         am.approx_match(a, b_, temp_floats=b * (n + m) * 2 - 1)
 
@@ -292,6 +301,40 @@ def test_emd_fused_loss_equals_the_three_ops(b, n, m):
     (am.emd_cost(t1, t2) * w).sum().backward()
     torch.testing.assert_close(t1.grad, g1 * w.reshape(-1, 1, 1))
     torch.testing.assert_close(t2.grad, g2 * w.reshape(-1, 1, 1))
+
+
+@pytest.mark.parametrize("b,n,m,spread", [(3, 1024, 1024, 1.0), (2, 2048, 2048, 1.0), (2, 1500, 700, 1.0),
+                                          (2, 700, 1500, 1.0), (2, 1024, 1024, 0.05), (4, 300, 300, 3.0)])
+def test_emd_exhausted_receivers_are_skipped_exactly(b, n, m, spread):
+    """The passes leave receivers without capacity out of their loops (giver pass: receivers whose weight is zero in both
+    sweeps are not staged; receiver pass: receivers whose previous ratio is zero are not evaluated).  A skipped term is
+    e * 0 = +0 and a skipped receiver's outputs are 0 whatever its sum: match, cost and both gradients must equal the
+    evaluate-everything form (mpsr_debug_set_emd_skip(0), the round-3 kernels) BIT FOR BIT (mode 1) -- on uniform clouds
+    (where most receivers are exhausted by the middle levels), ragged sizes both ways, a tight cluster (nothing ever
+    skipped) and a wide one.  The default (mode 2) additionally splits short receiver passes over waves: 2e-5."""
+    from monopsr_amd import _lib
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    rng = np.random.default_rng(n + 3 * m)
+    a = _dev((rng.uniform(-1, 1, (b, n, 3)) * spread).astype(np.float32))
+    c = _dev((rng.uniform(-1, 1, (b, m, 3)) * spread).astype(np.float32))
+    lib = _lib.lib()
+    out = {}
+    for on in (2, 1, 0):
+        lib.mpsr_debug_set_emd_skip(on)
+        try:
+            out[on] = (am.approx_match(a, c), ) + tuple(am.emd_loss_fwd_bwd(a, c))
+            # (the cost is a sum of per-workgroup partial sums met in an fp32 atomic: its last bit is free)
+            again = (am.approx_match(a, c), ) + tuple(am.emd_loss_fwd_bwd(a, c))
+            assert all(torch.equal(out[on][k], again[k]) for k in (0, 2, 3)), "not deterministic"
+        finally:
+            lib.mpsr_debug_set_emd_skip(2)
+    for k in (0, 2, 3):
+        assert torch.equal(out[1][k], out[0][k])
+    torch.testing.assert_close(out[1][1], out[0][1], rtol=1e-6, atol=0)
+    # the default also splits the short receiver passes over waves: the same terms in another summation order
+    for x, y in zip(out[2], out[0]):
+        torch.testing.assert_close(x, y, rtol=0, atol=2e-5 * float(y.abs().max()))
+    assert float(out[1][1].abs().min()) > 0
 
 
 def test_emd_cfg5_per_gpu_share_full_size():

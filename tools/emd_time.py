@@ -1,14 +1,36 @@
-import sys, os, torch
+"""Interleaved timing rounds of the EMD entry points (256 x 2048^2 = BASELINE cfg5's per-GPU share, and the model's
+own 32 x 2304^2), with the exhausted-receiver skipping of the passes on (default) and off (mpsr_debug_set_emd_skip(0):
+every pair evaluated, the round-3 kernels).  Same bits either way (tests/test_ops_gpu.py)."""
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.getcwd())
-from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+from monopsr_amd import _lib  # noqa: E402
+from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am  # noqa: E402
+
+
 def timeit(fn, reps):
-    fn(); torch.cuda.synchronize()
+    fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+lib = _lib.lib()
 for b, n in ((256, 2048), (32, 2304)):
     y1 = torch.rand((b, n, 3), device="cuda") * 2 - 1
     y2 = torch.rand((b, n, 3), device="cuda") * 2 - 1
-    print(b, n, "approx_match %.2f ms  fused %.2f  cost-only %.2f" % (timeit(lambda: am.approx_match(y1, y2), 5), timeit(lambda: am.emd_loss_fwd_bwd(y1, y2), 5), timeit(lambda: am.emd_loss_fwd_bwd(y1, y2, want_grads=False), 5)))
+    for rnd in range(1):
+        for skip in (0, 1, 2):
+            lib.mpsr_debug_set_emd_skip(skip)
+            print("%d x %d^2 skip=%d (round %d): approx_match %.2f ms  fused loss %.2f  cost only %.2f" % (
+                b, n, skip, rnd, timeit(lambda: am.approx_match(y1, y2), 5), timeit(lambda: am.emd_loss_fwd_bwd(y1, y2), 5),
+                timeit(lambda: am.emd_loss_fwd_bwd(y1, y2, want_grads=False), 5)))
+lib.mpsr_debug_set_emd_skip(2)
