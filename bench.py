@@ -741,8 +741,37 @@ class Emitter:
     def arm(self, result):
         self.result = result
         self.timer.start()
+        if self.rank == 0:
+            # the launcher stops every rank with SIGTERM when another rank dies (GPU fault, OOM kill) during the extras:
+            # the measured headline must still come out
+            import signal
+
+            def on_term(signum, frame):
+                sys.stderr.write("bench.py: rank 0 received signal %d after the headline was measured; emitting it "
+                                 "without the unfinished extras\n" % signum)
+                self._flush(reason="terminated_by_signal_%d" % signum)
+                os._exit(0)
+            try:
+                signal.signal(signal.SIGTERM, on_term)
+            except ValueError:  # not the main thread
+                pass
+
+    def _flush(self, reason):
+        with self.lock:
+            if self.done or self.result is None:
+                return
+            keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config")
+            try:
+                line = json.dumps(dict(self.result, extras_incomplete=reason))
+            except (RuntimeError, TypeError, ValueError):
+                line = json.dumps(dict({k: self.result[k] for k in keys if k in self.result}, extras_incomplete=reason))
+            print(line, flush=True)
+            self.done = True
 
     def _expired(self):
+        sys.stderr.write("bench.py: rank %d: the extra measurements did not finish within %.0f s; %s\n" %
+                         (self.rank, self.deadline_s, "printing the headline without them" if self.rank == 0 else "exiting"))
         with self.lock:
             if not self.done and self.rank == 0 and self.result is not None:
                 line = None

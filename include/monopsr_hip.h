@@ -228,7 +228,10 @@ int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, 
  * not use any) lets the big dense 3x3 layers (the map decoder: stride 1, no dilation, H and W multiples of 4, C and N
  * multiples of 32, B*H*W >= 65536) run in the Winograd F(4x4,3x3) domain -- 36 products per channel pair and 4x4
  * block where the direct weight gradient has 144; results agree with mpsr_conv2d_wgrad_f32 to ~1e-4 of the
- * gradient's scale.  ws = NULL or too small: exactly mpsr_conv2d_wgrad_f32. */
+ * gradient's scale.  ws = NULL or too small: exactly mpsr_conv2d_wgrad_f32.
+ * Run-to-run reproducibility: BOTH forms combine the partial sums of their pixel / tile slices with fp32 atomics, so a
+ * weight gradient's last bits depend on the order in which workgroups arrive (relative spread ~1e-7 direct, ~1e-6 in
+ * the Winograd domain, where the transformed sums are larger); forward results and data gradients are deterministic. */
 size_t mpsr_conv2d_wgrad_scratch_floats(int B, int H, int W, int C, int N, int KH, int KW, int dilation);
 int mpsr_conv2d_wgrad_ws_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
                              int dilation, float *dw, float *db, float *ws, size_t ws_floats, mpsr_stream_t stream);

@@ -560,12 +560,17 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
     p.cblocks = ceil_div(N, COLS);
     p.ntiles = ceil_div(p.rgroups, 8) * 8 * p.cblocks;
     p.wbytes = (unsigned)((long long)N * K * 4);
-    static int cus = 0;
+    // CU count of the CURRENT device, cached per device id (a process may drive several GPUs; the count only sizes
+    // the persistent grid)
+    static std::atomic<int> cu_count[64];
+    int dev = 0;
+    MPSR_CHECK_HIP(hipGetDevice(&dev));
+    int cus = dev >= 0 && dev < 64 ? cu_count[dev].load() : 0;
     if (cus == 0) {
-        int dev = 0, n = 256;
-        MPSR_CHECK_HIP(hipGetDevice(&dev));
+        int n = 256;
         MPSR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = n;
+        cus = n > 0 ? n : 256;
+        if (dev >= 0 && dev < 64) cu_count[dev] = cus;
     }
     // persistent grid: g_pws_per_cu workgroups per CU, rounded down to a multiple of 8 x column blocks
     const int unit = 8 * p.cblocks;

@@ -102,6 +102,30 @@ def test_a_hanging_extra_does_not_cost_the_headline():
     assert "rank_proof" not in lines[0]
 
 
+def test_a_rank_dying_during_the_extras_does_not_cost_the_headline():
+    #  a non-zero rank that dies while the extras run makes the launcher SIGTERM the others: rank 0, whose
+    # headline is already measured, prints it (marked) from its signal handler instead of dying silently
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MPSR_BENCH_RENDEZVOUS_ONLY="1", MPSR_BENCH_TEST_HANG_EXTRAS="1", MPSR_BENCH_TEST_DEADLINE="300",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    try:
+        time.sleep(12)  # rendezvous + headline, then the extras "hang"
+        assert p.poll() is None
+        p.send_signal(signal.SIGTERM)
+        out, err = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    lines = _json_lines(out)
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, out[-500:], err[-1000:])
+    assert lines[0]["extras_incomplete"] == "terminated_by_signal_15" and "emitting it" in err
+
+
 def test_sigterm_to_the_launcher_stops_the_ranks():
     import signal
     import time

@@ -791,8 +791,10 @@ def test_evaluate_predictions_metrics():
 
 
 def test_device_net_batch_chunking_is_bit_identical():
-    """Batches above DeviceNet.MAX_CHUNK run as several native calls; instances are independent and every output
-    element's K order is unchanged, so the result has the same bits."""
+    """Batches above DeviceNet.MAX_CHUNK run as several native calls; instances are independent, and as long as the
+    library picks the SAME kernel for every chunk each output element's K order is unchanged: the same bits.  (Kernel
+    choice depends on the chunk's size -- the pointwise kernel wants >= 512 tiles, F(3x3,3x3) >= 1024 sub-grids -- so a
+    short last chunk of a real batch can differ from its neighbours in the last bits; here every chunk is small.)"""
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
     weights = W.synthetic_weights(seed=71, width_div=4)
