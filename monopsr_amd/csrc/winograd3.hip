@@ -245,19 +245,24 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     __syncthreads();
 
     // ---- K loop, two steps per trip (roles as in winograd4.hip)
+#ifdef W3_NO_BARRIER  // (timing experiment only: wrong results)
+#define W3_SYNC() do { } while (0)
+#else
+#define W3_SYNC() __syncthreads()
+#endif
     if (DG == 0) {
         for (int s = 0; s < nsteps; s += 2) {
             kstep(s, IC3<0>{}, request(s + 2));
-            __syncthreads();
+            W3_SYNC();
             kstep(s + 1, IC3<1>{}, transform(IC3<0>{}));
-            __syncthreads();
+            W3_SYNC();
         }
     } else {
         for (int s = 0; s < nsteps; s += 2) {
             kstep(s, IC3<0>{}, transform(IC3<1>{}));
-            __syncthreads();
+            W3_SYNC();
             kstep(s + 1, IC3<1>{}, request(s + 3));
-            __syncthreads();
+            W3_SYNC();
         }
     }
     int tid2 = tid;
