@@ -449,15 +449,30 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
         }
         return MPSR_OK;
     }
-    if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
+    // NHWC chain (small batches, maps that do not divide into 4x4 blocks, MPSR_WINOGRAD_OFF, the bf16x3 mode): conv2d
+    // per layer; the two upsampled convolutions keep their tap GEMM + gather (NHWC output) where it applies
     auto cached = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y) {
         cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
         return run_layer(blob, Lr, x, B, H, W, nullptr, y, 0, sk, skn, s);
     };
-    if ((rc = cached(L[2], r1, hh, hw, a))) return rc;
+    auto upconv_nhwc = [&](const mpsr_layer &Lr, const float *x, int h, int w, int H, int W, float *y, float *z, size_t zn) {
+        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+        return mpsr::conv3x3_upsampled(x, B, h, w, Lr.cin, H, W, 1, blob + Lr.w_off,
+                                       Lr.b_off >= 0 ? blob + Lr.b_off : nullptr, Lr.relu, y, Lr.cout, 0, z, zn, sk, skn, s);
+    };
+    if (up1) {
+        if ((rc = upconv_nhwc(L[2], sq, fh, fw, hh, hw, a, r1, r1n))) return rc;
+    } else {
+        if ((rc = mpsr_resize_bilinear(sq, B, fh, fw, csq, hh, hw, 1, r1, stream))) return rc;
+        if ((rc = cached(L[2], r1, hh, hw, a))) return rc;
+    }
     if ((rc = cached(L[3], a, hh, hw, b))) return rc;
-    if ((rc = mpsr_resize_bilinear(b, B, hh, hw, c2, mh, mw, 1, r2, stream))) return rc;
-    if ((rc = cached(L[4], r2, mh, mw, c))) return rc;
+    if (up2) {
+        if ((rc = upconv_nhwc(L[4], b, hh, hw, mh, mw, c, r2, r2n))) return rc;
+    } else {
+        if ((rc = mpsr_resize_bilinear(b, B, hh, hw, c2, mh, mw, 1, r2, stream))) return rc;
+        if ((rc = cached(L[4], r2, mh, mw, c))) return rc;
+    }
     if ((rc = cached(L[5], c, mh, mw, fm))) return rc;
     if (xyz_map && (rc = run_layer(blob, L[6], fm, B, mh, mw, nullptr, xyz_map, 1, nullptr, 0, s))) return rc;
     return MPSR_OK;
