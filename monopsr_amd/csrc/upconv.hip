@@ -61,6 +61,7 @@ struct UpcParams {
 };
 
 constexpr int kPf = 8;  // float4 registers per thread that carry source pixels on their way into LDS
+std::atomic<int> g_upconv_band{0};  // mpsr_debug_set_upconv_band: output rows per band of the rolling window (0 = 8)
 
 // One workgroup per (8-channel block, image) walks the image in bands of RB output rows.  LDS is a ring of `cap` source
 // rows, [row % cap][column][tap][8 channels]; while a band is summed the source rows the NEXT band adds are already on
@@ -236,6 +237,7 @@ bool gather_geometry(int h, int w, int H, int W, float hscale, int *threads, int
     // and arithmetic phases); otherwise bands of 8 rows (or one pass) with the next band's rows prefetched
     int rb = rpp > 8 ? rpp : 8;
     if ((size_t)h * w * 288 <= kGatherLdsBytes * 3 / 5) rb = (H + rpp - 1) / rpp * rpp;
+    else if (g_upconv_band.load() > 0) rb = (g_upconv_band.load() + rpp - 1) / rpp * rpp;  // (tuning knob)
     // the kernel's own band arithmetic: the most rows a band reaches, the most a further band adds
     int rows = 0, add = 0, prev_hi = -1;
     for (int k = 0; k * rb < H; ++k) {
@@ -261,6 +263,7 @@ bool gather_geometry(int h, int w, int H, int W, float hscale, int *threads, int
 // images per GEMM + gather round, as MB of z (0 = the whole batch at once); see conv3x3_upsampled
 static std::atomic<int> g_upconv_chunk_mb{0};
 extern "C" void mpsr_debug_set_upconv_chunk_mb(int mb) { g_upconv_chunk_mb = mb > 0 ? mb : 0; }
+extern "C" void mpsr_debug_set_upconv_band(int rows) { g_upconv_band = rows > 0 ? rows : 0; }
 
 namespace mpsr {
 

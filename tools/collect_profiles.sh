@@ -9,14 +9,14 @@
 TAG=${1:-r02}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fast-mode --no-train-step > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err || echo "stats pass failed"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fast-mode --no-train-step --no-full-image > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err || echo "stats pass failed"
 cp $OUT/stats/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" \
   "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
   "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-roofline --no-fast-mode > $OUT/p$i.log 2>&1 || echo "pmc pass $i failed/timeout"
+  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-roofline --no-fast-mode > $OUT/p$i.log 2>&1 || echo "pmc pass $i failed/timeout"
 done
 python3 tools/pmc_summary.py $OUT/p*/pmc_counter_collection.csv > $OUT/${TAG}_pmc_summary.md
 python3 tools/pmc_reduce.py $TAG $COMMIT $OUT/p*/pmc_counter_collection.csv > $OUT/${TAG}_pmc_traffic.json
