@@ -371,7 +371,9 @@ typedef struct mpsr_layer {
  *    job per layer).  With a caller-owned buffer of mpsr_filter_cache_floats() floats they are written there by the
  *    first call (filter_cache_valid = 0) and only read by later calls that pass filter_cache_valid != 0 -- the caller
  *    vouches that blob / layers / B / shape are the ones the cache was filled for (inference: weights never change;
- *    a training loop passes 0 or no cache).  A cache that is too small is used for the layers that fit.
+ *    a training loop passes 0 or no cache).  A cache that is too small is used for the layers that fit.  Which form a
+ *    layer's filters take depends on the kernel the call picks (batch size, mpsr_set_conv_math,
+ *    mpsr_set_winograd_policy): pass filter_cache_tags and the library keeps track itself.
  *  - ready_event (mpsr_squash_decoder_fwd_ex): recorded on `stream` as soon as feat_box3d is complete, so that the
  *    caller can start the FC heads (mpsr_heads_fwd) on ANOTHER stream while the map decoder still runs -- the heads
  *    are many small launches that fill the decoder kernels' partially occupied last rounds (reference graph: the two
@@ -381,6 +383,12 @@ typedef struct mpsr_net_opts {
     size_t filter_cache_floats;
     int32_t filter_cache_valid;
     mpsr_event_t ready_event;
+    /* optional HOST array, one int per layer record (n_layers of the call), zero-initialised by the caller and kept with
+     * the cache: the library notes in it WHAT it stored in a layer's slice (F(4x4,3x3) / F(3x3,3x3) transformed filters,
+     * the tap GEMM's re-ordered rows) and re-fills a slice whose note does not match what the call is about to read --
+     * so a cache survives a change of arithmetic mode, Winograd policy or batch size without the caller tracking it.
+     * NULL: filter_cache_valid alone decides. */
+    int32_t *filter_cache_tags;
 } mpsr_net_opts;
 
 /* Floats of filter cache that serve every 3x3 layer of `layers` (36 cout cin per dense layer, 25 per atrous one). */

@@ -51,7 +51,8 @@ class HeadOutputs(ctypes.Structure):
 class NetOpts(ctypes.Structure):
     """struct mpsr_net_opts"""
     _fields_ = [("filter_cache", ctypes.c_void_p), ("filter_cache_floats", ctypes.c_size_t),
-                ("filter_cache_valid", ctypes.c_int32), ("ready_event", ctypes.c_void_p)]
+                ("filter_cache_valid", ctypes.c_int32), ("ready_event", ctypes.c_void_p),
+                ("filter_cache_tags", ctypes.POINTER(ctypes.c_int32))]
 
 
 # name -> (restype, argtypes); must list every symbol include/monopsr_hip.h declares (tests/test_cabi.py checks).

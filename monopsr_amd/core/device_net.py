@@ -24,20 +24,24 @@ class PackedPart:
 
 
 class FilterCache:
-    """Transformed Winograd filters of one weight blob kept across calls (mpsr_net_opts.filter_cache): filled by the
-    first native call, only read afterwards.  Valid for one (blob, batch, shape): a different key refills it."""
+    """Transformed filters of one weight blob kept across calls (mpsr_net_opts.filter_cache + filter_cache_tags): filled
+    by the first native call, only read afterwards."""
 
     def __init__(self, part, device):
         n = _lib.lib().mpsr_filter_cache_floats(part.layers, part.n)
         self.buf = torch.empty((int(n),), dtype=torch.float32, device=device) if n else None
-        self.key = None
+        # per-layer notes of what each slice holds: the library keeps them, so the cache survives a change of the
+        # arithmetic mode / Winograd policy / batch size (another kernel, another form of the filters) by itself
+        self.tags = (ctypes.c_int32 * part.n)()
+        self.filled = False
 
-    def opts(self, key, event=None):
+    def opts(self, key=None, event=None):
         o = _lib.NetOpts()
         if self.buf is not None:
             o.filter_cache, o.filter_cache_floats = self.buf.data_ptr(), self.buf.numel()
-            o.filter_cache_valid = 1 if self.key == key else 0
-            self.key = key
+            o.filter_cache_valid = 1 if self.filled else 0
+            o.filter_cache_tags = self.tags
+            self.filled = True
         o.ready_event = event
         return o
 

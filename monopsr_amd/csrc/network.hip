@@ -93,12 +93,14 @@ struct FilterCache {
     float *base = nullptr;
     size_t floats = 0, used = 0;
     bool valid = false;
+    int *tags = nullptr;  // the caller's per-layer notes (mpsr_net_opts.filter_cache_tags), indexed by layer record
     explicit FilterCache(const mpsr_net_opts *o)
     {
         if (o && o->filter_cache && o->filter_cache_floats) {
             base = o->filter_cache;
             floats = o->filter_cache_floats;
             valid = o->filter_cache_valid != 0;
+            tags = o->filter_cache_tags;
         }
     }
     // slice of layer L (nullptr: no cache, or it is full); call once per 3x3 layer, in order
@@ -110,7 +112,7 @@ struct FilterCache {
         used += need;
         return r;
     }
-    void offer(const float *w, float *slice, const mpsr_layer &L) const
+    void offer(const float *w, float *slice, const mpsr_layer &L, int layer_index) const
     {
         mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot();
         if (slice) {
@@ -118,6 +120,7 @@ struct FilterCache {
             mpsr::g_filter_cache_slot.u = slice;
             mpsr::g_filter_cache_slot.floats = cache_floats_of(L);
             mpsr::g_filter_cache_slot.ready = valid;
+            mpsr::g_filter_cache_slot.tag = tags ? tags + layer_index : nullptr;
         }
     }
 };
@@ -234,7 +237,9 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
             // transform rides on conv1's launch as a tail job (wino3_filter.h) instead of a launch of its own
             // (with a VALID filter cache there is nothing to transform; with one being filled the job writes the slice)
             float *uslice = cache.take(c2);
-            if (!(uslice && cache.valid) &&
+            const int c2i = (int)(&c2 - layers);
+            const bool cached_u = uslice && cache.valid && (!cache.tags || cache.tags[c2i] == mpsr::FILTER_FORM_WINO3);
+            if (!cached_u &&
                 mpsr::conv2d_takes_pointwise((long long)B * d.PH * d.PW, c1.cin, c1.cout, 1, 1, 0) &&
                 mpsr::conv2d_takes_winograd3(B, d.PH, d.PW, c2.cin, c2.cout, c2.kh, c2.kw, c2.dilation, 0, sk, skn)) {
                 mpsr::g_filter_tail_job.w = blob + c2.w_off;
@@ -244,7 +249,7 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
             }
             if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 0, sk, skn, s))) return rc;
             mpsr::g_filter_tail_job = mpsr::FilterTailJob();  // (not taken: conv2 transforms its filters itself)
-            cache.offer(blob + c2.w_off, uslice, c2);
+            cache.offer(blob + c2.w_off, uslice, c2, c2i);
             rc = run_layer(blob, c2, t1, B, d.PH, d.PW, nullptr, t2, 0, sk, skn, s);
             mpsr::g_filter_cache_slot = mpsr::FilterCacheSlot();
             if (rc) return rc;
@@ -414,13 +419,13 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
     const bool xyz_c8 = ch.xyz_c8, up1 = ch.up1, up2 = ch.up2, c8 = ch.c8;
     if (c8) {
         auto wino = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y, int in_c8, int out_c8) {
-            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr, (int)(&Lr - L));
             return mpsr::conv3x3_winograd4(x, B, H, W, Lr.cin, blob + Lr.w_off, Lr.b_off >= 0 ? blob + Lr.b_off : nullptr,
                                            Lr.relu, y, Lr.cout, sk, skn, s, in_c8, out_c8, partb, partn);
         };
         // upsampling + 3x3 convolution in one: x (NHWC, source size) -> y (channel-blocked, output size); z = r1 / r2
         auto upconv = [&](const mpsr_layer &Lr, const float *x, int h, int w, int H, int W, float *y, float *z, size_t zn) {
-            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+            cache.offer(blob + Lr.w_off, cache.take(Lr), Lr, (int)(&Lr - L));
             return mpsr::conv3x3_upsampled(x, B, h, w, Lr.cin, H, W, 1, blob + Lr.w_off,
                                            Lr.b_off >= 0 ? blob + Lr.b_off : nullptr, Lr.relu, y, Lr.cout, 1, z, zn, sk,
                                            skn, s);
@@ -452,11 +457,11 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
     // NHWC chain (small batches, maps that do not divide into 4x4 blocks, MPSR_WINOGRAD_OFF, the bf16x3 mode): conv2d
     // per layer; the two upsampled convolutions keep their tap GEMM + gather (NHWC output) where it applies
     auto cached = [&](const mpsr_layer &Lr, const float *x, int H, int W, float *y) {
-        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr, (int)(&Lr - L));
         return run_layer(blob, Lr, x, B, H, W, nullptr, y, 0, sk, skn, s);
     };
     auto upconv_nhwc = [&](const mpsr_layer &Lr, const float *x, int h, int w, int H, int W, float *y, float *z, size_t zn) {
-        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr);
+        cache.offer(blob + Lr.w_off, cache.take(Lr), Lr, (int)(&Lr - L));
         return mpsr::conv3x3_upsampled(x, B, h, w, Lr.cin, H, W, 1, blob + Lr.w_off,
                                        Lr.b_off >= 0 ? blob + Lr.b_off : nullptr, Lr.relu, y, Lr.cout, 0, z, zn, sk, skn, s);
     };

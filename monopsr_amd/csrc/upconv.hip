@@ -302,7 +302,7 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
     bool ready = false;
     if (g_filter_cache_slot.w == g && g_filter_cache_slot.u && g_filter_cache_slot.floats >= upconv_weight_floats(C, N)) {
         wp = g_filter_cache_slot.u;
-        ready = g_filter_cache_slot.ready;
+        ready = g_filter_cache_slot.holds(FILTER_FORM_UPCONV);
     } else if (!ws || ws_floats < upconv_weight_floats(C, N)) {
         g_filter_cache_slot = FilterCacheSlot();
         return fail(MPSR_ERR_WORKSPACE, "conv3x3_upsampled: scratch holds %zu floats, needs %zu", ws_floats,

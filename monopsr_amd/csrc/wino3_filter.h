@@ -62,6 +62,16 @@ struct FilterCacheSlot {
     float *u = nullptr;
     size_t floats = 0;
     bool ready = false;
+    int *tag = nullptr;  // caller's note of what the slice holds (mpsr_net_opts.filter_cache_tags), or nullptr
+    // true when the slice already holds form `kind` of this layer's filters; notes `kind` for the next call either way
+    // (the consumer is about to write it if not)
+    bool holds(int kind)
+    {
+        const bool ok = ready && (!tag || *tag == kind);
+        if (tag) *tag = kind;
+        return ok;
+    }
 };
+enum { FILTER_FORM_WINO4 = 1, FILTER_FORM_WINO3 = 2, FILTER_FORM_UPCONV = 3 };
 extern thread_local FilterCacheSlot g_filter_cache_slot;
 }  // namespace mpsr

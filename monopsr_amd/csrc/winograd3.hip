@@ -376,7 +376,7 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     bool ready = false;
     if (g_filter_cache_slot.w == w && g_filter_cache_slot.u && g_filter_cache_slot.floats >= winograd3_scratch_floats(C, N)) {
         u = g_filter_cache_slot.u;
-        ready = g_filter_cache_slot.ready;
+        ready = g_filter_cache_slot.holds(FILTER_FORM_WINO3);
     }
     g_filter_cache_slot = FilterCacheSlot();
     // (or the filters were transformed into `u` by the tail job of the preceding pointwise launch)

@@ -206,3 +206,40 @@ def test_decoder_upsampled_convs_as_tap_gemm_vs_resize_winograd(width_div, B):
     for name, a, b in zip(("features_for_box_3d", "features_for_map", "inst_xyz_map_local"), outs[1], outs[0]):
         assert _rel(a, b) < 1e-4, (name, _rel(a, b))
     assert float(outs[1][2].abs().max()) > 0
+
+
+def test_filter_cache_survives_changes_of_mode_and_batch():
+    """DeviceNet keeps the transformed filters of its 3x3 layers across calls (mpsr_net_opts.filter_cache).  WHICH form a
+    layer's slice holds depends on the kernel a call picks -- F(4x4,3x3) filters, the tap GEMM's re-ordered rows, nothing
+    -- and that changes with the arithmetic mode, the Winograd policy and the batch size; the library notes the form
+    per layer (filter_cache_tags) and re-fills a slice that holds another one.  One net, calls in every order: each
+    configuration must reproduce its own first result bit for bit, and the fp32 ones must agree with each other."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    net = dn.DeviceNet(W.synthetic_weights(seed=13))
+    g = torch.Generator(device="cuda").manual_seed(14)
+    feats = {B: (torch.randn((B, 12, 12, 1024), device="cuda", generator=g).clamp_(min=0),
+                 torch.randn((B, 12, 12, 1024), device="cuda", generator=g).clamp_(min=0)) for B in (128, 8)}
+
+    def run(B, math, policy):
+        _lib.set_conv_math(math)
+        _lib.set_winograd_policy(policy)
+        try:
+            return [t.clone() for t in net.squash_decoder(feats[B][0], feats[B][1], (48, 48), want_feat_map=True)]
+        finally:
+            _lib.set_conv_math("fp32")
+            _lib.set_winograd_policy("auto")
+    configs = [(128, "fp32", "auto"), (128, "bf16x3", "auto"), (128, "fp32", "off"), (8, "fp32", "auto"), (8, "bf16x3", "auto")]
+    first = {}
+    for order in (configs, configs[::-1], configs[1:] + configs[:1]):
+        for cfg in order:
+            out = run(*cfg)
+            if cfg not in first:
+                first[cfg] = out
+            for a, b in zip(out, first[cfg]):
+                assert torch.equal(a, b), cfg
+    for a, b in zip(first[(128, "fp32", "auto")], first[(128, "fp32", "off")]):
+        assert _rel(a, b) < 1e-4
+    for a, b in zip(first[(128, "fp32", "auto")], first[(128, "bf16x3", "auto")]):
+        assert _rel(a, b) < 1e-3

@@ -28,7 +28,7 @@ caches = dict(net.fcache)
 
 
 class NoCache:
-    def opts(self, key, event=None):
+    def opts(self, key=None, event=None):
         from monopsr_amd import _lib
         o = _lib.NetOpts()
         o.ready_event = event
