@@ -1,0 +1,48 @@
+"""The committed evidence must be self-consistent (r03 review, item 5): bench.py's `roofline.frac` -- executed
+multiply-adds of the replayed matrix-pipe launches / launch time / peak -- has to agree with the in-situ PMC figure
+(SQ_VALU_MFMA_BUSY_CYCLES over the same kernel set, tools/pmc_reduce.py) collected at the same commit, and the timed
+replay must not exceed the step it replays.  CPU-only: reads the newest round's files under profiles/."""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _newest(pattern):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    assert paths, pattern
+    return paths[-1]
+
+
+def _line(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def test_roofline_frac_agrees_with_the_pmc_busy_fraction():
+    bench = _newest("r*_bench_default_run.json")
+    rnd = re.match(r"(r\d+)_", os.path.basename(bench)).group(1)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)))
+    r = _line(bench)
+    roof = r["roofline"]
+    assert roof["bound"] == "mfma" and 0.0 < roof["frac"] <= 1.0
+    assert abs(roof["frac"] - pmc["mfma_busy"]) <= 0.02, (roof["frac"], pmc["mfma_busy"])
+    assert roof["kernel_ms_per_step"] <= r["ms_per_step"]
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
+    # the kernels the line names are the kernels the PMC collection saw
+    for k in ("pw_conv_kernel", "wino3_conv_kernel", "wino4_conv_kernel"):
+        assert k in roof["kernel"] and any(name.startswith(k) for name in pmc["kernels"])
+
+
+def test_bench_line_carries_the_contract_and_the_round_objects():
+    r = _line(_newest("r*_bench_default_run.json"))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["dtype"] == "f32" and r["vs_baseline"] is None and "workload" in r["config"]
+    assert abs(r["value"] - r["config"]["global_batch"] * 1e3 / r["ms_per_step"]) / r["value"] < 1e-3
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    if "cfg5_step" in r:
+        assert r["cfg5_step"]["ms_per_step"] > r["ms_per_step"]  # forward + EMD loss costs more than forward + Chamfer
