@@ -207,6 +207,18 @@ size_t mpsr_conv3x3_upsampled_scratch_floats(int B, int h, int w, int C, int N);
 int mpsr_conv3x3_upsampled_f32(const float *x, int B, int h, int w, int C, int OH, int OW, int align_corners,
                                const float *weights, const float *bias, int relu, float *y, int N, float *ws,
                                size_t ws_floats, mpsr_stream_t stream);
+/* 0: the shape is outside what mpsr_conv3x3_upsampled_f32 takes; 1: forward only; 2: forward and backward. */
+int mpsr_conv3x3_upsampled_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners);
+/* Its backward for training (TF autodiff of the two operators in the reference): dy (B,OH,OW,N) = gradient at the
+ * convolution's output BEFORE bias / activation.  dw (N, 9 C) += weight gradient (accumulated, like
+ * mpsr_conv2d_wgrad_f32; the bias gradient is mpsr_bias_grad of dy); dx (B,h,w,C) = data gradient, or NULL.  Everything
+ * happens at the SOURCE resolution: dz = the transposed gather of dy, then a 1x1 weight gradient and a 1x1 GEMM with
+ * K = 9 N -- in place of the resize gradient + the 3x3 data and weight gradients on the upsampled map.  Deterministic
+ * except for the weight gradient's pixel slices (fp32 atomics, as mpsr_conv2d_wgrad_f32). */
+size_t mpsr_conv3x3_upsampled_bwd_scratch_floats(int B, int h, int w, int C, int N);
+int mpsr_conv3x3_upsampled_bwd_f32(const float *x, const float *dy, int B, int h, int w, int C, int OH, int OW,
+                                   int align_corners, const float *weights, int N, float *dw, float *dx, float *ws,
+                                   size_t ws_floats, mpsr_stream_t stream);
 
 /* Explicit im2col for the ResNet root: explicit zero pad 3 + 7x7 stride-2 VALID (resnet_utils.py:115-122 via
  * resnet_v1.py:234).  x (B,H,W,3) -> cols (B*OH*OW, kpad) with OH=(H+6-7)/2+1; column (ky*7+kx)*3+c, columns

@@ -112,6 +112,10 @@ SIGNATURES = {
     "mpsr_trunk_fwd": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz, c_f]),
     "mpsr_conv3x3_upsampled_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "mpsr_conv3x3_upsampled_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_sz, c_f]),
+    "mpsr_conv3x3_upsampled_applies": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mpsr_conv3x3_upsampled_bwd_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "mpsr_conv3x3_upsampled_bwd_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_sz,
+                                            c_f]),
     "mpsr_filter_cache_floats": (c_sz, [ctypes.POINTER(Layer), c_i]),
     "mpsr_trunk_fwd_ex": (c_i, [c_f, c_i, c_i, c_i, c_f, ctypes.POINTER(Layer), c_i, c_f, c_f, c_sz,
                                 ctypes.POINTER(NetOpts), c_f]),
@@ -155,6 +159,10 @@ def lib():
 
 
 MATH_MODES = {"fp32": 0, "bf16x3": 1}
+
+
+def get_conv_math():
+    return {v: k for k, v in MATH_MODES.items()}[lib().mpsr_get_conv_math()]
 
 
 def set_conv_math(mode):

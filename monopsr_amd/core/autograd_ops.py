@@ -172,6 +172,48 @@ class BottleneckFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+_UPCONV_SCRATCH = {}
+
+
+class UpsampledConv2dFn(torch.autograd.Function):
+    """tf.image.resize_bilinear(x, size, align_corners) -> 3x3 SAME conv with layer L as ONE operator that never forms
+    the upsampled map (csrc/upconv.hip; the map decoder's conv2_1 / conv3_1, net_builder.py:72-85).  Forward: tap GEMM on
+    the source map + gather.  Backward: the transposed gather of dy, then a 1x1 weight gradient and a 1x1 data-gradient
+    GEMM, all at the SOURCE resolution -- in place of the resize gradient, the 3x3 data gradient and the (Winograd-domain)
+    weight gradient on the 4x larger map.  With a BatchNormState on the layer the convolution runs bare (BatchNormReluFn
+    follows), otherwise bias + ReLU are part of the operator."""
+
+    @staticmethod
+    def forward(ctx, x, layer, size, align_corners, token):
+        x = x.contiguous()
+        bn = layer.batch_norm is not None
+        y = dn.conv3x3_upsampled(x, size, layer.w, None if bn else layer.b, layer.relu and not bn, align_corners)
+        ctx.layer, ctx.cfg = layer, (tuple(size), bool(align_corners))
+        ctx.save_for_backward(x, y if (layer.relu and not bn) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = ctx.layer
+        x, y = ctx.saved_tensors
+        (oh, ow), ac = ctx.cfg
+        g = _masked_grad(L, dy, y)
+        lib = _lib.lib()
+        B, h, w, C = x.shape
+        s = _lib.stream()
+        if L.batch_norm is None:  # (with BatchNorm, db is the beta gradient and BatchNormReluFn deposits it)
+            _lib.check(lib.mpsr_bias_grad(_lib.ptr(g), g.numel() // L.cout, L.cout, _lib.ptr(L.db), s))
+        nws = lib.mpsr_conv3x3_upsampled_bwd_scratch_floats(B, h, w, C, L.cout)
+        ws = dn.stream_scratch(_UPCONV_SCRATCH, x.device, nws)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.mpsr_conv3x3_upsampled_bwd_f32(_lib.ptr(x), _lib.ptr(g), B, h, w, C, oh, ow, int(ac), _lib.ptr(L.w),
+                                                      L.cout, _lib.ptr(L.dw), _lib.ptr(dx), _lib.ptr(ws), ws.numel(), s))
+        ready = getattr(L, "on_grad_ready", None)
+        if ready is not None:
+            ready()
+        return dx, None, None, None, None
+
+
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, s, padding):
@@ -295,6 +337,22 @@ def conv2d(x, layer, residual=None):
     """One layer: convolution (+ bias + residual + ReLU), or convolution -> training-mode BatchNorm -> ReLU when the
     layer carries a BatchNormState."""
     y = Conv2dFn.apply(x, residual, layer, _token(x.device))
+    if layer.batch_norm is not None:
+        y = BatchNormReluFn.apply(y, layer, _token(x.device))
+    return y
+
+
+def upsampled_conv_applies(x_shape, layer, size, align_corners=True):
+    """True when resize -> 3x3 conv with `layer` can run (forward AND backward) as the single tap-GEMM operator."""
+    B, h, w, C = x_shape
+    return layer.kh == 3 and layer.kw == 3 and layer.dilation == 1 and _lib.get_conv_math() == "fp32" and \
+        _lib.lib().mpsr_conv3x3_upsampled_applies(B, h, w, C, size[0], size[1], layer.cout, int(align_corners)) == 2
+
+
+def upsampled_conv2d(x, layer, size, align_corners=True):
+    """resize_bilinear(x, size) -> conv(layer) (-> training-mode BatchNorm -> ReLU when the layer carries a
+    BatchNormState) without the upsampled map; see UpsampledConv2dFn."""
+    y = UpsampledConv2dFn.apply(x, layer, tuple(size), align_corners, _token(x.device))
     if layer.batch_norm is not None:
         y = BatchNormReluFn.apply(y, layer, _token(x.device))
     return y

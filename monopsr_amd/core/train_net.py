@@ -105,6 +105,7 @@ class TrainNet:
 
     # ------------------------------------------------------------------ forward pieces
     fused_units = True  # trunk(): bottleneck units as single autograd nodes (ops.BottleneckFn); False = layer by layer
+    fused_upsampled_convs = True  # squash_decoder(): resize -> conv pairs as one tap-GEMM operator, forward and backward
 
     def trunk(self, img, scope='crop'):
         if scope == 'crop':
@@ -140,10 +141,14 @@ class TrainNet:
         part = ops.conv2d(crop_feat, L[0])
         sq = ops.conv2d(full_feat, L[1], residual=part)
         feat_box = ops.max_pool(sq, 2, 2, "VALID")
-        y = ops.resize_bilinear(sq, (map_size[0] // 2, map_size[1] // 2), True)
-        y = ops.conv2d(ops.conv2d(y, L[2]), L[3])
-        y = ops.resize_bilinear(y, tuple(map_size), True)
-        feat_map = ops.conv2d(ops.conv2d(y, L[4]), L[5])
+        half = (map_size[0] // 2, map_size[1] // 2)
+
+        def up_conv(x, layer, size):  # resize -> conv: one operator where the tap-GEMM form applies (csrc/upconv.hip)
+            if self.fused_upsampled_convs and ops.upsampled_conv_applies(tuple(x.shape), layer, size):
+                return ops.upsampled_conv2d(x, layer, size, True)
+            return ops.conv2d(ops.resize_bilinear(x, size, True), layer)
+        y = ops.conv2d(up_conv(sq, L[2], half), L[3])
+        feat_map = ops.conv2d(up_conv(y, L[4], tuple(map_size)), L[5])
         xyz = ops.conv2d(feat_map, L[6])
         return feat_box, feat_map, xyz
 

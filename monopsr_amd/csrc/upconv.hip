@@ -223,6 +223,105 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward
+// dz = gather^T(dy): dz[s][t][n] = sum over the upsampled pixels q that interpolate from source pixel s of
+// a[q][s] * dy[q - t][n] (q - t inside the output) -- the transpose of upconv_gather_kernel, written as a gather so that
+// nothing is scattered and the sum order is fixed.  One workgroup per (image, 8-channel block), XCD-aware order; the
+// image's dy slice for the block ([OH][OW][8]) sits in LDS next to two small tables: for every source row / column the
+// (upsampled index, weight) pairs that touch it.  Item = (source pixel, 16-byte piece of its 288 output bytes).
+constexpr int kGtMax = 8;  // most upsampled rows (columns) that interpolate from one source row (column)
+
+struct UpcGradParams {
+    const float *dy;
+    float *dz;
+    int B, h, w, H, W, N;
+    float hscale, wscale;
+};
+
+__global__ __launch_bounds__(256) void upconv_gather_t_kernel(const UpcGradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 g4[];  // [OH][OW][2]
+    const int tid = threadIdx.x;
+    const int nblk = p.N >> 3;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int bq = jx / nblk, blk = jx - bq * nblk, b = bq * 8 + xcd;
+    if (b >= p.B) return;  // block-uniform
+    const int npix = p.H * p.W;
+    // tables behind the image slice: qi[axis][s][k], qw[axis][s][k], cnt[axis][s]
+    int *qi = reinterpret_cast<int *>(g4 + (size_t)npix * 2);
+    float *qw = reinterpret_cast<float *>(qi + (p.h + p.w) * kGtMax);
+    int *qc = reinterpret_cast<int *>(qw + (p.h + p.w) * kGtMax);
+    for (int i = tid; i < npix * 2; i += 256)
+        g4[i] = *reinterpret_cast<const float4 *>(p.dy + ((size_t)b * npix + (i >> 1)) * p.N + blk * 8 + 4 * (i & 1));
+    for (int s = tid; s < p.h + p.w; s += 256) {
+        const bool row = s < p.h;
+        const int sv = row ? s : s - p.h, n_in = row ? p.h : p.w, n_out = row ? p.H : p.W;
+        const float scale = row ? p.hscale : p.wscale;
+        int c = 0;
+        for (int q = 0; q < n_out; ++q) {  // the forward kernel's own arithmetic
+            const float sq = (float)q * scale;
+            const int r0 = (int)floorf(sq), r1 = min(r0 + 1, n_in - 1);
+            const float l = sq - (float)r0;
+            const float wgt = (r0 == sv ? 1.f - l : 0.f) + (r1 == sv ? l : 0.f);
+            if ((r0 == sv || r1 == sv) && c < kGtMax) {
+                qi[s * kGtMax + c] = q;
+                qw[s * kGtMax + c] = wgt;
+                ++c;
+            }
+        }
+        qc[s] = c;
+    }
+    __syncthreads();
+    float *dzb = p.dz + (size_t)b * p.h * p.w * 9 * p.N + (size_t)blk * 72;
+    const int nitems = p.h * p.w * 18;
+    for (int it = tid; it < nitems; it += 256) {
+        const int s = it / 18, q18 = it - s * 18, t = q18 >> 1, half = q18 & 1;
+        const int sy = s / p.w, sx = s - sy * p.w;
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const int ny = qc[sy], nx = qc[p.h + sx];
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int ky = 0; ky < ny; ++ky) {
+            const int py = qi[sy * kGtMax + ky] - dy;
+            if (py < 0 || py >= p.H) continue;
+            const float wy = qw[sy * kGtMax + ky];
+            for (int kx = 0; kx < nx; ++kx) {
+                const int px = qi[(p.h + sx) * kGtMax + kx] - dx;
+                if (px < 0 || px >= p.W) continue;
+                const float wgt = wy * qw[(p.h + sx) * kGtMax + kx];
+                const float4 v = g4[(py * p.W + px) * 2 + half];
+                const f32x2 w2 = {wgt, wgt};
+                a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
+                a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+            }
+        }
+        *reinterpret_cast<float4 *>(dzb + (size_t)s * 9 * p.N + t * 8 + 4 * half) = make_float4(a01.x, a01.y, a23.x, a23.y);
+    }
+}
+
+// wt[c][j] = g[n][t*C + c], j = (n / 8) * 72 + t * 8 + (n % 8): the (C, 9 N) weight matrix of the data-gradient GEMM
+__global__ __launch_bounds__(256) void upconv_weights_t_kernel(const float *__restrict__ g, int N, int C, float *__restrict__ wt)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int K = 9 * N;
+    if (i >= (long long)C * K) return;
+    const int c = (int)(i / K), j = (int)(i - (long long)c * K);
+    const int blk = j / 72, r = j - blk * 72, t = r >> 3, n = blk * 8 + (r & 7);
+    wt[i] = g[((size_t)n * 9 + t) * C + c];
+}
+
+// dw[n][t*C + c] += dwp[j][c]: folds the tap GEMM's weight gradient back into the filter's layout
+__global__ __launch_bounds__(256) void upconv_fold_dw_kernel(const float *__restrict__ dwp, int N, int C, float *__restrict__ dw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (i >= (long long)9 * N * c4) return;
+    const int j = (int)(i / c4), q = (int)(i - (long long)j * c4);
+    const int blk = j / 72, r = j - blk * 72, t = r >> 3, n = blk * 8 + (r & 7);
+    float4 *d = reinterpret_cast<float4 *>(dw + ((size_t)n * 9 + t) * C) + q;
+    const float4 a = *d, v = reinterpret_cast<const float4 *>(dwp)[i];
+    *d = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+}
+
 // Launch geometry of the gather: threads = rpp x 2 W (rows of a pass x (column, channel half)), rpp a power of two with
 // at most 512 threads; RB = output rows per band (8, or rpp if larger); cap = the ring's rows, a power of two >= the rows
 // any band reaches; the rows a band ADDS must fit the prefetch registers.  false: the map is too wide for this kernel.
@@ -365,6 +464,104 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
 }
 
 }  // namespace mpsr
+
+namespace mpsr {
+
+// LDS of upconv_gather_t_kernel: the image's dy slice for 8 channels + the two interpolation tables
+static size_t gather_t_lds_bytes(int h, int w, int OH, int OW)
+{
+    return (size_t)OH * OW * 32 + (size_t)(h + w) * (kGtMax * 8 + 4);
+}
+
+bool upconv_bwd_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners)
+{
+    const long long M = (long long)B * h * w;
+    // (at most kGtMax upsampled rows per source row: scales down to 1/3)
+    const bool scale_ok = (long long)OH <= 3LL * h && (long long)OW <= 3LL * w;
+    return upconv_applies(B, h, w, C, OH, OW, N, align_corners) && scale_ok && gather_t_lds_bytes(h, w, OH, OW) <= 96 * 1024 &&
+           pointwise_applies(M, 9 * N, C) && M * 9 * N * 4 < 0xfffff000LL && M < (1LL << 24);
+}
+
+// floats: dz (M x 9N) | dW' (9N x C) | W'^T (C x 9N)
+size_t upconv_bwd_scratch_floats(int B, int h, int w, int C, int N)
+{
+    const size_t M = (size_t)B * h * w;
+    return align_up(M * 9 * N, 64) + 2 * align_up((size_t)9 * N * C, 64);
+}
+
+}  // namespace mpsr
+
+extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int H, int W, int C, int N, int KH, int KW,
+                                     int dilation, float *dw, float *db, mpsr_stream_t stream);
+
+namespace mpsr {
+
+// Backward of conv3x3_upsampled (bias-free part): dy (B,OH,OW,N) NHWC -> dw (N, 9 C) += weight gradient, dx (B,h,w,C) =
+// data gradient (or nullptr).  dz = gather^T(dy) at the SOURCE resolution; dW' = dz^T x (a 1x1 weight gradient with 9 N
+// outputs) folded back into the filter layout; dx = dz W' (a 1x1 GEMM with K = 9 N on the pointwise kernel) -- the
+// resize gradient, the F(4x4) data gradient on the upsampled map and the Winograd-domain weight gradient in one.
+int conv3x3_upsampled_bwd(const float *x, const float *dy, int B, int h, int w, int C, int OH, int OW, int align_corners,
+                          const float *g, int N, float *dw, float *dx, float *ws, size_t ws_floats, hipStream_t s)
+{
+    MPSR_REQUIRE(upconv_bwd_applies(B, h, w, C, OH, OW, N, align_corners), "conv3x3_upsampled_bwd: unsupported shape");
+    if (!ws || ws_floats < upconv_bwd_scratch_floats(B, h, w, C, N))
+        return fail(MPSR_ERR_WORKSPACE, "conv3x3_upsampled_bwd: scratch holds %zu floats, needs %zu", ws_floats,
+                    upconv_bwd_scratch_floats(B, h, w, C, N));
+    const size_t M = (size_t)B * h * w, wf = align_up((size_t)9 * N * C, 64);
+    float *dz = ws, *dwp = ws + align_up(M * 9 * N, 64), *wt = dwp + wf;
+    UpcGradParams p;
+    p.dy = dy; p.dz = dz;
+    p.B = B; p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N;
+    p.hscale = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
+    p.wscale = (align_corners && OW > 1) ? (float)(w - 1) / (float)(OW - 1) : (float)w / (float)OW;
+    const size_t lds = gather_t_lds_bytes(h, w, OH, OW);
+    MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_t_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(upconv_gather_t_kernel, dim3((unsigned)(8 * ceil_div(B, 8) * (N / 8))), dim3(256), lds, s, p);
+    MPSR_CHECK_LAUNCH("upconv_gather_t_kernel");
+    // weight gradient of the tap GEMM, folded back into (N, 9 C)
+    MPSR_CHECK_HIP(hipMemsetAsync(dwp, 0, (size_t)9 * N * C * sizeof(float), s));
+    if (int rc = mpsr_conv2d_wgrad_f32(x, dz, B, h, w, C, 9 * N, 1, 1, 1, dwp, nullptr, reinterpret_cast<mpsr_stream_t>(s))) return rc;
+    {
+        const long long total = (long long)9 * N * (C / 4);
+        hipLaunchKernelGGL(upconv_fold_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dwp, N, C, dw);
+        MPSR_CHECK_LAUNCH("upconv_fold_dw_kernel");
+    }
+    if (dx) {
+        const long long total = (long long)C * 9 * N;
+        hipLaunchKernelGGL(upconv_weights_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, N, C, wt);
+        MPSR_CHECK_LAUNCH("upconv_weights_t_kernel");
+        if (int rc = conv1x1_pointwise(dz, (long long)M, 9 * N, wt, nullptr, nullptr, 0, dx, C, s)) return rc;
+    }
+    return MPSR_OK;
+}
+
+}  // namespace mpsr
+
+extern "C" int mpsr_conv3x3_upsampled_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners)
+{
+    return mpsr::upconv_applies(B, h, w, C, OH, OW, N, align_corners) ? (mpsr::upconv_bwd_applies(B, h, w, C, OH, OW, N, align_corners) ? 2 : 1) : 0;
+}
+
+extern "C" size_t mpsr_conv3x3_upsampled_bwd_scratch_floats(int B, int h, int w, int C, int N)
+{
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || N <= 0) return 0;
+    return mpsr::upconv_bwd_scratch_floats(B, h, w, C, N);
+}
+
+extern "C" int mpsr_conv3x3_upsampled_bwd_f32(const float *x, const float *dy, int B, int h, int w, int C, int OH, int OW,
+                                              int align_corners, const float *weights, int N, float *dw, float *dx,
+                                              float *ws, size_t ws_floats, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(B >= 0 && h > 0 && w > 0 && C > 0 && OH > 0 && OW > 0 && N > 0, "conv3x3_upsampled_bwd: bad shape");
+    if (B == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && dy && weights && dw && ws, "conv3x3_upsampled_bwd: null pointer");
+    if (!mpsr::upconv_bwd_applies(B, h, w, C, OH, OW, N, align_corners))
+        return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv3x3_upsampled_bwd: shape outside what the tap-GEMM backward takes "
+                                                "(B=%d %dx%dx%d -> %dx%dx%d); use the resize / conv gradients", B, h, w, C, OH, OW, N);
+    return mpsr::conv3x3_upsampled_bwd(x, dy, B, h, w, C, OH, OW, align_corners, weights, N, dw, dx, ws, ws_floats,
+                                       mpsr::as_stream(stream));
+}
 
 extern "C" size_t mpsr_conv3x3_upsampled_scratch_floats(int B, int h, int w, int C, int N)
 {

@@ -280,6 +280,41 @@ def test_network_training_gradients_end_to_end():
     assert float((net.params - before).abs().max()) > 0
 
 
+@pytest.mark.parametrize("B,h,w,C,OH,OW,N,bias_relu", [(2, 12, 12, 128, 24, 24, 128, True), (2, 6, 9, 192, 12, 18, 256, False),
+                                                      (1, 24, 24, 256, 48, 48, 128, True), (2, 5, 7, 128, 11, 16, 128, True)])
+def test_upsampled_conv_backward_vs_float64_autograd(B, h, w, C, OH, OW, N, bias_relu):
+    """UpsampledConv2dFn (resize_bilinear(align_corners) -> 3x3 conv as one tap-GEMM operator, csrc/upconv.hip): data,
+    weight and bias gradients against float64 autograd of oracle/net.py's two TF-1.8 operators."""
+    from monopsr_amd.core import autograd_ops as ops
+    from monopsr_amd.core import weights as W
+    from oracle import net as onet
+    rng = np.random.default_rng(B + h + C + N)
+    x = rng.standard_normal((B, h, w, C)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    up = rng.standard_normal((B, OH, OW, N)).astype(np.float32)
+    w_ok, _ = W.fold_conv(wt)
+    wd, bd = _dev(w_ok), _dev(b)
+    L = ops.LayerRef(wd, bd, torch.zeros_like(wd), torch.zeros_like(bd), C, N, 3, 3, 1, bias_relu)
+    assert ops.upsampled_conv_applies((B, h, w, C), L, (OH, OW))
+    xd = _dev(x).requires_grad_(True)
+    y = ops.upsampled_conv2d(xd, L, (OH, OW), True)
+    (y * _dev(up)).sum().backward()
+    torch.cuda.synchronize()
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    w64 = torch.from_numpy(wt).double().requires_grad_(True)
+    b64 = torch.from_numpy(b).double().requires_grad_(True)
+    ref = onet.tf_conv2d(onet.tf_resize_bilinear(x64, OH, OW, True), w64) + b64
+    if bias_relu:
+        ref = torch.relu(ref)
+    (ref * torch.from_numpy(up).double()).sum().backward()
+    _close(y, ref, 1e-5, "forward")
+    _close(xd.grad, x64.grad, 2e-5, "data gradient")
+    dw_ref = w64.grad.permute(3, 0, 1, 2).reshape(N, -1)  # HWIO -> (N, 9 C)
+    _close(L.dw, dw_ref, 1e-4, "weight gradient")
+    _close(L.db, b64.grad, 1e-4, "bias gradient")
+
+
 def test_bottleneck_units_as_one_autograd_node_give_the_same_gradients():
     """TrainNet.trunk runs every bottleneck unit as ONE autograd node (autograd_ops.BottleneckFn: the two gradients of
     the unit's input meet in the epilogue of conv1's data-gradient convolution instead of in an elementwise launch).
