@@ -226,75 +226,121 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
 // ------------------------------------------------------------------------------------------------ backward
 // dz = gather^T(dy): dz[s][t][n] = sum over the upsampled pixels q that interpolate from source pixel s of
 // a[q][s] * dy[q - t][n] (q - t inside the output) -- the transpose of upconv_gather_kernel, written as a gather so that
-// nothing is scattered and the sum order is fixed.  One workgroup per (image, 8-channel block), XCD-aware order; the
-// image's dy slice for the block ([OH][OW][8]) sits in LDS next to two small tables: for every source row / column the
-// (upsampled index, weight) pairs that touch it.  Item = (source pixel, 16-byte piece of its 288 output bytes).
+// nothing is scattered and the sum order is fixed.  One workgroup per (32-channel group, source row, image): the dy rows
+// that source row reaches (the upsampled rows that interpolate from it, one more on each side for the taps) sit in LDS
+// as [row][x][32 channels] -- 128 contiguous bytes per pixel of the NHWC gradient, whole lines (a first version with one
+// workgroup per (image, 8-channel block) read 32 of every 128 bytes and took 1.06 ms on conv3_1) -- next to the
+// (upsampled index, weight) pairs of this source row and of every source column.  Item = (source column, tap, channel quad).
 constexpr int kGtMax = 8;  // most upsampled rows (columns) that interpolate from one source row (column)
 
 struct UpcGradParams {
     const float *dy;
     float *dz;
-    int B, h, w, H, W, N;
+    int B, h, w, H, W, N, rows_max;
     float hscale, wscale;
 };
 
 __global__ __launch_bounds__(256) void upconv_gather_t_kernel(const UpcGradParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 g4[];  // [OH][OW][2]
+    extern __shared__ __attribute__((aligned(16))) float4 g4[];  // [rows_max][W][8]
+    __shared__ int yq[kGtMax];
+    __shared__ float yw[kGtMax];
+    __shared__ int ycnt, yrange[2];
     const int tid = threadIdx.x;
-    const int nblk = p.N >> 3;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int bq = jx / nblk, blk = jx - bq * nblk, b = bq * 8 + xcd;
-    if (b >= p.B) return;  // block-uniform
-    const int npix = p.H * p.W;
-    // tables behind the image slice: qi[axis][s][k], qw[axis][s][k], cnt[axis][s]
-    int *qi = reinterpret_cast<int *>(g4 + (size_t)npix * 2);
-    float *qw = reinterpret_cast<float *>(qi + (p.h + p.w) * kGtMax);
-    int *qc = reinterpret_cast<int *>(qw + (p.h + p.w) * kGtMax);
-    for (int i = tid; i < npix * 2; i += 256)
-        g4[i] = *reinterpret_cast<const float4 *>(p.dy + ((size_t)b * npix + (i >> 1)) * p.N + blk * 8 + 4 * (i & 1));
-    for (int s = tid; s < p.h + p.w; s += 256) {
-        const bool row = s < p.h;
-        const int sv = row ? s : s - p.h, n_in = row ? p.h : p.w, n_out = row ? p.H : p.W;
+    const int grp = blockIdx.x, sy = blockIdx.y, b = blockIdx.z;
+    int *xq = reinterpret_cast<int *>(g4 + (size_t)p.rows_max * p.W * 8 + (size_t)3 * p.W * 8);  // [w][kGtMax], behind V
+    float *xw = reinterpret_cast<float *>(xq + p.w * kGtMax);
+    int *xc = reinterpret_cast<int *>(xw + p.w * kGtMax);
+    // (upsampled index, weight) pairs by the forward kernel's own arithmetic: this source row (thread 0), every source
+    // column (threads 1 .. w).  q interpolates from s iff floor(q scale) is s - 1 or s: only q in
+    // [(s - 1) / scale, (s + 1) / scale] need a look
+    if (tid <= p.w) {
+        const bool row = tid == 0;
+        const int sv = row ? sy : tid - 1, n_in = row ? p.h : p.w, n_out = row ? p.H : p.W;
         const float scale = row ? p.hscale : p.wscale;
-        int c = 0;
-        for (int q = 0; q < n_out; ++q) {  // the forward kernel's own arithmetic
+        const int q_lo = max((int)floorf((float)(sv - 1) / scale) - 1, 0), q_hi = min((int)ceilf((float)(sv + 1) / scale) + 1, n_out - 1);
+        int *oq = row ? yq : xq + sv * kGtMax;
+        float *ow = row ? yw : xw + sv * kGtMax;
+        int c = 0, lo = n_out, hi = -1;
+        for (int q = q_lo; q <= q_hi; ++q) {
             const float sq = (float)q * scale;
             const int r0 = (int)floorf(sq), r1 = min(r0 + 1, n_in - 1);
             const float l = sq - (float)r0;
-            const float wgt = (r0 == sv ? 1.f - l : 0.f) + (r1 == sv ? l : 0.f);
             if ((r0 == sv || r1 == sv) && c < kGtMax) {
-                qi[s * kGtMax + c] = q;
-                qw[s * kGtMax + c] = wgt;
+                oq[c] = q;
+                ow[c] = (r0 == sv ? 1.f - l : 0.f) + (r1 == sv ? l : 0.f);
                 ++c;
+                lo = min(lo, q);
+                hi = max(hi, q);
             }
         }
-        qc[s] = c;
+        if (row) {
+            ycnt = c;
+            yrange[0] = max(lo - 1, 0);
+            yrange[1] = min(hi + 1, p.H - 1);
+        } else {
+            xc[sv] = c;
+        }
     }
     __syncthreads();
-    float *dzb = p.dz + (size_t)b * p.h * p.w * 9 * p.N + (size_t)blk * 72;
-    const int nitems = p.h * p.w * 18;
-    for (int it = tid; it < nitems; it += 256) {
-        const int s = it / 18, q18 = it - s * 18, t = q18 >> 1, half = q18 & 1;
-        const int sy = s / p.w, sx = s - sy * p.w;
-        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
-        const int ny = qc[sy], nx = qc[p.h + sx];
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-        for (int ky = 0; ky < ny; ++ky) {
-            const int py = qi[sy * kGtMax + ky] - dy;
-            if (py < 0 || py >= p.H) continue;
-            const float wy = qw[sy * kGtMax + ky];
-            for (int kx = 0; kx < nx; ++kx) {
-                const int px = qi[(p.h + sx) * kGtMax + kx] - dx;
-                if (px < 0 || px >= p.W) continue;
-                const float wgt = wy * qw[(p.h + sx) * kGtMax + kx];
-                const float4 v = g4[(py * p.W + px) * 2 + half];
-                const f32x2 w2 = {wgt, wgt};
-                a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
-                a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+    const int rlo = yrange[0], nrows = yrange[1] - rlo + 1;
+    {  // dy rows rlo .. rhi of this image, channels 32 grp .. + 31: 8 float4 per pixel, contiguous; loads issued in
+       // batches of kPf before they are stored (a load -> store loop waits for every round trip in turn)
+        const float *src = p.dy + (((size_t)b * p.H + rlo) * p.W) * p.N + grp * 32;
+        const int total = nrows * p.W * 8;
+        for (int first = 0; first < total; first += kPf * 256) {
+            f32x4 pf[kPf];
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const int i = first + j * 256 + tid;
+                pf[j] = *reinterpret_cast<const f32x4 *>(i < total ? src + (size_t)(i >> 3) * p.N + 4 * (i & 7) : src);
+            }
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const int i = first + j * 256 + tid;
+                if (i < total) reinterpret_cast<f32x4 *>(g4)[i] = pf[j];
             }
         }
-        *reinterpret_cast<float4 *>(dzb + (size_t)s * 9 * p.N + t * 8 + 4 * half) = make_float4(a01.x, a01.y, a23.x, a23.y);
+    }
+    __syncthreads();
+    // Separable: first the row direction -- V[dy][x][quad] = sum_ky wy[ky] dy[yq[ky] - dy][x] for the three tap rows, into
+    // LDS behind the rows -- then the column direction from V: 2.4x fewer inner iterations than the direct double sum.
+    const int ny = ycnt;
+    float4 *V = g4 + (size_t)p.rows_max * p.W * 8;  // [3][W][8]   (the column table sits behind it)
+    for (int it = tid; it < 3 * p.W * 8; it += 256) {
+        const int d = it / (p.W * 8), r = it - d * (p.W * 8);  // r = x * 8 + quad
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int ky = 0; ky < ny; ++ky) {
+            const int py = yq[ky] - (d - 1);
+            if (py < 0 || py >= p.H) continue;
+            const float4 v = g4[(size_t)(py - rlo) * p.W * 8 + r];
+            const f32x2 w2 = {yw[ky], yw[ky]};
+            a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
+            a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+        }
+        V[it] = make_float4(a01.x, a01.y, a23.x, a23.y);
+    }
+    __syncthreads();
+    float *dzrow = p.dz + (((size_t)b * p.h + sy) * p.w) * 9 * p.N + (size_t)grp * 4 * 72;
+    const int nitems = p.w * 72;  // (source column, tap, channel quad)
+    for (int it = tid; it < nitems; it += 256) {
+        const int sx = it / 72, r = it - sx * 72, t = r >> 3, quad = r & 7;
+        const int d = t / 3, dx = t - d * 3 - 1;
+        const int nx = xc[sx];
+        const int *qix = xq + sx * kGtMax;
+        const float *qwx = xw + sx * kGtMax;
+        const float4 *row = V + (size_t)d * p.W * 8 + quad;
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int kx = 0; kx < nx; ++kx) {
+            const int px = qix[kx] - dx;
+            if (px < 0 || px >= p.W) continue;
+            const float4 v = row[px * 8];
+            const f32x2 w2 = {qwx[kx], qwx[kx]};
+            a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
+            a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+        }
+        *reinterpret_cast<float4 *>(dzrow + (size_t)sx * 9 * p.N + (quad >> 1) * 72 + t * 8 + 4 * (quad & 1)) =
+            make_float4(a01.x, a01.y, a23.x, a23.y);
     }
 }
 
@@ -467,19 +513,40 @@ int conv3x3_upsampled(const float *x, int B, int h, int w, int C, int OH, int OW
 
 namespace mpsr {
 
-// LDS of upconv_gather_t_kernel: the image's dy slice for 8 channels + the two interpolation tables
-static size_t gather_t_lds_bytes(int h, int w, int OH, int OW)
+// most dy rows one source row reaches in upconv_gather_t_kernel: the upsampled rows that interpolate from it + one on
+// each side (the kernel's own arithmetic)
+static int gather_t_rows(int h, int OH, float hscale)
 {
-    return (size_t)OH * OW * 32 + (size_t)(h + w) * (kGtMax * 8 + 4);
+    int most = 1;
+    for (int sy = 0; sy < h; ++sy) {
+        int lo = OH, hi = -1;
+        for (int q = 0; q < OH; ++q) {
+            const float sq = (float)q * hscale;
+            const int r0 = (int)floorf(sq), r1 = r0 + 1 < h - 1 ? r0 + 1 : h - 1;
+            if (r0 == sy || r1 == sy) {
+                lo = q < lo ? q : lo;
+                hi = q > hi ? q : hi;
+            }
+        }
+        if (hi >= lo) {
+            const int a = lo - 1 > 0 ? lo - 1 : 0, b = hi + 1 < OH - 1 ? hi + 1 : OH - 1;
+            most = b - a + 1 > most ? b - a + 1 : most;
+        }
+    }
+    return most;
 }
+// LDS of upconv_gather_t_kernel: those rows for 32 channels + the three row-reduced rows V + the column table
+static size_t gather_t_lds_bytes(int rows, int w, int OW) { return (size_t)(rows + 3) * OW * 128 + (size_t)w * (kGtMax * 8 + 4); }
 
 bool upconv_bwd_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners)
 {
     const long long M = (long long)B * h * w;
     // (at most kGtMax upsampled rows per source row: scales down to 1/3)
     const bool scale_ok = (long long)OH <= 3LL * h && (long long)OW <= 3LL * w;
-    return upconv_applies(B, h, w, C, OH, OW, N, align_corners) && scale_ok && gather_t_lds_bytes(h, w, OH, OW) <= 96 * 1024 &&
-           pointwise_applies(M, 9 * N, C) && M * 9 * N * 4 < 0xfffff000LL && M < (1LL << 24);
+    const float hs = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
+    return upconv_applies(B, h, w, C, OH, OW, N, align_corners) && scale_ok && OH <= 65535 && h <= 65535 &&
+           gather_t_lds_bytes(gather_t_rows(h, OH, hs), w, OW) <= 64 * 1024 && pointwise_applies(M, 9 * N, C) &&
+           M * 9 * N * 4 < 0xfffff000LL && M < (1LL << 24);
 }
 
 // floats: dz (M x 9N) | dW' (9N x C) | W'^T (C x 9N)
@@ -514,10 +581,11 @@ int conv3x3_upsampled_bwd(const float *x, const float *dy, int B, int h, int w, 
     p.B = B; p.h = h; p.w = w; p.H = OH; p.W = OW; p.N = N;
     p.hscale = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
     p.wscale = (align_corners && OW > 1) ? (float)(w - 1) / (float)(OW - 1) : (float)w / (float)OW;
-    const size_t lds = gather_t_lds_bytes(h, w, OH, OW);
+    p.rows_max = gather_t_rows(h, OH, p.hscale);
+    const size_t lds = gather_t_lds_bytes(p.rows_max, w, OW);
     MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_t_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(upconv_gather_t_kernel, dim3((unsigned)(8 * ceil_div(B, 8) * (N / 8))), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(upconv_gather_t_kernel, dim3((unsigned)(N / 32), (unsigned)h, (unsigned)B), dim3(256), lds, s, p);
     MPSR_CHECK_LAUNCH("upconv_gather_t_kernel");
     // weight gradient of the tap GEMM, folded back into (N, 9 C)
     MPSR_CHECK_HIP(hipMemsetAsync(dwp, 0, (size_t)9 * N * C * sizeof(float), s));
