@@ -263,6 +263,20 @@ int mpsr_bias_grad(const float *dy, long long M, int N, float *db, mpsr_stream_t
 /* dx = dy where y > 0 else 0 (y = post-activation output of the layer).  dx may alias dy. */
 int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, mpsr_stream_t stream);
 
+/* The ReLU mask of a tensor as bits, and a 1x1 data gradient that leaves through it (training: a bottleneck unit's
+ * input gradient, TF autodiff of resnet_v1.py:104-135, without the elementwise ReLU-gradient pass over it).
+ * mpsr_relu_bitmask: bit (m & 31) of bits[(m >> 5) * N + n] = (y[m][n] > 0); bits holds mpsr_relu_bitmask_words(M, N)
+ * = ceil(M / 32) * N words, 16-byte aligned; N % 4 == 0.
+ * mpsr_conv1x1_masked_f32: y[m][n] = bit(m, n) ? sum_k x[m][k] w[n][k] + bias[n] + residual[m][n] : 0 (bias,
+ * residual may be NULL) on the persistent pointwise kernel; mpsr_conv1x1_masked_applies says whether the shape (and
+ * the arithmetic mode: fp32 only) is taken -- otherwise MPSR_ERR_UNSUPPORTED and the caller runs
+ * mpsr_conv2d_nhwc_f32 + mpsr_relu_grad.  Kept elements are bit-identical to the unmasked launch. */
+long long mpsr_relu_bitmask_words(long long M, int N);
+int mpsr_relu_bitmask(const float *y, long long M, int N, unsigned *bits, mpsr_stream_t stream);
+int mpsr_conv1x1_masked_applies(long long M, int K, int N);
+int mpsr_conv1x1_masked_f32(const float *x, long long M, int K, const float *w, const float *bias,
+                            const float *residual, const unsigned *mask, float *y, int N, mpsr_stream_t stream);
+
 /* Gradient of mpsr_max_pool w.r.t. its input (first maximum of each window takes the gradient); dx (B,H,W,C) is
  * fully overwritten. */
 int mpsr_max_pool_grad(const float *x, const float *dy, int B, int H, int W, int C, int k, int s, int pad_same,

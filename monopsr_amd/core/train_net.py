@@ -105,6 +105,7 @@ class TrainNet:
 
     # ------------------------------------------------------------------ forward pieces
     fused_units = True  # trunk(): bottleneck units as single autograd nodes (ops.BottleneckFn); False = layer by layer
+    linked_units = True  # ... and chained: a unit's input gradient leaves through the previous unit's ReLU mask
     fused_upsampled_convs = True  # squash_decoder(): resize -> conv pairs as one tap-GEMM operator, forward and backward
 
     def trunk(self, img, scope='crop'):
@@ -120,6 +121,7 @@ class TrainNet:
         x = ops.conv2d(cols, L[0]).reshape(B, oh, ow, L[0].cout)
         x = ops.max_pool(x, 3, 2, "SAME")
         li = 1
+        link = None  # (the first unit reads the max-pool's output: no ReLU mask belongs to its input gradient)
         for blk, units in enumerate((3, 4, 23)):
             for u in range(units):
                 shortcut = None
@@ -127,7 +129,11 @@ class TrainNet:
                     shortcut = L[li]
                     li += 1
                 if self.fused_units:  # one autograd node per unit: the two gradients of its input meet in a conv epilogue
-                    x = ops.bottleneck(x, L[li], L[li + 1], L[li + 2], shortcut)
+                    # consecutive units are linked: the tensor between them has no other reader, so a unit may hand
+                    # its input gradient over already masked by the previous unit's ReLU (ops.UnitLink)
+                    out_link = ops.UnitLink() if self.linked_units else None
+                    x = ops.bottleneck(x, L[li], L[li + 1], L[li + 2], shortcut, link, out_link)
+                    link = out_link
                 else:
                     residual = ops.conv2d(x, shortcut) if shortcut is not None else x
                     t = ops.conv2d(x, L[li])

@@ -215,6 +215,43 @@ __global__ __launch_bounds__(256) void dgrad_pack_kernel(const float *__restrict
     }
 }
 
+// ReLU mask of a tensor as bits: bit (m & 31) of bits[(m >> 5) * N + n] = (y[m][n] > 0); rows past M read as zero.
+// Consumed by the masked store path of the pointwise kernel (pointwise.hip): the data gradient of a 1x1 layer then
+// leaves already multiplied by the mask of the tensor it belongs to.  A thread owns 32 rows x 4 columns.
+__global__ __launch_bounds__(256) void relu_bitmask_kernel(const float *__restrict__ y, long long M, int N,
+                                                           unsigned *__restrict__ bits, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int groups = N >> 2;
+    const long long g = t / groups;
+    const int cg = (int)(t - g * groups);
+    const float4 *src = reinterpret_cast<const float4 *>(y) + (size_t)g * 32 * groups + cg;
+    const int rows = (int)min(32LL, M - g * 32);
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (rows == 32) {
+        float4 v[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) v[b] = src[(size_t)b * groups];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            w.x |= (v[b].x > 0.f ? 1u : 0u) << b;
+            w.y |= (v[b].y > 0.f ? 1u : 0u) << b;
+            w.z |= (v[b].z > 0.f ? 1u : 0u) << b;
+            w.w |= (v[b].w > 0.f ? 1u : 0u) << b;
+        }
+    } else {
+        for (int b = 0; b < rows; ++b) {
+            const float4 v = src[(size_t)b * groups];
+            w.x |= (v.x > 0.f ? 1u : 0u) << b;
+            w.y |= (v.y > 0.f ? 1u : 0u) << b;
+            w.z |= (v.z > 0.f ? 1u : 0u) << b;
+            w.w |= (v.w > 0.f ? 1u : 0u) << b;
+        }
+    }
+    reinterpret_cast<uint4 *>(bits)[(size_t)g * groups + cg] = w;
+}
+
 // Fused activation + bias gradient: g = (y > 0 ? dy : 0) (or g = dy when y == nullptr), written to dx (may be
 // nullptr when only the column sums are wanted), and db[n] += sum_m g[m][n].  One pass over dy: a thread owns one
 // float4 column group and strides over rows; column sums are combined across the workgroup in LDS, then one fp32
@@ -537,6 +574,44 @@ extern "C" int mpsr_act_bias_grad(const float *dy, const float *y, float *dx, fl
         MPSR_CHECK_LAUNCH("bias_grad_kernel");
     }
     return MPSR_OK;
+}
+
+namespace mpsr {
+bool pointwise_masked_applies(long long M, int K, int N);
+int conv1x1_pointwise_masked(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                             const unsigned *mask, float *y, int N, hipStream_t s);
+}  // namespace mpsr
+
+extern "C" long long mpsr_relu_bitmask_words(long long M, int N) { return M > 0 && N > 0 ? (M + 31) / 32 * N : 0; }
+
+extern "C" int mpsr_relu_bitmask(const float *y, long long M, int N, unsigned *bits, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(M >= 0 && N > 0 && N % 4 == 0, "relu_bitmask: N=%d must be a positive multiple of 4", N);
+    if (M == 0) return MPSR_OK;
+    MPSR_REQUIRE(y && bits && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bits & 15) == 0, "relu_bitmask: null or unaligned pointer");
+    const long long total = (M + 31) / 32 * (N / 4);
+    MPSR_REQUIRE((total + 255) / 256 < 0x7fffffffLL, "relu_bitmask: tensor too large");
+    hipLaunchKernelGGL(relu_bitmask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mpsr::as_stream(stream), y,
+                       M, N, bits, total);
+    MPSR_CHECK_LAUNCH("relu_bitmask_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_conv1x1_masked_applies(long long M, int K, int N)
+{
+    return mpsr_get_conv_math() == 0 && mpsr::pointwise_masked_applies(M, K, N) ? 1 : 0;
+}
+
+extern "C" int mpsr_conv1x1_masked_f32(const float *x, long long M, int K, const float *w, const float *bias,
+                                       const float *residual, const unsigned *mask, float *y, int N, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(M >= 0 && K > 0 && N > 0, "conv1x1_masked: bad shape");
+    if (M == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && w && mask && y, "conv1x1_masked: null pointer");
+    if (!mpsr_conv1x1_masked_applies(M, K, N))
+        return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv1x1_masked: shape M=%lld K=%d N=%d (or the arithmetic mode) is not taken; "
+                                                "ask mpsr_conv1x1_masked_applies first", M, K, N);
+    return mpsr::conv1x1_pointwise_masked(x, M, K, w, bias, residual, mask, y, N, mpsr::as_stream(stream));
 }
 
 extern "C" int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, mpsr_stream_t stream)

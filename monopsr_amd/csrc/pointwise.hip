@@ -85,11 +85,16 @@ struct PwsParams {
     const float *fw;
     float *fu;
     int fN, fC;
+    // MASK instantiations (training, data-gradient launches): bit (row & 31) of mask[(row >> 5) * N + column] says whether
+    // the output element is kept or written as zero -- the ReLU mask of the tensor this gradient belongs to
+    // (mpsr_relu_bitmask), applied in the store path instead of by an elementwise pass over the result
+    const unsigned *mask;
+    unsigned maskbytes;
 };
 
 // LONG: K >= 256 (eight or more stages: the stores of a tile are spread over the next tile's first eight); otherwise
 // four stages carry them.
-template <bool RES, bool LONG>
+template <bool RES, bool LONG, bool MASK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_conv_kernel(const PwsParams p)
 {
     using namespace pws;
@@ -194,7 +199,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float one = lane < 32 ? 1.f : 0.f;
     const float bias_k0 = lane < 32 ? bias : 0.f;  // wide form: the bias is the A operand (row index = channel), k = 0 only
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+    // MASK: the three mask words (32 rows x this lane's column) of the tile that accumulates in set S, requested when the
+    // tile starts and used a whole tile later; out_bits() = what a store writes for element (q, e) of a set
+    static_assert(!(MASK && WIDE), "the mask words follow the narrow accumulator layout");
+    unsigned mw[2][WT];
+    const unsigned mvoff = wave_live ? (unsigned)ncol * 4u : OOB;
+    auto load_mask = [&](auto set_c, int r0, bool live) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const __amdgpu_buffer_rsrc_t rr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(p.mask), 0, live ? (int)p.maskbytes : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < WT; ++q)
+            mw[S][q] = __builtin_amdgcn_raw_buffer_load_b32(rr, mvoff, (unsigned)((live ? r0 : 0) / 32 + q) * (unsigned)p.N * 4u, 0);
+    };
+    const unsigned mshift = 4u * (unsigned)(lane >> 5);
     f32x16 acc[2][WT];  // a tile accumulates in one set while the previous tile is stored from the other
+    auto out_bits = [&](auto set_c, int q, int e) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        if constexpr (MASK) {
+            const int keep = __builtin_amdgcn_sbfe((int)mw[S][q], mshift + (unsigned)((e & 3) + 8 * (e >> 2)), 1u);
+            const float v = acc[S][q][e];  // (bit_cast of the vector-element lvalue itself picks element 0)
+            return (unsigned)keep & __builtin_bit_cast(unsigned, v);
+        } else {
+            return __builtin_bit_cast(unsigned, fmaxf(acc[S][q][e], relu_lo));
+        }
+    };
 #pragma unroll
     for (int q = 0; q < WT; ++q)
 #pragma unroll
@@ -255,9 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (D % SSTEP == 1 && SE0 + D / SSTEP < 4 * WT) store_quad(IC<SET ^ 1>{}, SE0 + D / SSTEP, yp);
                     } else if constexpr (SE0 >= 0) if (D % SSTEP == 1 && SE0 + D / SSTEP < 16 * WT) {
                         const int q = (SE0 + D / SSTEP) / 16, e = (SE0 + D / SSTEP) % 16;
-                        __builtin_amdgcn_raw_buffer_store_b32(
-                            __builtin_bit_cast(unsigned, fmaxf(acc[SET ^ 1][q][e], relu_lo)),
-                            rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET ^ 1>{}, q, e),
+                                                              rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
                     }
 #endif
                     if (D >= 4 && D < 4 + 12 * WT && (D - 4) % 12 == 0) store_a(buf ^ 1, (D - 4) / 12);
@@ -319,6 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const RowRef xc = row_ref(p.x, p.K, r0c, true), xn = row_ref(p.x, p.K, r0n, nlive);
         const RowRef rn = row_ref(p.residual, p.N, r0n, nlive);
         const RowRef yp = row_ref(p.y, p.N, r0_of(i - 1), i > 0 && wave_live);
+        if constexpr (MASK) load_mask(IC<SET>{}, r0c, r0c < p.M);
         // the accumulators start from the residual (its LDS copy) ...
         if constexpr (WIDE) {
 #pragma unroll
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < WT; ++q)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[SET][q][e], relu_lo)),
+                    __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET>{}, q, e),
                                                           rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
         }
     };
@@ -548,12 +577,39 @@ bool pointwise_applies(long long M, int K, int N)
            M * K * 4 < 0x7f000000LL && M * N * 4 < 0xfffffff0LL && (long long)N * K * 4 < 0x7f000000LL;
 }
 
+// Shapes whose result can leave through a ReLU bit mask (conv1x1_pointwise_masked): the long-K instantiations
+bool pointwise_masked_applies(long long M, int K, int N)
+{
+    return !pws::WIDE && pointwise_applies(M, K, N) && K / pws::KS >= 8;
+}
+
+static int pointwise_launch(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                            int relu, const unsigned *mask, float *y, int N, hipStream_t s);
+
 int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias,
                              const float *residual, int relu, float *y, int N, hipStream_t s)
 {
-    using namespace pws;
     MPSR_REQUIRE(pointwise_applies(M, K, N), "conv1x1_pointwise: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
+    return pointwise_launch(x, M, K, w, bias, residual, relu, nullptr, y, N, s);
+}
+
+// y[m][n] = keep(m, n) ? sum_k x[m][k] w[n][k] + bias[n] + residual[m][n] : 0, keep = bit (m & 31) of
+// mask[(m >> 5) * N + n] ((M + 31) / 32 * N words, mpsr_relu_bitmask)
+int conv1x1_pointwise_masked(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                             const unsigned *mask, float *y, int N, hipStream_t s)
+{
+    MPSR_REQUIRE(pointwise_masked_applies(M, K, N), "conv1x1_pointwise_masked: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
+    MPSR_REQUIRE(mask, "conv1x1_pointwise_masked: null mask");
+    return pointwise_launch(x, M, K, w, bias, residual, 0, mask, y, N, s);
+}
+
+static int pointwise_launch(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                            int relu, const unsigned *mask, float *y, int N, hipStream_t s)
+{
+    using namespace pws;
     PwsParams p;
+    p.mask = mask;
+    p.maskbytes = (unsigned)(((M + 31) / 32) * N * 4);
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y;
     p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
     p.rgroups = (int)((M + ROWS - 1) / ROWS);
@@ -583,12 +639,20 @@ int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const 
     if (p.fw) g_filter_tail_done = g_filter_tail_job;
     g_filter_tail_job = FilterTailJob();
     const size_t lds_bytes = (size_t)LDS_B;
-#define MPSR_PW(RES_, LONG_)                                                                                          \
+#define MPSR_PW(...)                                                                                                  \
     do {                                                                                                              \
-        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<RES_, LONG_>),               \
+        MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<__VA_ARGS__>),               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
-        hipLaunchKernelGGL((pw_conv_kernel<RES_, LONG_>), dim3(grid), dim3(256), lds_bytes, s, p);                    \
+        hipLaunchKernelGGL((pw_conv_kernel<__VA_ARGS__>), dim3(grid), dim3(256), lds_bytes, s, p);                    \
     } while (0)
+#if !PWS_WIDE
+    if (mask) {
+        if (residual) MPSR_PW(true, true, true);
+        else MPSR_PW(false, true, true);
+        MPSR_CHECK_LAUNCH("pw_conv_kernel");
+        return MPSR_OK;
+    }
+#endif
     if (K / KS >= 8) {
         if (residual) MPSR_PW(true, true);
         else MPSR_PW(false, true);

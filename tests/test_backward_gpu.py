@@ -345,6 +345,84 @@ def test_bottleneck_units_as_one_autograd_node_give_the_same_gradients():
         assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max() + 1e-30), n
 
 
+@pytest.mark.parametrize("M,K,N,res", [(256 * 144, 256, 1024, True), (5 * 96 + 17, 1024, 256, False),
+                                       (3 * 144, 256, 512, True)])
+def test_masked_pointwise_data_gradient_is_the_unmasked_one_times_the_relu_mask(M, K, N, res):
+    """mpsr_relu_bitmask + mpsr_conv1x1_masked_f32 (the masked store path of the persistent pointwise kernel): kept
+    elements are BIT-identical to the plain launch, the others exactly zero -- i.e. conv -> mpsr_relu_grad in one
+    launch.  Ragged M (not a multiple of 32 or of the 96-row tile) included."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    lib = _lib.lib()
+    rng = np.random.default_rng(M + K + N)
+    x = _dev(rng.standard_normal((1, 1, M, K)).astype(np.float32))
+    w = _dev((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    r = _dev(rng.standard_normal((1, 1, M, N)).astype(np.float32)) if res else None
+    act = _dev(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))  # the post-ReLU tensor the mask is of
+    assert lib.mpsr_conv1x1_masked_applies(M, K, N) == 1
+    bits = torch.zeros((lib.mpsr_relu_bitmask_words(M, N),), dtype=torch.int32, device="cuda")
+    _lib.check(lib.mpsr_relu_bitmask(_lib.ptr(act), M, N, _lib.ptr(bits), _lib.stream()))
+    got = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(lib.mpsr_conv1x1_masked_f32(_lib.ptr(x), M, K, _lib.ptr(w), None, _lib.ptr(r), _lib.ptr(bits),
+                                           _lib.ptr(got), N, _lib.stream()))
+    lib.mpsr_debug_set_conv_pointwise(1)  # (few rows would otherwise go to the implicit GEMM: another summation order)
+    try:
+        plain = dn.conv2d(x, w, None, r, 1, 1, 1, False, split_k=0).reshape(M, N)
+    finally:
+        lib.mpsr_debug_set_conv_pointwise(-1)
+    want = torch.where(act > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(got, want)
+    # the bit layout the header documents
+    b = bits.cpu().numpy().view(np.uint32).reshape(-1, N)
+    a = act.cpu().numpy() > 0
+    for m in (0, 31, 32, M - 1):
+        assert np.array_equal((b[m >> 5] >> (m & 31)) & 1, a[m].astype(np.uint32)), m
+    assert lib.mpsr_conv1x1_masked_applies(M, 128, N) == 0  # short K: the caller keeps conv + relu_grad
+    rc = lib.mpsr_conv1x1_masked_f32(_lib.ptr(x), M, 128, _lib.ptr(w), None, None, _lib.ptr(bits), _lib.ptr(got), N,
+                                     _lib.stream())
+    assert rc != 0 and b"masked" in lib.mpsr_last_error()
+
+
+def test_linked_bottleneck_units_give_the_same_gradients():
+    """TrainNet.trunk chains its bottleneck units (autograd_ops.UnitLink): a unit's input gradient leaves conv1's
+    data-gradient launch already masked by the previous unit's ReLU, and that unit skips its elementwise pass.  Full
+    width (the masked launch takes K >= 256), two crops: every parameter gradient and the image-side gradient must
+    equal the unlinked graph's (kept elements are bit-identical; wgrad slices meet in fp32 atomics: 1e-5 of the scale)."""
+    from monopsr_amd.core import autograd_ops, train_net
+    from monopsr_amd.core import weights as W
+    B = 2
+    net = train_net.TrainNet(W.synthetic_weights(seed=81, heads=False), with_heads=False)
+    rng = np.random.default_rng(82)
+    crops = _dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32))
+    taken = []
+    orig = autograd_ops._data_grad_masked
+
+    def counting(L, g, x, residual):
+        dx = orig(L, g, x, residual)
+        taken.append(dx is not None)
+        return dx
+    autograd_ops._data_grad_masked = counting
+    out = {}
+    try:
+        for linked in (True, False):
+            net.linked_units = linked
+            net.zero_grad()
+            feat = net.trunk(crops)
+            (feat * feat).sum().backward()
+            torch.cuda.synchronize()
+            out[linked] = (feat.detach().clone(), net.grads.clone())
+    finally:
+        autograd_ops._data_grad_masked = orig
+        net.linked_units = True
+    assert sum(taken) == 23, taken  # every unit of block3 (conv1 has 256 outputs: K = 256); blocks 1-2 are narrower
+    assert torch.equal(out[True][0], out[False][0])
+    g1, g0 = out[True][1], out[False][1]
+    for n, L in enumerate(net.layers[:net.n_trunk]):
+        lo = (L.dw.data_ptr() - net.grads.data_ptr()) // 4
+        a, b_ = g1[lo:lo + L.dw.numel()], g0[lo:lo + L.dw.numel()]
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max() + 1e-30), n
+
+
 def test_instance_trainer_step_reduces_loss():
     """Full training step on a 1/4-width copy: heads included (method-by-method output builder over differentiable
     FC layers), the reference's configured loss set (monopsr_model.py:554-958), per-variable clip, Adam; the loss

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--unlinked-units", action="store_true",
+                    help="A/B: bottleneck units not chained (every unit runs its own ReLU-gradient pass)")
     ap.add_argument("--decoder-bn", default="batch", choices=["batch", "frozen"],
                     help="map-decoder BatchNorm: batch statistics as in the reference's training graph (default), or "
                          "frozen moving statistics folded into the convolutions")
@@ -51,6 +53,7 @@ def main():
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn)
+    net.linked_units = not args.unlinked_units
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
