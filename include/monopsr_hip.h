@@ -265,15 +265,21 @@ int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, 
 
 /* The ReLU mask of a tensor as bits, and a 1x1 data gradient that leaves through it (training: a bottleneck unit's
  * input gradient, TF autodiff of resnet_v1.py:104-135, without the elementwise ReLU-gradient pass over it).
- * mpsr_relu_bitmask: bit (m & 31) of bits[(m >> 5) * N + n] = (y[m][n] > 0); bits holds mpsr_relu_bitmask_words(M, N)
- * = ceil(M / 32) * N words, 16-byte aligned; N % 4 == 0.
+ * Layout: bits[(m >> 5) * N + n], bit b <-> row m = 32 (m >> 5) + (b & 3) + 8 ((b >> 2) & 3) + 4 (b >> 4) -- the
+ * accumulator layout of the 32x32 MFMA, so that a convolution can write the words from its epilogue;
+ * mpsr_relu_bitmask_words(M, N) = ceil(M / 32) * N words, 16-byte aligned; N % 4 == 0.
+ * mpsr_relu_bitmask: the words of y (M,N): bit = (y[m][n] > 0), rows >= M zero.
+ * mpsr_conv1x1_relu_bitmask_f32: y = act(x w^T + bias + residual) on the persistent pointwise kernel AND the words
+ * of y in the same launch (bits of rows >= M unspecified); y is bit-identical to mpsr_conv2d_nhwc_f32's.
  * mpsr_conv1x1_masked_f32: y[m][n] = bit(m, n) ? sum_k x[m][k] w[n][k] + bias[n] + residual[m][n] : 0 (bias,
- * residual may be NULL) on the persistent pointwise kernel; mpsr_conv1x1_masked_applies says whether the shape (and
- * the arithmetic mode: fp32 only) is taken -- otherwise MPSR_ERR_UNSUPPORTED and the caller runs
- * mpsr_conv2d_nhwc_f32 + mpsr_relu_grad.  Kept elements are bit-identical to the unmasked launch. */
+ * residual may be NULL); kept elements are bit-identical to the unmasked launch.
+ * mpsr_conv1x1_masked_applies says whether the shape (and the arithmetic mode: fp32 only) is taken by the last two --
+ * otherwise MPSR_ERR_UNSUPPORTED and the caller runs mpsr_conv2d_nhwc_f32 (+ mpsr_relu_grad). */
 long long mpsr_relu_bitmask_words(long long M, int N);
 int mpsr_relu_bitmask(const float *y, long long M, int N, unsigned *bits, mpsr_stream_t stream);
 int mpsr_conv1x1_masked_applies(long long M, int K, int N);
+int mpsr_conv1x1_relu_bitmask_f32(const float *x, long long M, int K, const float *w, const float *bias,
+                                  const float *residual, int relu, float *y, unsigned *bits, int N, mpsr_stream_t stream);
 int mpsr_conv1x1_masked_f32(const float *x, long long M, int K, const float *w, const float *bias,
                             const float *residual, const unsigned *mask, float *y, int N, mpsr_stream_t stream);
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "mpsr_relu_bitmask": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
     "mpsr_conv1x1_masked_applies": (c_i, [ctypes.c_longlong, c_i, c_i]),
     "mpsr_conv1x1_masked_f32": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f]),
+    "mpsr_conv1x1_relu_bitmask_f32": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f]),
     "mpsr_max_pool_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_resize_bilinear_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -140,23 +140,39 @@ class UnitLink:
 
     def __init__(self):
         self.premasked = False
+        self.bits = None  # the ReLU bit mask of the tensor between the units, written by the earlier unit's conv3 launch
 
 
 _MASK_SCRATCH = {}
 
 
-def _data_grad_masked(L, g, x, residual):
+def _conv1x1_with_mask(x, L, residual):
+    """y = L(x) + residual through ReLU AND the bit mask of y from the same launch (mpsr_conv1x1_relu_bitmask_f32), or
+    None when that launch does not take the layer."""
+    lib = _lib.lib()
+    B, H, W, C = x.shape
+    M, N = B * H * W, L.cout
+    if L.kh != 1 or L.kw != 1 or not L.relu or not lib.mpsr_conv1x1_masked_applies(M, C, N):
+        return None
+    y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    bits = torch.empty((lib.mpsr_relu_bitmask_words(M, N),), dtype=torch.int32, device=x.device)
+    _lib.check(lib.mpsr_conv1x1_relu_bitmask_f32(_lib.ptr(x), M, C, _lib.ptr(L.w), _lib.ptr(L.b), _lib.ptr(residual), 1,
+                                                 _lib.ptr(y), _lib.ptr(bits), N, _lib.stream()))
+    return y, bits
+
+
+def _data_grad_masked(L, g, x, residual, bits=None):
     """dX of the 1x1 layer L times the ReLU mask of x (= L's post-ReLU input), or None when the masked pointwise launch
-    does not take the shape: mpsr_relu_bitmask(x) -> mpsr_conv1x1_masked_f32."""
+    does not take the shape: mpsr_relu_bitmask(x) (unless the producer of x left its `bits`) -> mpsr_conv1x1_masked_f32."""
     lib = _lib.lib()
     C, N = x.shape[3], L.cout
     M = x.numel() // C
     if L.kh != 1 or L.kw != 1 or N % 4 or not lib.mpsr_conv1x1_masked_applies(M, N, C):
         return None
     s = _lib.stream()
-    words = lib.mpsr_relu_bitmask_words(M, C)
-    bits = dn.stream_scratch(_MASK_SCRATCH, x.device, words)
-    _lib.check(lib.mpsr_relu_bitmask(_lib.ptr(x), M, C, _lib.ptr(bits), s))
+    if bits is None:
+        bits = dn.stream_scratch(_MASK_SCRATCH, x.device, lib.mpsr_relu_bitmask_words(M, C))
+        _lib.check(lib.mpsr_relu_bitmask(_lib.ptr(x), M, C, _lib.ptr(bits), s))
     wd = torch.empty((C, N), dtype=torch.float32, device=g.device)
     _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(L.w), N, 1, 1, C, _lib.ptr(wd), s))
     dx = torch.empty_like(x)
@@ -181,7 +197,12 @@ class BottleneckFn(torch.autograd.Function):
         res = dn.conv2d(x, sc.w, sc.b, None, sc.kh, sc.kw, sc.dilation, sc.relu, split_k=_SCHED) if sc is not None else x
         t1 = dn.conv2d(x, c1.w, c1.b, None, c1.kh, c1.kw, c1.dilation, c1.relu, split_k=_SCHED)
         t2 = dn.conv2d(t1, c2.w, c2.b, None, c2.kh, c2.kw, c2.dilation, c2.relu, split_k=_SCHED)
-        y = dn.conv2d(t2, c3.w, c3.b, res, c3.kh, c3.kw, c3.dilation, c3.relu, split_k=_SCHED)
+        # (a linked unit's conv3 launch also leaves the bit mask of y for the next unit's backward)
+        ym = _conv1x1_with_mask(t2, c3, res.contiguous()) if out_link is not None else None
+        if ym is not None:
+            y, out_link.bits = ym
+        else:
+            y = dn.conv2d(t2, c3.w, c3.b, res, c3.kh, c3.kw, c3.dilation, c3.relu, split_k=_SCHED)
         ctx.layers = (c1, c2, c3, sc)
         ctx.links = (in_link, out_link)
         ctx.save_for_backward(x, t1, t2, y)
@@ -198,7 +219,9 @@ class BottleneckFn(torch.autograd.Function):
         else:
             g3 = _masked_grad(c3, dy, y)  # also the gradient that enters the shortcut branch
         _deposit_weight_grad(c3, t2, g3)
-        g2 = _masked_grad(c2, _data_grad(c3, g3, t2.shape[3]), t2)
+        g2 = _data_grad_masked(c3, g3, t2, None) if c2.relu else None  # conv3's data gradient through conv2's ReLU mask
+        if g2 is None:
+            g2 = _masked_grad(c2, _data_grad(c3, g3, t2.shape[3]), t2)
         _deposit_weight_grad(c2, t1, g2)
         g1 = _masked_grad(c1, _data_grad(c2, g2, t1.shape[3]), t1)
         _deposit_weight_grad(c1, x, g1)
@@ -211,8 +234,9 @@ class BottleneckFn(torch.autograd.Function):
                 residual = _data_grad(sc, gs, x.shape[3])
         if ctx.needs_input_grad[0]:
             if in_link is not None:
-                dx = _data_grad_masked(c1, g1, x, residual)
+                dx = _data_grad_masked(c1, g1, x, residual, in_link.bits)
                 in_link.premasked = dx is not None
+                in_link.bits = None
             if dx is None:
                 dx = _data_grad(c1, g1, x.shape[3], residual=residual)
         return dx, None, None, None, None, None, None, None

@@ -215,9 +215,13 @@ __global__ __launch_bounds__(256) void dgrad_pack_kernel(const float *__restrict
     }
 }
 
-// ReLU mask of a tensor as bits: bit (m & 31) of bits[(m >> 5) * N + n] = (y[m][n] > 0); rows past M read as zero.
-// Consumed by the masked store path of the pointwise kernel (pointwise.hip): the data gradient of a 1x1 layer then
-// leaves already multiplied by the mask of the tensor it belongs to.  A thread owns 32 rows x 4 columns.
+// ReLU mask of a tensor as bits: bit b of bits[(m >> 5) * N + n] = (y[m][n] > 0) for m = 32 (m >> 5) + mask_row(b);
+// rows past M read as zero.  mask_row(b) = (b & 3) + 8 ((b >> 2) & 3) + 4 (b >> 4) is the accumulator layout of the
+// 32x32 MFMA (a lane's 16 elements of a 32-row block are one halfword), so that the pointwise kernel (pointwise.hip) can
+// write the same words from its forward epilogue and apply them in the store path of a data-gradient launch: the
+// gradient then leaves already multiplied by the mask of the tensor it belongs to.  A thread owns 32 rows x 4 columns.
+__device__ __forceinline__ int mask_row(int b) { return (b & 3) + 8 * ((b >> 2) & 3) + 4 * (b >> 4); }
+
 __global__ __launch_bounds__(256) void relu_bitmask_kernel(const float *__restrict__ y, long long M, int N,
                                                            unsigned *__restrict__ bits, long long total)
 {
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void relu_bitmask_kernel(const float *__restri
     if (rows == 32) {
         float4 v[32];
 #pragma unroll
-        for (int b = 0; b < 32; ++b) v[b] = src[(size_t)b * groups];
+        for (int b = 0; b < 32; ++b) v[b] = src[(size_t)mask_row(b) * groups];
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
             w.x |= (v[b].x > 0.f ? 1u : 0u) << b;
@@ -241,8 +245,9 @@ __global__ __launch_bounds__(256) void relu_bitmask_kernel(const float *__restri
             w.w |= (v[b].w > 0.f ? 1u : 0u) << b;
         }
     } else {
-        for (int b = 0; b < rows; ++b) {
-            const float4 v = src[(size_t)b * groups];
+        for (int b = 0; b < 32; ++b) {
+            if (mask_row(b) >= rows) continue;
+            const float4 v = src[(size_t)mask_row(b) * groups];
             w.x |= (v.x > 0.f ? 1u : 0u) << b;
             w.y |= (v.y > 0.f ? 1u : 0u) << b;
             w.z |= (v.z > 0.f ? 1u : 0u) << b;
@@ -580,6 +585,8 @@ namespace mpsr {
 bool pointwise_masked_applies(long long M, int K, int N);
 int conv1x1_pointwise_masked(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
                              const unsigned *mask, float *y, int N, hipStream_t s);
+int conv1x1_pointwise_emit(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                           int relu, float *y, unsigned *bits, int N, hipStream_t s);
 }  // namespace mpsr
 
 extern "C" long long mpsr_relu_bitmask_words(long long M, int N) { return M > 0 && N > 0 ? (M + 31) / 32 * N : 0; }
@@ -612,6 +619,19 @@ extern "C" int mpsr_conv1x1_masked_f32(const float *x, long long M, int K, const
         return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv1x1_masked: shape M=%lld K=%d N=%d (or the arithmetic mode) is not taken; "
                                                 "ask mpsr_conv1x1_masked_applies first", M, K, N);
     return mpsr::conv1x1_pointwise_masked(x, M, K, w, bias, residual, mask, y, N, mpsr::as_stream(stream));
+}
+
+extern "C" int mpsr_conv1x1_relu_bitmask_f32(const float *x, long long M, int K, const float *w, const float *bias,
+                                             const float *residual, int relu, float *y, unsigned *bits, int N,
+                                             mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(M >= 0 && K > 0 && N > 0, "conv1x1_relu_bitmask: bad shape");
+    if (M == 0) return MPSR_OK;
+    MPSR_REQUIRE(x && w && bits && y, "conv1x1_relu_bitmask: null pointer");
+    if (!mpsr_conv1x1_masked_applies(M, K, N))
+        return mpsr::fail(MPSR_ERR_UNSUPPORTED, "conv1x1_relu_bitmask: shape M=%lld K=%d N=%d (or the arithmetic mode) is not "
+                                                "taken; ask mpsr_conv1x1_masked_applies first", M, K, N);
+    return mpsr::conv1x1_pointwise_emit(x, M, K, w, bias, residual, relu, y, bits, N, mpsr::as_stream(stream));
 }
 
 extern "C" int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, mpsr_stream_t stream)

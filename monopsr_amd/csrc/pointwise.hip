@@ -85,16 +85,21 @@ struct PwsParams {
     const float *fw;
     float *fu;
     int fN, fC;
-    // MASK instantiations (training, data-gradient launches): bit (row & 31) of mask[(row >> 5) * N + column] says whether
-    // the output element is kept or written as zero -- the ReLU mask of the tensor this gradient belongs to
-    // (mpsr_relu_bitmask), applied in the store path instead of by an elementwise pass over the result
+    // MASK instantiations (training, data-gradient launches): a bit of mask[(row >> 5) * N + column] says whether the
+    // output element is kept or written as zero -- the ReLU mask of the tensor this gradient belongs to, applied in the
+    // store path instead of by an elementwise pass over the result.  Bit b of a word <-> row 32 g + (b & 3) +
+    // 8 ((b >> 2) & 3) + 4 (b >> 4): the accumulator layout of v_mfma_f32_32x32x2_f32 (lane half h = b >> 4 holds element
+    // e = b & 15), so a lane's 16 elements of a 32-row tile are one halfword.
+    // EMIT instantiations (training, forward launches): the same words written for THIS launch's result (y > 0), one
+    // 2-byte store per lane and 32 x 32 block, so that no pass has to read y back to make them (mpsr_relu_bitmask).
     const unsigned *mask;
+    unsigned *emit;
     unsigned maskbytes;
 };
 
 // LONG: K >= 256 (eight or more stages: the stores of a tile are spread over the next tile's first eight); otherwise
 // four stages carry them.
-template <bool RES, bool LONG, bool MASK = false>
+template <bool RES, bool LONG, bool MASK = false, bool EMIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_conv_kernel(const PwsParams p)
 {
     using namespace pws;
@@ -212,17 +217,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < WT; ++q)
             mw[S][q] = __builtin_amdgcn_raw_buffer_load_b32(rr, mvoff, (unsigned)((live ? r0 : 0) / 32 + q) * (unsigned)p.N * 4u, 0);
     };
-    const unsigned mshift = 4u * (unsigned)(lane >> 5);
+    const unsigned mshift = 16u * (unsigned)(lane >> 5);
+    unsigned mb[2][WT];  // EMIT: the halfword of set S's tile gathering while its elements are stored
+    const unsigned emvoff = wave_live ? (unsigned)ncol * 4u + 2u * (unsigned)(lane >> 5) : OOB;
     f32x16 acc[2][WT];  // a tile accumulates in one set while the previous tile is stored from the other
     auto out_bits = [&](auto set_c, int q, int e) __attribute__((always_inline)) {
         constexpr int S = decltype(set_c)::value;
         if constexpr (MASK) {
-            const int keep = __builtin_amdgcn_sbfe((int)mw[S][q], mshift + (unsigned)((e & 3) + 8 * (e >> 2)), 1u);
+            const int keep = __builtin_amdgcn_sbfe((int)mw[S][q], mshift + (unsigned)e, 1u);
             const float v = acc[S][q][e];  // (bit_cast of the vector-element lvalue itself picks element 0)
             return (unsigned)keep & __builtin_bit_cast(unsigned, v);
         } else {
-            return __builtin_bit_cast(unsigned, fmaxf(acc[S][q][e], relu_lo));
+            const float v = fmaxf(acc[S][q][e], relu_lo);
+            if constexpr (EMIT) mb[S][q] = (e ? mb[S][q] : 0u) | (v > 0.f ? 1u << e : 0u);
+            return __builtin_bit_cast(unsigned, v);
         }
+    };
+    // EMIT: after element 15 of block q of the tile at row r0 the halfword is complete
+    auto emit_bits = [&](auto set_c, int q, int r0, bool live) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const __amdgpu_buffer_rsrc_t rr =
+            __builtin_amdgcn_make_buffer_rsrc(p.emit, 0, live ? (int)p.maskbytes : 0, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b16((short)mb[S][q], rr, emvoff, (unsigned)((live ? r0 : 0) / 32 + q) * (unsigned)p.N * 4u, 0);
     };
 #pragma unroll
     for (int q = 0; q < WT; ++q)
@@ -251,7 +267,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the stores issued before it, and those complete sooner the thinner they are spread (12 KB per wave in one burst
     // behind the K loop held the wave for 9000 cycles; over three stages the stages after them took 3x as long).
     auto stage_body = [&](auto set_c, auto buf_c, auto duty_c, auto se0_c, auto sstep_c, int s, RowRef xc, bool clive,
-                          RowRef xn, bool nlive, RowRef rn, RowRef yp) __attribute__((always_inline)) {
+                          RowRef xn, bool nlive, RowRef rn, RowRef yp, int r0p = 0, bool plive = false)
+                          __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, buf = decltype(buf_c)::value, DUTY = decltype(duty_c)::value,
                       SE0 = decltype(se0_c)::value, SSTEP = decltype(sstep_c)::value;
         read_a(buf, 0, 0);
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int q = (SE0 + D / SSTEP) / 16, e = (SE0 + D / SSTEP) % 16;
                         __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET ^ 1>{}, q, e),
                                                               rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+                        if constexpr (EMIT) if (e == 15) emit_bits(IC<SET ^ 1>{}, q, r0p, plive);
                     }
 #endif
                     if (D >= 4 && D < 4 + 12 * WT && (D - 4) % 12 == 0) store_a(buf ^ 1, (D - 4) / 12);
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // stage (s, buffer s & 1, residual duty, first stored element, slots per store)
 #define PWS_STAGE(S_, DUTY_, SE0_, SSTEP_)                                                                            \
-    stage_body(IC<SET>{}, IC<(S_) & 1>{}, IC<DUTY_>{}, IC<SE0_>{}, IC<SSTEP_>{}, S_, xc, true, xn, nlive, rn, yp);    \
+    stage_body(IC<SET>{}, IC<(S_) & 1>{}, IC<DUTY_>{}, IC<SE0_>{}, IC<SSTEP_>{}, S_, xc, true, xn, nlive, rn, yp,     \
+               r0_of(i - 1), i > 0 && r0_of(i - 1) < p.M);                                                            \
     __syncthreads()
         if constexpr (WIDE) {
             // 12 quad stores: PWS_WSTEP slots apart (48 / PWS_WSTEP per stage) over the first stages; the residual duties
@@ -455,8 +474,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < WT; ++q)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
+                {
                     __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET>{}, q, e),
                                                           rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+                    if constexpr (EMIT) if (e == 15) emit_bits(IC<SET>{}, q, r0s, r0s < p.M);
+                }
         }
     };
     if (last & 1) finish(IC<1>{});  // block-uniform
@@ -584,13 +606,22 @@ bool pointwise_masked_applies(long long M, int K, int N)
 }
 
 static int pointwise_launch(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
-                            int relu, const unsigned *mask, float *y, int N, hipStream_t s);
+                            int relu, const unsigned *mask, unsigned *emit, float *y, int N, hipStream_t s);
 
 int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias,
                              const float *residual, int relu, float *y, int N, hipStream_t s)
 {
     MPSR_REQUIRE(pointwise_applies(M, K, N), "conv1x1_pointwise: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
-    return pointwise_launch(x, M, K, w, bias, residual, relu, nullptr, y, N, s);
+    return pointwise_launch(x, M, K, w, bias, residual, relu, nullptr, nullptr, y, N, s);
+}
+
+// conv1x1_pointwise that also writes the ReLU bit mask of its result (bits of rows >= M unspecified)
+int conv1x1_pointwise_emit(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
+                           int relu, float *y, unsigned *bits, int N, hipStream_t s)
+{
+    MPSR_REQUIRE(pointwise_masked_applies(M, K, N), "conv1x1_pointwise_emit: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
+    MPSR_REQUIRE(bits, "conv1x1_pointwise_emit: null mask");
+    return pointwise_launch(x, M, K, w, bias, residual, relu, nullptr, bits, y, N, s);
 }
 
 // y[m][n] = keep(m, n) ? sum_k x[m][k] w[n][k] + bias[n] + residual[m][n] : 0, keep = bit (m & 31) of
@@ -600,15 +631,16 @@ int conv1x1_pointwise_masked(const float *x, long long M, int K, const float *w,
 {
     MPSR_REQUIRE(pointwise_masked_applies(M, K, N), "conv1x1_pointwise_masked: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
     MPSR_REQUIRE(mask, "conv1x1_pointwise_masked: null mask");
-    return pointwise_launch(x, M, K, w, bias, residual, 0, mask, y, N, s);
+    return pointwise_launch(x, M, K, w, bias, residual, 0, mask, nullptr, y, N, s);
 }
 
 static int pointwise_launch(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
-                            int relu, const unsigned *mask, float *y, int N, hipStream_t s)
+                            int relu, const unsigned *mask, unsigned *emit, float *y, int N, hipStream_t s)
 {
     using namespace pws;
     PwsParams p;
     p.mask = mask;
+    p.emit = emit;
     p.maskbytes = (unsigned)(((M + 31) / 32) * N * 4);
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y;
     p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
@@ -646,9 +678,11 @@ static int pointwise_launch(const float *x, long long M, int K, const float *w, 
         hipLaunchKernelGGL((pw_conv_kernel<__VA_ARGS__>), dim3(grid), dim3(256), lds_bytes, s, p);                    \
     } while (0)
 #if !PWS_WIDE
-    if (mask) {
-        if (residual) MPSR_PW(true, true, true);
-        else MPSR_PW(false, true, true);
+    if (mask || emit) {
+        if (mask && residual) MPSR_PW(true, true, true);
+        else if (mask) MPSR_PW(false, true, true);
+        else if (residual) MPSR_PW(true, true, false, true);
+        else MPSR_PW(false, true, false, true);
         MPSR_CHECK_LAUNCH("pw_conv_kernel");
         return MPSR_OK;
     }

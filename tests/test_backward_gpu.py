@@ -372,11 +372,37 @@ def test_masked_pointwise_data_gradient_is_the_unmasked_one_times_the_relu_mask(
         lib.mpsr_debug_set_conv_pointwise(-1)
     want = torch.where(act > 0, plain, torch.zeros_like(plain))
     assert torch.equal(got, want)
-    # the bit layout the header documents
+    # the bit layout the header documents: bit b <-> row 32 g + (b & 3) + 8 ((b >> 2) & 3) + 4 (b >> 4)
     b = bits.cpu().numpy().view(np.uint32).reshape(-1, N)
     a = act.cpu().numpy() > 0
-    for m in (0, 31, 32, M - 1):
-        assert np.array_equal((b[m >> 5] >> (m & 31)) & 1, a[m].astype(np.uint32)), m
+    row_of = [(bb & 3) + 8 * ((bb >> 2) & 3) + 4 * (bb >> 4) for bb in range(32)]
+    assert sorted(row_of) == list(range(32))
+    for m in (0, 1, 4, 31, 32, 37, M - 1):
+        bb = row_of.index(m & 31)
+        assert np.array_equal((b[m >> 5] >> bb) & 1, a[m].astype(np.uint32)), m
+    # ... and the forward launch that writes the words of its own result: y bit-identical to the plain launch, the
+    # words equal to mpsr_relu_bitmask(y) on the rows that exist
+    bias = _dev(rng.standard_normal(N).astype(np.float32))
+    y2 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    bits2 = torch.zeros_like(bits)
+    _lib.check(lib.mpsr_conv1x1_relu_bitmask_f32(_lib.ptr(x), M, K, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(r), 1,
+                                                 _lib.ptr(y2), _lib.ptr(bits2), N, _lib.stream()))
+    lib.mpsr_debug_set_conv_pointwise(1)
+    try:
+        y_plain = dn.conv2d(x, w, bias, r, 1, 1, 1, True, split_k=0).reshape(M, N)
+    finally:
+        lib.mpsr_debug_set_conv_pointwise(-1)
+    assert torch.equal(y2, y_plain)
+    bits3 = torch.zeros_like(bits)
+    _lib.check(lib.mpsr_relu_bitmask(_lib.ptr(y_plain), M, N, _lib.ptr(bits3), _lib.stream()))
+    b2 = bits2.cpu().numpy().view(np.uint32).reshape(-1, N)
+    b3 = bits3.cpu().numpy().view(np.uint32).reshape(-1, N)
+    valid = np.zeros(32, dtype=np.uint32)  # bits of the last word group whose rows exist
+    for bb in range(32):
+        valid[bb] = 1 if (M - 1) // 32 * 32 + row_of[bb] < M else 0
+    vmask = np.uint32(sum(int(v) << i for i, v in enumerate(valid)))
+    assert np.array_equal(b2[:-1], b3[:-1]) and np.array_equal(b2[-1] & vmask, b3[-1])
+    assert 0.2 < float((y_plain > 0).float().mean()) < 0.8
     assert lib.mpsr_conv1x1_masked_applies(M, 128, N) == 0  # short K: the caller keeps conv + relu_grad
     rc = lib.mpsr_conv1x1_masked_f32(_lib.ptr(x), M, 128, _lib.ptr(w), None, None, _lib.ptr(bits), _lib.ptr(got), N,
                                      _lib.stream())
@@ -387,22 +413,29 @@ def test_linked_bottleneck_units_give_the_same_gradients():
     """TrainNet.trunk chains its bottleneck units (autograd_ops.UnitLink): a unit's input gradient leaves conv1's
     data-gradient launch already masked by the previous unit's ReLU, and that unit skips its elementwise pass.  Full
     width (the masked launch takes K >= 256), two crops: every parameter gradient and the image-side gradient must
-    equal the unlinked graph's (kept elements are bit-identical; wgrad slices meet in fp32 atomics: 1e-5 of the scale)."""
+    equal the unlinked graph's."""
+    from monopsr_amd import _lib
     from monopsr_amd.core import autograd_ops, train_net
     from monopsr_amd.core import weights as W
     B = 2
     net = train_net.TrainNet(W.synthetic_weights(seed=81, heads=False), with_heads=False)
     rng = np.random.default_rng(82)
     crops = _dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32))
-    taken = []
+    taken, emitted = [], []
     orig = autograd_ops._data_grad_masked
 
-    def counting(L, g, x, residual):
-        dx = orig(L, g, x, residual)
-        taken.append(dx is not None)
+    def counting(L, g, x, residual, bits=None):
+        dx = orig(L, g, x, residual, bits)
+        if residual is not None:  # conv1's data gradient + the shortcut's (conv3's goes through conv2's mask: no residual)
+            taken.append(dx is not None)
+            emitted.append(bits is not None)
         return dx
     autograd_ops._data_grad_masked = counting
     out = {}
+    # (at two crops the library would send the unlinked graph's 1x1 layers to the implicit GEMM -- another summation
+    # order than the pointwise kernel the mask-writing launch is; with the pointwise kernel wherever it applies both
+    # graphs run the same launches and the forward must be bit-identical)
+    _lib.lib().mpsr_debug_set_conv_pointwise(1)
     try:
         for linked in (True, False):
             net.linked_units = linked
@@ -412,15 +445,17 @@ def test_linked_bottleneck_units_give_the_same_gradients():
             torch.cuda.synchronize()
             out[linked] = (feat.detach().clone(), net.grads.clone())
     finally:
+        _lib.lib().mpsr_debug_set_conv_pointwise(-1)
         autograd_ops._data_grad_masked = orig
         net.linked_units = True
     assert sum(taken) == 23, taken  # every unit of block3 (conv1 has 256 outputs: K = 256); blocks 1-2 are narrower
+    assert sum(emitted) == 22, emitted  # ... and units 2..23 got the mask words from the previous unit's conv3 launch
     assert torch.equal(out[True][0], out[False][0])
     g1, g0 = out[True][1], out[False][1]
     for n, L in enumerate(net.layers[:net.n_trunk]):
         lo = (L.dw.data_ptr() - net.grads.data_ptr()) // 4
         a, b_ = g1[lo:lo + L.dw.numel()], g0[lo:lo + L.dw.numel()]
-        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max() + 1e-30), n
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max() + 1e-30), n  # (wgrad slices meet in atomics)
 
 
 def test_instance_trainer_step_reduces_loss():
