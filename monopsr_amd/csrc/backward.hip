@@ -33,6 +33,12 @@ struct WgradParams {
     // pixel slices per tap (proportional to the tap's valid pixels) and the cumulative workgroup count; used when
     // the kernel has at most MAX_TAPS taps, otherwise every tap gets `splits` slices
     int per_tap, tap_splits[9], tap_end[9];
+    // grouped: workgroup b -> XCD b % 8 (the dispatcher's round-robin); a GROUP = the ntile_n * ntile_c output tiles of
+    // one (tap, pixel slice), which all read the same rows of x and dy, is kept on ONE XCD (consecutive workgroups of
+    // that XCD), so that the slice comes from HBM once and from that XCD's L2 for the other tiles (r04: -1..3 % per
+    // launch: the Infinity Cache already absorbed most of it).  ngroups groups in all, tap_gend[] their cumulative
+    // count per tap.
+    int grouped, ngroups, tap_gend[9];
     unsigned xbytes, dybytes;
 };
 constexpr int MAX_TAPS = 9;
@@ -43,7 +49,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     __shared__ __attribute__((aligned(16))) float Bt[WG_K * WG_T];  // [pixel][c]
     int t = blockIdx.x;
     int tap, si, nsplit;
-    if (p.per_tap) {
+    if (p.grouped) {
+        const int tiles = p.ntile_n * p.ntile_c;
+        const int xcd = t & 7, l = t >> 3;
+        const int g = (l / tiles) * 8 + xcd;
+        if (g >= p.ngroups) return;  // block-uniform
+        t = l % tiles;
+        if (p.per_tap) {
+            tap = 0;
+            while (g >= p.tap_gend[tap]) ++tap;
+            si = g - (tap > 0 ? p.tap_gend[tap - 1] : 0);
+            nsplit = p.tap_splits[tap];
+        } else {
+            const int taps = p.KH * p.KW;
+            tap = g % taps;
+            si = g / taps;
+            nsplit = p.splits;
+        }
+        t += si * tiles;  // (decoded below: tile column, tile row, slice)
+    } else if (p.per_tap) {
         tap = 0;
         while (t >= p.tap_end[tap]) ++tap;
         if (tap > 0) t -= p.tap_end[tap - 1];
@@ -120,6 +144,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     };
     const unsigned lcol4 = (unsigned)lcol * 4u;
     auto load_tile = [&](int ms) {
+#ifdef WG_NO_LOAD  // (timing experiment only)
+        if (ms > ms_begin + 1) return;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint2 o = offs[ms & 1][lrow + 8 * j];
@@ -132,6 +159,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         }
     };
     auto store_tile = [&]() {
+#ifdef WG_NO_LDS_STORE  // (timing experiment only)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ra[j].x), "v"(ra[j].y), "v"(ra[j].z), "v"(ra[j].w), "v"(rb[j].x), "v"(rb[j].y), "v"(rb[j].z), "v"(rb[j].w));
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             *reinterpret_cast<float4 *>(&At[(lrow + 8 * j) * WG_T + lcol]) = ra[j];
@@ -195,7 +227,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wm * 64 + i * 32 + rsub + (e & 3) + 8 * (e >> 2);
+#ifdef WG_PLAIN_STORE  // (timing experiments only, tools/README.md: wrong results)
+                if (n < p.N) p.dw[(size_t)n * Ktot + (size_t)tap * p.C + c] = acc[i][j][e];
+#elif defined(WG_NO_STORE)
+                asm volatile("" ::"v"(acc[i][j][e]));
+#else
                 if (n < p.N) unsafeAtomicAdd(&p.dw[(size_t)n * Ktot + (size_t)tap * p.C + c], acc[i][j][e]);
+#endif
             }
     }
 }
@@ -461,6 +499,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+int g_wgrad_grouped = 1;  // mpsr_debug_set_wgrad_grouped: the XCD-aware workgroup order (A/B)
 int g_wgrad_target = 768;  // one round of the 3 workgroups per CU the kernel's registers allow (measured best)
 
 inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
@@ -496,6 +535,7 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     p.splits = slices;
     p.per_tap = taps <= MAX_TAPS;
     long long blocks = (long long)tiles * taps * slices;
+    long long groups = (long long)taps * slices;
     if (p.per_tap) {
         // share taps * slices pixel slices among the taps in proportion to their valid pixels
         long long valid[MAX_TAPS], sum = 0;
@@ -514,8 +554,13 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
             p.tap_splits[t] = (int)st;
             blocks += st * tiles;
             p.tap_end[t] = (int)blocks;
+            p.tap_gend[t] = (int)(blocks / tiles);
         }
+        groups = blocks / tiles;
     }
+    p.grouped = g_wgrad_grouped && groups >= 8 && tiles > 1;
+    p.ngroups = (int)groups;
+    if (p.grouped) blocks = (groups + 7) / 8 * 8 * tiles;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, mpsr::as_stream(stream), p);
     MPSR_CHECK_LAUNCH("conv_wgrad_kernel");
     return MPSR_OK;
@@ -711,3 +756,4 @@ extern "C" int mpsr_adam_step(float *param, const float *grad, float *m, float *
 }
 
 extern "C" void mpsr_debug_set_wgrad_target(int workgroups) { g_wgrad_target = workgroups; }
+extern "C" void mpsr_debug_set_wgrad_grouped(int on) { g_wgrad_grouped = on; }

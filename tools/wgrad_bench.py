@@ -31,11 +31,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--target", type=int, default=0, help="debug: workgroups per launch the pixel slicing aims at")
+    ap.add_argument("--ungrouped", action="store_true", help="A/B: the workgroup order that ignores the XCDs")
     args = ap.parse_args()
     B = args.batch
     lib = _lib.lib()
     if args.target:
         lib.mpsr_debug_set_wgrad_target(args.target)
+    if args.ungrouped:
+        lib.mpsr_debug_set_wgrad_grouped(0)
     total = 0.0
     print("%-28s %3s %9s %10s %8s" % ("layer", "n", "GFLOP", "us", "TF/s"))
     for name, count, H, W, C, N, k, dil in SHAPES:
