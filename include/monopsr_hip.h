@@ -275,6 +275,11 @@ int mpsr_relu_grad(const float *dy, const float *y, float *dx, long long total, 
  * residual may be NULL); kept elements are bit-identical to the unmasked launch.
  * mpsr_conv1x1_masked_applies says whether the shape (and the arithmetic mode: fp32 only) is taken by the last two --
  * otherwise MPSR_ERR_UNSUPPORTED and the caller runs mpsr_conv2d_nhwc_f32 (+ mpsr_relu_grad). */
+/* y = conv(x, w) (no bias, as scheduled by the library: split_k = 0 of mpsr_conv2d_nhwc_f32, same scratch) where
+ * mask > 0 and zero elsewhere; mask (B,H,W,N) = the post-ReLU tensor this data gradient belongs to.  The F(3x3,3x3)
+ * atrous kernel (block3's conv2) applies it in its epilogue, other shapes run mpsr_relu_grad in place afterwards. */
+int mpsr_conv2d_relu_masked_f32(const float *x, int B, int H, int W, int C, const float *w, const float *mask, float *y,
+                                int N, int KH, int KW, int dilation, float *ws, size_t ws_floats, mpsr_stream_t stream);
 long long mpsr_relu_bitmask_words(long long M, int N);
 int mpsr_relu_bitmask(const float *y, long long M, int N, unsigned *bits, mpsr_stream_t stream);
 int mpsr_conv1x1_masked_applies(long long M, int K, int N);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mpsr_act_bias_grad": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f]),
     "mpsr_bias_grad": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
     "mpsr_relu_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_f]),
+    "mpsr_conv2d_relu_masked_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "mpsr_relu_bitmask_words": (ctypes.c_longlong, [ctypes.c_longlong, c_i]),
     "mpsr_relu_bitmask": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
     "mpsr_conv1x1_masked_applies": (c_i, [ctypes.c_longlong, c_i, c_i]),

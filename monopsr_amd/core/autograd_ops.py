@@ -144,6 +144,8 @@ class UnitLink:
 
 
 _MASK_SCRATCH = {}
+# A/B switch (tools/train_bench.py --unfused-relu-grads): False = every ReLU gradient inside a unit is an elementwise pass
+FUSED_RELU_GRADS = True
 
 
 def _conv1x1_with_mask(x, L, residual):
@@ -178,6 +180,25 @@ def _data_grad_masked(L, g, x, residual, bits=None):
     dx = torch.empty_like(x)
     _lib.check(lib.mpsr_conv1x1_masked_f32(_lib.ptr(g), M, N, _lib.ptr(wd), None, _lib.ptr(residual), _lib.ptr(bits),
                                            _lib.ptr(dx), C, s))
+    return dx
+
+
+def _data_grad_relu_masked(L, g, y_in):
+    """dX of layer L times the ReLU mask of its (post-ReLU) input y_in in ONE library call
+    (mpsr_conv2d_relu_masked_f32: the F(3x3,3x3) kernel applies the mask in its epilogue)."""
+    lib = _lib.lib()
+    g4, pad = _pad4(L, g)
+    N4 = L.cout + pad
+    C = y_in.shape[3]
+    w4 = F.pad(L.w, (0, 0, 0, pad)) if pad else L.w
+    s = _lib.stream()
+    wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=g.device)
+    _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd), s))
+    B, H, W, _ = g4.shape
+    ws = dn.stream_scratch(dn._SCHED_SCRATCH, g.device, lib.mpsr_conv2d_scratch_floats(B, H, W, C))
+    dx = torch.empty_like(y_in)
+    _lib.check(lib.mpsr_conv2d_relu_masked_f32(_lib.ptr(g4.contiguous()), B, H, W, N4, _lib.ptr(wd), _lib.ptr(y_in),
+                                               _lib.ptr(dx), C, L.kh, L.kw, L.dilation, _lib.ptr(ws), ws.numel(), s))
     return dx
 
 
@@ -219,11 +240,15 @@ class BottleneckFn(torch.autograd.Function):
         else:
             g3 = _masked_grad(c3, dy, y)  # also the gradient that enters the shortcut branch
         _deposit_weight_grad(c3, t2, g3)
-        g2 = _data_grad_masked(c3, g3, t2, None) if c2.relu else None  # conv3's data gradient through conv2's ReLU mask
+        # conv3's data gradient through conv2's ReLU mask, conv2's through conv1's: in the launches' store paths
+        g2 = _data_grad_masked(c3, g3, t2, None) if (c2.relu and FUSED_RELU_GRADS) else None
         if g2 is None:
             g2 = _masked_grad(c2, _data_grad(c3, g3, t2.shape[3]), t2)
         _deposit_weight_grad(c2, t1, g2)
-        g1 = _masked_grad(c1, _data_grad(c2, g2, t1.shape[3]), t1)
+        if c1.relu and FUSED_RELU_GRADS:
+            g1 = _data_grad_relu_masked(c2, g2, t1)
+        else:
+            g1 = _masked_grad(c1, _data_grad(c2, g2, t1.shape[3]), t1)
         _deposit_weight_grad(c1, x, g1)
         dx = None
         residual = g3

@@ -1108,7 +1108,8 @@ extern std::atomic<int> g_wino4_split;
 size_t winograd3_scratch_floats(int C, int N);
 bool winograd3_applies(int H, int W, int C, int dilation);
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s);
+                      float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s,
+                      const float *mask = nullptr);
 
 // pointwise.hip
 bool pointwise_applies(long long M, int K, int N);
@@ -1467,6 +1468,21 @@ extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, 
 {
     return mpsr::conv2d(x, B, H, W, C, w, bias, residual, y, N, KH, KW, dilation, relu, split_k, ws, ws_floats,
                         mpsr::as_stream(stream));
+}
+
+// y = conv(x, w) where mask > 0, else 0 (mask shaped like y): a data gradient through the ReLU of the layer it belongs to.
+// The F(3x3,3x3) atrous kernel applies the mask in its epilogue; every other shape runs the convolution as scheduled and
+// then mpsr_relu_grad in place.
+extern "C" int mpsr_conv2d_relu_masked_f32(const float *x, int B, int H, int W, int C, const float *w, const float *mask,
+                                           float *y, int N, int KH, int KW, int dilation, float *ws, size_t ws_floats,
+                                           mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(mask, "conv2d_relu_masked: null mask");
+    hipStream_t s = mpsr::as_stream(stream);
+    if (B > 0 && x && w && y && mpsr::conv2d_takes_winograd3(B, H, W, C, N, KH, KW, dilation, 0, ws, ws_floats))
+        return mpsr::conv3x3_winograd3(x, B, H, W, C, w, nullptr, 0, y, N, dilation, ws, ws_floats, s, mask);
+    if (int rc = mpsr::conv2d(x, B, H, W, C, w, nullptr, nullptr, y, N, KH, KW, dilation, 0, 0, ws, ws_floats, s)) return rc;
+    return mpsr_relu_grad(y, mask, y, (long long)B * H * W * N, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ calibration

@@ -43,6 +43,10 @@ struct Wino3Params {
     int B, H, W, C, N, dil, T;  // T = B * dil * dil tiles
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes;
+    // training (data-gradient launches): a tensor shaped like y; an output element is kept where mask[...] > 0 and written
+    // as zero elsewhere -- the ReLU gradient of the layer this gradient belongs to, in the epilogue instead of by an
+    // elementwise pass over the result
+    const float *mask;
 };
 
 __global__ __launch_bounds__(256) void wino3_filter_kernel(const float *__restrict__ w, int N, int C, float *__restrict__ u)
@@ -295,10 +299,24 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
                 const int trow = (e8 & 3) + 8 * (e8 >> 2);  // tile within the round, less 4 (lane >> 5)
                 mwr[q * (16 * NT) + trow * NT] = acc[q][8 * round + e8];
             }
-        __syncthreads();
         const int tt = t0 + 16 * round + (tid2 >> 5);
         const int img = tt / (d * d), rem = tt - img * d * d;
         const int a = rem / d, b = rem - a * d;
+        // (the mask values of this thread's 2 x 9 outputs are requested in front of the barrier the exchange needs anyway)
+        float mk[2][9];
+        if (p.mask) {  // block-uniform
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n0 + (tid2 & 31) + 32 * h;
+                const bool ok = tt < p.T && n < p.N;
+                const float *mo = p.mask + ((size_t)(img * p.H + a) * p.W + b) * p.N + n;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mk[h][3 * j + i] = ok ? mo[((size_t)(d * i) * p.W + d * j) * p.N] : 0.f;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float z[5][3];
@@ -320,6 +338,7 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
                 for (int i = 0; i < 3; ++i) {
                     float v = yv[i] + bias2[h];
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask) v = mk[h][3 * j + i] > 0.f ? v : 0.f;
                     if (ok) o[((size_t)(d * i) * p.W + d * j) * p.N] = v;
                 }
             }
@@ -359,7 +378,7 @@ bool winograd3_applies(int H, int W, int C, int dilation)
 }
 
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
-                      float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s)
+                      float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s, const float *mask)
 {
     using namespace f3;
     MPSR_REQUIRE(winograd3_applies(H, W, C, dilation), "conv3x3_winograd3: needs H = W = 3 * dilation and C %% 16 == 0");
@@ -389,7 +408,7 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
         MPSR_CHECK_LAUNCH("wino3_filter_kernel");
     }
     Wino3Params p;
-    p.x = x; p.u = u; p.bias = bias; p.y = y;
+    p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
     p.T = B * dilation * dilation;
     p.cblocks = C / KC;

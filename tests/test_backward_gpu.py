@@ -409,6 +409,29 @@ def test_masked_pointwise_data_gradient_is_the_unmasked_one_times_the_relu_mask(
     assert rc != 0 and b"masked" in lib.mpsr_last_error()
 
 
+@pytest.mark.parametrize("B,H,C,N,k,dil", [(64, 12, 256, 256, 3, 4), (3, 12, 64, 32, 3, 4), (2, 6, 32, 64, 3, 2),
+                                            (2, 12, 64, 64, 3, 1), (2, 5, 128, 256, 1, 1)])
+def test_conv2d_relu_masked_is_conv_then_relu_grad(B, H, C, N, k, dil):
+    """mpsr_conv2d_relu_masked_f32 = the scheduled convolution followed by mpsr_relu_grad, bit for bit: the F(3x3,3x3)
+    atrous kernel selects in its epilogue (first three shapes: 12x12 at dilation 4 and 6x6 at dilation 2 have 3x3
+    sub-grids), the others run the two launches inside the call."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    lib = _lib.lib()
+    rng = np.random.default_rng(B * 1000 + N)
+    x = _dev(rng.standard_normal((B, H, H, C)).astype(np.float32))
+    w = _dev((rng.standard_normal((N, k * k * C)) / np.sqrt(k * k * C)).astype(np.float32))
+    act = _dev(np.maximum(rng.standard_normal((B, H, H, N)), 0).astype(np.float32))
+    ws = torch.empty((lib.mpsr_conv2d_scratch_floats(B, H, H, N),), dtype=torch.float32, device="cuda")
+    got = torch.full((B, H, H, N), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(lib.mpsr_conv2d_relu_masked_f32(_lib.ptr(x), B, H, H, C, _lib.ptr(w), _lib.ptr(act), _lib.ptr(got), N, k, k,
+                                               dil, _lib.ptr(ws), ws.numel(), _lib.stream()))
+    plain = dn.conv2d(x, w, None, None, k, k, dil, False, split_k=0)
+    want = torch.where(act > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(got, want)
+    assert 0.3 < float((got != 0).float().mean()) < 0.7
+
+
 def test_linked_bottleneck_units_give_the_same_gradients():
     """TrainNet.trunk chains its bottleneck units (autograd_ops.UnitLink): a unit's input gradient leaves conv1's
     data-gradient launch already masked by the previous unit's ReLU, and that unit skips its elementwise pass.  Full

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--unfused-relu-grads", action="store_true",
+                    help="A/B: the ReLU gradients inside a bottleneck unit as elementwise passes")
     ap.add_argument("--unlinked-units", action="store_true",
                     help="A/B: bottleneck units not chained (every unit runs its own ReLU-gradient pass)")
     ap.add_argument("--decoder-bn", default="batch", choices=["batch", "frozen"],
@@ -54,6 +56,9 @@ def main():
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn)
     net.linked_units = not args.unlinked_units
+    if args.unfused_relu_grads:
+        from monopsr_amd.core import autograd_ops
+        autograd_ops.FUSED_RELU_GRADS = False
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
