@@ -16,8 +16,8 @@
 // threads; K step = 8 channels; A (transformed patches) double buffered in LDS with the 16-byte-half XOR swizzle; B
 // fragments straight from the transformed filters (L2) into registers one unit ahead; producers alternate request /
 // transform steps; every MFMA followed by its slot of producer work, order pinned.  25 positions over 8 waves: wave
-// (pg, nh) owns positions 6 pg .. 6 pg + 5 x 32 of the 64 channels, and one of the four k pairs of the 25th position
-// (a partial accumulator: 112 accumulator registers per wave) -- 25 MFMAs per K step on every wave.
+// (pg, nh) owns positions 6 pg .. 6 pg + 5 (pg = 3: .. + 6) x 32 of the 64 channels -- 96 or 112 accumulator
+// registers; the two seven-position waves sit on different SIMDs.
 #include <atomic>
 #include <type_traits>
 
@@ -32,7 +32,7 @@ namespace f3 {
 constexpr int MT = 32, NT = 64, KC = 8, NP = 25;
 constexpr int APOS = MT * KC;           // floats per position of an A buffer (256)
 constexpr int ABUF = NP * APOS;         // one A buffer (6400 floats = 25 KB)
-constexpr int MEXF = (NP + 3) * 16 * NT;  // epilogue exchange of one round: (24 + 4 partials of the 25th) x 16 tiles x 64 channels (112 KB)
+constexpr int MEXF = NP * 16 * NT;      // epilogue exchange of one round: 25 x 16 tiles x 64 channels (100 KB)
 constexpr int LDSF = MEXF > 2 * ABUF ? MEXF : 2 * ABUF;
 constexpr unsigned OOB = 0x80000000u;
 }  // namespace f3
@@ -78,15 +78,12 @@ __device__ __forceinline__ void at3(float m0, float m1, float m2, float m3, floa
 template <int V>
 using IC3 = std::integral_constant<int, V>;
 
-// DG = producer group (0: patches of the even K steps, 1: odd).  Every wave owns six positions x 32 channels, and the
-// 25th position is shared: wave (pg, nh) runs k pair pg (of the four in a K step) of position 24 for channel half nh into a
-// partial accumulator of its own -- 25 MFMAs per wave and step for all eight waves (r03 gave the whole 25th position to
-// two waves: 28 against 24, i.e. a 52-vs-48 split between the SIMD pairs); the four partials meet in the epilogue.
-template <int DG>
+// NPOS = positions of this wave (6 or 7), DG = producer group (0: patches of the even K steps, 1: odd)
+template <int NPOS, int DG>
 __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, const int t0, float *lds)
 {
     using namespace f3;
-    constexpr int NPOS = 6, NU = 2;  // units: 3 + 3 positions
+    constexpr int NU = NPOS == 7 ? 3 : 2;  // units: 3 + 3 (+ 1) positions
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave >> 1, nh = wave & 1;
@@ -166,22 +163,6 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     };
     const float *ard = lds + gpos * APOS + (lane & 31) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1));
     float4 fa[3];
-    // the shared 25th position: component pg of the fragments (k = pg for lanes < 32, 4 + pg above)
-    const float *ard24 = lds + 24 * APOS + (lane & 31) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1)) + pg;
-    float fb24[2], a24 = 0.f;
-    auto load_b24 = [&](int step, int set) __attribute__((always_inline)) {
-#ifdef W3_SKIP_BLOAD
-        if (step > 0) return;
-#endif
-        const bool live = step < nsteps;
-        const __amdgpu_buffer_rsrc_t rr =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
-        const unsigned so = ((unsigned)(live ? step : 0) * (unsigned)NP + 24u) * bpstride + 4u * (unsigned)pg;
-        fb24[set] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, bvoff, so, 0));
-    };
-    f32x16 acc24;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc24[e] = 0.f;
 
     f32x16 acc[NPOS];
 #pragma unroll
@@ -189,38 +170,39 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
-    // One K step: two units of 3 positions -- within a unit k = 0..3 of the fragments outermost, the unit's positions
-    // round-robin -- then this wave's k pair of the 25th position.  MFMA number m of the step is followed by duty(m)
-    // for m < 24.  The B fragments of the next unit are requested in the first slots of a unit (register set = unit
-    // index), the 25th position's dword for the next step in slot 1.
+    // One K step: units of 3, 3 (and 1) positions; within a unit k = 0..3 of the fragments outermost, the unit's
+    // positions round-robin.  MFMA number m of the step is followed by duty(m) for m < 24.  The B fragments of the next
+    // unit are requested in the first slots of a unit (register set = unit index).
     auto kstep = [&](int s, auto buf_c, auto &&duty) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            constexpr int np = 3;  // positions of a unit
+            const int np = u < 2 ? 3 : 1;  // positions of this unit
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fa[j] = *reinterpret_cast<const float4 *>(ard + buf * ABUF + (3 * u + j) * APOS);
-            if (u == 1) a24 = ard24[buf * ABUF];
+            for (int j = 0; j < 3; ++j)
+                if (j < np) fa[j] = *reinterpret_cast<const float4 *>(ard + buf * ABUF + (3 * u + j) * APOS);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
+                    if (j >= np) continue;
                     const int m = 12 * u + np * k + j;
                     const float av = k == 0 ? fa[j].x : k == 1 ? fa[j].y : k == 2 ? fa[j].z : fa[j].w;
                     const float bv = k == 0 ? fb[u][j].x : k == 1 ? fb[u][j].y : k == 2 ? fb[u][j].z : fb[u][j].w;
                     acc[3 * u + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[3 * u + j], 0, 0, 0);
                     if (k == 0) {  // request the next unit's fragment j (of this step, or unit 0 of the next step)
-                        const int un = (u + 1) % NU;
-                        load_b1(u + 1 < NU ? s : s + 1, 3 * un + j, un, j);
+                        const int un = (u + 1) % NU, npn = un < 2 ? 3 : 1;
+                        if (j < npn) load_b1(u + 1 < NU ? s : s + 1, 3 * un + j, un, j);
+                        if (np == 1 && npn == 3) {  // a one-position unit requests all three of the next
+                            load_b1(u + 1 < NU ? s : s + 1, 3 * un + 1, un, 1);
+                            load_b1(u + 1 < NU ? s : s + 1, 3 * un + 2, un, 2);
+                        }
                     }
-                    if (m == 1) load_b24(s + 1, buf ^ 1);
                     if (m < 24) duty(m);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        acc24 = __builtin_amdgcn_mfma_f32_32x32x2f32(a24, fb24[buf], acc24, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     };
     // producer duties: request = the nine loads in slots 3..11; transform = slots 0..2 the three column transforms,
     // 3..7 the five row transforms, a row's five stores in the two slots behind it... (row r: slots 4 + r and 5 + r
@@ -254,7 +236,6 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     // ---- prologue: B of (step 0, unit 0); A of step 0 by waves 0-3; the patch of step 1 requested by waves 4-7
 #pragma unroll
     for (int j = 0; j < 3; ++j) load_b1(0, j, 0, j);
-    load_b24(0, 0);
 #pragma unroll
     for (int i = 0; i < 9; ++i) load_patch1(DG, i);
     if (DG == 0) {
@@ -289,8 +270,13 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
         }
     }
     int tid2 = tid;
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc24), "+v"(tid2));
+    if constexpr (NPOS == 7)
+        asm volatile("s_nop 15\n\ts_nop 7"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                       "+v"(tid2));
+    else
+        asm volatile("s_nop 15\n\ts_nop 7"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(tid2));
 
     // ---- epilogue: two rounds of 16 tiles.  M[pos][tile][64 n] through LDS; thread (tile = tid >> 5, n = tid & 31 and
     // + 32) gathers the 25 positions of its two (tile, n) pairs, A^T M A, bias, ReLU, nine strided pixels out.
@@ -313,12 +299,6 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
                 const int trow = (e8 & 3) + 8 * (e8 >> 2);  // tile within the round, less 4 (lane >> 5)
                 mwr[q * (16 * NT) + trow * NT] = acc[q][8 * round + e8];
             }
-        // (this wave's partial of the 25th position: slot 24 + pg)
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-            const int trow = (e8 & 3) + 8 * (e8 >> 2);
-            mwr[(24 + pg - gpos) * (16 * NT) + trow * NT] = acc24[8 * round + e8];
-        }
         const int tt = t0 + 16 * round + (tid2 >> 5);
         const int img = tt / (d * d), rem = tt - img * d * d;
         const int a = rem / d, b = rem - a * d;
@@ -345,8 +325,6 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
                 float m[5];
 #pragma unroll
                 for (int v = 0; v < 5; ++v) m[v] = mrd[(5 * u + v) * (16 * NT) + 32 * h];
-                if (u == 4)  // the 25th position arrives as four partial sums (one per k pair of a K step)
-                    m[4] = (m[4] + mrd[25 * (16 * NT) + 32 * h]) + (mrd[26 * (16 * NT) + 32 * h] + mrd[27 * (16 * NT) + 32 * h]);
                 at3(m[0], m[1], m[2], m[3], m[4], z[u][0], z[u][1], z[u][2]);
             }
             const int n = n0 + (tid2 & 31) + 32 * h;
@@ -377,9 +355,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (mb >= p.mblocks) return;  // block-uniform
     const int n0 = nb * f3::NT, t0 = mb * f3::MT;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // two straight-line copies selected once: the K loop never sees a branch on the wave's producer role
-    if (wave < 4) wino3_body<0>(p, n0, t0, lds);
-    else wino3_body<1>(p, n0, t0, lds);
+    // three straight-line copies selected once: the K loop never sees a branch on the wave's role
+    if (wave < 4) wino3_body<6, 0>(p, n0, t0, lds);
+    else if (wave < 6) wino3_body<6, 1>(p, n0, t0, lds);
+    else wino3_body<7, 1>(p, n0, t0, lds);
 }
 
 }  // namespace
