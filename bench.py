@@ -882,6 +882,8 @@ def main():
                                                                "(0 = --batch)")
     ap.add_argument("--streams", type=int, default=1,
                     help="split each GPU's batch into this many instance shards on separate HIP streams")
+    ap.add_argument("--pws-per-cu", type=int, default=0,
+                    help="tuning knob with --streams: persistent pointwise workgroups per CU of every launch (default 2)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the timed run: fp32 (default, the headline) or the opt-in "
                          "split-bfloat16 mode (include/monopsr_hip.h MPSR_MATH_BF16X3)")
@@ -944,6 +946,8 @@ def main():
     weights = W.synthetic_weights(seed=0)
     net = dn.DeviceNet(weights, device=device)
     inp, host = make_inputs(args.batch, args.points, rank, device)
+    if args.pws_per_cu > 0:
+        _lib.lib().mpsr_debug_set_pointwise_per_cu(args.pws_per_cu)
     step = Step(net, inp, args.points) if args.streams <= 1 else MultiStreamStep(net, inp, args.points, args.streams)
     grad_buf = torch.zeros((100204832,), dtype=torch.float32, device=device) if args.allreduce_grads else None
 
