@@ -301,6 +301,11 @@ int mpsr_resize_bilinear_grad(const float *dy, int B, int H, int W, int C, int O
  * g' = grad*grad_scale; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2; p -= lr*sqrt(1-b2^step)/(1-b1^step) * m/(sqrt(v)+eps). */
 int mpsr_adam_step(float *param, const float *grad, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, mpsr_stream_t stream);
+/* The same update with the bias-corrected rate lr_t = lr*sqrt(1-b2^step)/(1-b1^step) read from DEVICE memory when the
+ * kernel runs: a launch captured into a HIP graph (the training step replayed as one graph launch) then follows the
+ * schedule -- the caller writes *lr_t_dev (stream-ordered) before each replay. */
+int mpsr_adam_step_lr_dev(float *param, const float *grad, float *m, float *v, long long n, const float *lr_t_dev,
+                          float beta1, float beta2, float eps, float grad_scale, mpsr_stream_t stream);
 
 /* Gradient of mpsr_crop_and_resize w.r.t. the image (TensorFlow's CropAndResizeGradImage, reached through autodiff
  * from net_builder.py:54-59 when the full-image trunk trains).  grad_out (nb,ch,cw,C) -> grad_image (nimg,H,W,C),

@@ -98,6 +98,8 @@ SIGNATURES = {
     "mpsr_resize_bilinear_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, c_i, ctypes.c_float, c_f]),
+    "mpsr_adam_step_lr_dev": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, c_f, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, c_f]),
     "mpsr_crop_and_resize_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_batch_norm_stats": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f]),
     "mpsr_batch_norm_apply": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_i, c_f, c_f]),

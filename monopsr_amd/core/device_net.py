@@ -269,6 +269,20 @@ def stream_scratch(cache, device, floats, keep=8):
     return ws
 
 
+_CONSTANTS = {}
+
+
+def device_constant(values, device, dtype=torch.float32):
+    """A small constant tensor on `device`, uploaded ONCE per (values, dtype, device): a host -> device copy inside a
+    step is a synchronising call and cannot be captured into a HIP graph."""
+    arr = np.asarray(values)
+    key = (arr.shape, arr.astype(np.float64).tobytes(), str(dtype), str(device))
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = torch.as_tensor(arr, dtype=dtype, device=device)
+    return t
+
+
 def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1):
     """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C)."""
     x, w_ok = x.contiguous(), w_ok.contiguous()

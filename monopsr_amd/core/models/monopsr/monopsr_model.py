@@ -222,7 +222,8 @@ class MonoPSRModel:
                 eps = getattr(loss_config, constants.KEY_ALPHA + '_cls')[2]
                 one_hot = torch.full((self.num_boxes, self.num_alpha_bins), eps / self.dataset_config.num_alpha_bins,
                                      dtype=torch.float32, device=dev)
-                one_hot[rows, gt_bins] = 1.0 - eps
+                # (scatter_: index_put with index tensors cannot be captured into a HIP graph on this build)
+                one_hot.scatter_(1, gt_bins.reshape(-1, 1), 1.0 - eps)
                 bins_loss = box_term(output_dict[constants.KEY_ALPHA_BINS], one_hot, constants.KEY_ALPHA + '_cls')
                 reg_loss = box_term(output_dict[constants.KEY_ALPHA_REGS], gt_dict[constants.KEY_ALPHA_REGS],
                                     constants.KEY_ALPHA + '_reg', mask=gt_alpha_valid_bins.unsqueeze(0).float())
@@ -231,7 +232,7 @@ class MonoPSRModel:
                 total_loss = total_loss + (bins_loss + reg_loss)
             elif alpha_type == 'prob':  # :712-752: hard one-hot targets, the temperature softmax, alpha itself regressed
                 one_hot = torch.zeros((self.num_boxes, self.num_alpha_bins), dtype=torch.float32, device=dev)
-                one_hot[rows, gt_bins] = 1.0
+                one_hot.scatter_(1, gt_bins.reshape(-1, 1), 1.0)
                 bins_loss = box_term(output_dict[constants.KEY_ALPHA_BINS], one_hot, constants.KEY_ALPHA + '_cls_temp')
                 reg_loss = box_term(output_dict[constants.KEY_ALPHA], gt_dict[constants.KEY_ALPHA],
                                     constants.KEY_ALPHA + '_reg')

@@ -248,6 +248,19 @@ class TrainNet:
     def zero_grad(self):
         self.grads.zero_()
 
+    @staticmethod
+    def adam_rate(lr, step, beta1=0.9, beta2=0.999):
+        """lr_t of step `step` (1-based): what mpsr_adam_step computes from (lr, step) on the host."""
+        import math
+        return float(lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step))
+
+    def adam_step_lr_dev(self, lr_t_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """adam_step with the bias-corrected rate read from the device scalar `lr_t_dev` at run time (a launch that is
+        captured into a HIP graph); the caller keeps step_count."""
+        _lib.check(_lib.lib().mpsr_adam_step_lr_dev(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                                    _lib.ptr(self.adam_v), self.params.numel(), _lib.ptr(lr_t_dev),
+                                                    beta1, beta2, eps, grad_scale, _lib.stream()))
+
     def adam_step(self, lr=8e-5, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
         """tf.train.AdamOptimizer update (optimizer_builder.py:61-80; lr 8e-5 from monopsr_model_000.yaml:141-147)."""
         self.step_count += 1

@@ -111,6 +111,56 @@ class _ConstantLr:
         self.use_moving_average = False
 
 
+class _StepGraph:
+    """InstanceTrainer.capture_step(): eager warm-up calls, one captured call, then replays (see there)."""
+
+    def __init__(self, trainer, warmup):
+        self.tr, self.left = trainer, max(1, int(warmup))
+        dev = trainer.net.params.device
+        self.side = torch.cuda.Stream(device=dev)  # capture needs a non-default stream; the scratch caches are per stream
+        self.lr_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.graph = self.static = self.loss = None
+
+    def _copy_in(self, sample):
+        for k, v in sample.items():
+            if torch.is_tensor(v):
+                dst = self.static[k]
+                if dst.shape != v.shape or dst.dtype != v.dtype:
+                    raise _lib.InvalidArgumentError("captured step: sample[%r] is %s %s, the captured call saw %s %s" %
+                                                    (k, tuple(v.shape), v.dtype, tuple(dst.shape), dst.dtype))
+                if dst.data_ptr() != v.data_ptr():
+                    dst.copy_(v, non_blocking=True)
+            elif self.static.get(k) is not v and self.static.get(k) != v:
+                raise _lib.InvalidArgumentError("captured step: sample[%r] changed (only tensors may)" % k)
+
+    def step(self, sample):
+        tr = self.tr
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            if self.graph is None and self.left > 0:  # eager, on the capturing stream
+                self.left -= 1
+                loss = tr._eager_step(sample)
+            elif self.graph is None:
+                self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()}
+                self.lr_t.fill_(tr.optimizer.lr_t_of(tr.net, tr.global_step))
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.side):
+                    self.loss = tr._eager_step(self.static, lr_t_dev=self.lr_t)
+                # (capture records, it does not run: this call's step is the first replay)
+                self.graph.replay()
+                loss = self.loss.clone()
+            else:
+                self._copy_in(sample)
+                self.lr_t.fill_(tr.optimizer.lr_t_of(tr.net, tr.global_step))
+                self.graph.replay()
+                tr.global_step += 1
+                loss = self.loss.clone()
+        main.wait_stream(self.side)
+        return loss
+
+
 class InstanceTrainer:
     """sample keys for step(): those of MonoPSRModel.build (rgb_image_crops, full_img_feature_crop, boxes_2d, cam_p,
     est_view_angs, class_indices, mean_lwh, prop_cen_z_offset) plus the ground truth the reference feeds through
@@ -128,6 +178,7 @@ class InstanceTrainer:
             self.optimizer = optimizer_builder.build(train_config.optimizer)
         self.global_step = 0
         self._clip = None
+        self._graph = None
         spans = []
         base = net.grads.data_ptr()
         for L in net.layers:  # everything a layer's backward deposits: weight gradient and bias / beta gradient
@@ -178,6 +229,11 @@ class InstanceTrainer:
         return self.net.grads
 
     def step(self, sample):
+        if self._graph is not None:
+            return self._graph.step(sample)
+        return self._eager_step(sample)
+
+    def _eager_step(self, sample, lr_t_dev=None):
         self.net.zero_grad()
         out = self.forward(sample)
         self.losses_dict, loss = self.loss(out, sample)
@@ -185,9 +241,31 @@ class InstanceTrainer:
         self.reducer.finish(average=True)
         if self.clip_norm:
             self.clip_per_variable()
-        self.optimizer.apply_gradients(self.net, self.global_step)
+        if lr_t_dev is None:
+            self.optimizer.apply_gradients(self.net, self.global_step)
+        else:
+            self.optimizer.apply_gradients_lr_dev(self.net, lr_t_dev)
         self.global_step += 1
         return loss.detach()
+
+    def capture_step(self, warmup=2):
+        """From now on step() replays ONE HIP graph: the ~1100 launches of a training step (forward, configured losses,
+        backward, clip, Adam, moving average) captured once -- the eager step leaves 2-3 ms of launch gaps per step in
+        its loss / head / optimizer sections, where the host issues hundreds of tiny kernels (`tools/train_bench.py
+        --graph`: 59.8 -> 56.8 ms).  The first `warmup` + 1 calls run eagerly (they size the per-stream scratch caches,
+        create the moving average and are the captured call); every later call copies the sample into the captured
+        call's tensors, writes the step's learning rate where the captured Adam launch reads it and replays.  Shapes
+        and dtypes of the sample must stay those of the first call.  Single-process training only: a data-parallel
+        step exchanges gradients through torch.distributed while backward runs and stays eager."""
+        if self.reducer._active():
+            raise RuntimeError("capture_step(): data-parallel steps stay eager (the bucketed all-reduce is issued "
+                               "from Python while backward runs)")
+        if self._graph is None:
+            self._graph = _StepGraph(self, warmup)
+        return self
+
+    def release_step_graph(self):
+        self._graph = None
 
     # ------------------------------------------------------------------ checkpoint / resume (core/trainer.py:85,149-185)
     def save(self, checkpoint_dir, name='monopsr'):

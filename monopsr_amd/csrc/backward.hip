@@ -486,8 +486,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_grad_kernel(const float *
 // Adam (tf.train.AdamOptimizer form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)) over flat buffers
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, long long n,
-                                                   float lr_t, float b1, float b2, float eps, float grad_scale)
+                                                   float lr_t, float b1, float b2, float eps, float grad_scale,
+                                                   const float *__restrict__ lr_t_dev)
 {
+    if (lr_t_dev) lr_t = *lr_t_dev;  // (a captured launch reads the step's rate from memory: mpsr_adam_step_lr_dev)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
@@ -750,7 +752,20 @@ extern "C" int mpsr_adam_step(float *param, const float *grad, float *m, float *
     const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
     const float lr_t = (float)(lr * sqrt(c2) / c1);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, mpsr::as_stream(stream), param, grad, m, v, n, lr_t,
-                       beta1, beta2, eps, grad_scale);
+                       beta1, beta2, eps, grad_scale, (const float *)nullptr);
+    MPSR_CHECK_LAUNCH("adam_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_adam_step_lr_dev(float *param, const float *grad, float *m, float *v, long long n,
+                                     const float *lr_t_dev, float beta1, float beta2, float eps, float grad_scale,
+                                     mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(n >= 0, "adam_step_lr_dev: bad arguments");
+    if (n == 0) return MPSR_OK;
+    MPSR_REQUIRE(param && grad && m && v && lr_t_dev, "adam_step_lr_dev: null pointer");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, mpsr::as_stream(stream), param, grad, m, v, n, 0.f,
+                       beta1, beta2, eps, grad_scale, lr_t_dev);
     MPSR_CHECK_LAUNCH("adam_kernel");
     return MPSR_OK;
 }

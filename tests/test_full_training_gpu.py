@@ -214,3 +214,70 @@ def test_export_weights_round_trips_into_the_inference_net(tmp_path):
     n = "map_decoder/conv2/conv2_1"
     np.testing.assert_array_equal(eb[n + "/weights"], weights[n + "/weights"])
     np.testing.assert_array_equal(eb[n + "/BatchNorm/moving_variance"], weights[n + "/BatchNorm/moving_variance"])
+
+
+def test_captured_step_trains_like_the_eager_step():
+    """InstanceTrainer.capture_step(): the whole step as one HIP-graph launch.  Two trainers from the same weights, the
+    same batches (a different one every step: the replay must read the NEW sample), an exponentially decaying learning
+    rate (the captured Adam launch must read the NEW rate) and the parameter moving average: the losses of every step and
+    the parameters / Adam moments / averages after eight steps agree to the run-to-run spread of the weight gradient's
+    atomics."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    B, div, steps = 4, 4, 8
+    cfg = config_utils.default_config()
+    opt = cfg.train_config.optimizer.adam_optimizer
+    opt.learning_rate_type, opt.initial_learning_rate = 'exponential_decay', 2e-4
+    opt.decay_steps, opt.decay_factor, opt.staircase = 2, 0.8, True
+    opt.use_moving_average, opt.moving_average_decay = True, 0.9
+
+    def batches():
+        out = []
+        for i in range(steps):
+            rng = np.random.default_rng(500 + i)
+            y1, x1 = rng.uniform(0, 150, B), rng.uniform(0, 1000, B)
+            boxes = np.stack([y1, x1, y1 + rng.uniform(20, 200, B), x1 + rng.uniform(20, 200, B)], 1).astype(np.float32)
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            s = dict(rgb_image_crops=dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
+                     full_img_feature_crop=dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0)
+                                               .astype(np.float32)),
+                     boxes_2d=dev(boxes), cam_p=dev(np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2],
+                                                              [0, 0, 1, 0.003]], np.float32)),
+                     est_view_angs=dev(rng.uniform(-0.6, 0.6, (B, 1)).astype(np.float32)),
+                     class_indices=dev(np.ones((B, 1), np.int32)),
+                     mean_lwh=dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                     prop_cen_z_offset=dev(np.full((B,), 2.178, np.float32)))
+            s.update(trainer.synthetic_ground_truth(s, seed=600 + i))
+            out.append(s)
+        return out
+    data = batches()
+    runs = {}
+    for graphed in (False, True):
+        net = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
+        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
+        if graphed:
+            tr.capture_step(warmup=2)
+        losses = [float(tr.step(s)) for s in data]
+        torch.cuda.synchronize()
+        assert tr.global_step == steps and net.step_count == steps
+        runs[graphed] = (losses, net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), tr.optimizer.shadow.clone())
+    assert tr._graph.graph is not None  # steps 4..8 of the second run were replays
+    # (the weight gradient's atomics differ in the last bits from run to run and Adam's m / sqrt(v) amplifies that on
+    # small gradients: eager against eager shows the same spread.  A replay that ignored the new sample, the new learning
+    # rate or the moving average would be off by tens of percent in these measures.)
+    le, lg = runs[False][0], runs[True][0]
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(le[:1], lg[:1])), (le, lg)
+    assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    net0 = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
+    p0 = net0.params.clone()
+    for i, name in enumerate(("params", "average"), start=1):
+        a, b = runs[False][1 if name == "params" else 4] - p0, runs[True][1 if name == "params" else 4] - p0
+        rel = float((a - b).norm() / a.norm())
+        assert rel <= 0.03, (name, rel)
+    for i, name in ((2, "adam_m"), (3, "adam_v")):
+        a, b = runs[False][i], runs[True][i]
+        assert float((a - b).norm() / a.norm()) <= 0.10, name
+    # a sample of another shape is refused, not silently read through the captured tensors
+    bad = dict(data[0], rgb_image_crops=data[0]["rgb_image_crops"][:2])
+    with pytest.raises(ValueError):
+        tr.step(bad)
