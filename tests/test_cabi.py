@@ -64,3 +64,24 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.mpsr_conv2d_nhwc_f32(None, 1, 4, 4, 6, None, None, None, None, 8, 1, 1, 1, 0, 1, None, 0, None) == 1
     assert b"multiple of 4" in lib.mpsr_last_error()
     assert lib.mpsr_im2col_root(None, 1, 48, 48, None, 150, None) == 1
+
+
+def test_relu_bitmask_family_host_side():
+    """The training-side entry points added in round 4: size helper and shape predicates are pure host functions, and
+    argument errors are reported before anything touches the device."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    assert lib.mpsr_relu_bitmask_words(36864, 1024) == 1152 * 1024
+    assert lib.mpsr_relu_bitmask_words(33, 8) == 2 * 8 and lib.mpsr_relu_bitmask_words(0, 8) == 0
+    assert lib.mpsr_conv1x1_masked_applies(36864, 256, 1024) == 1   # block3 conv1's data gradient
+    assert lib.mpsr_conv1x1_masked_applies(36864, 1024, 256) == 1   # block3 conv3's
+    assert lib.mpsr_conv1x1_masked_applies(36864, 128, 512) == 0    # short K: conv + relu_grad
+    assert lib.mpsr_conv1x1_masked_applies(36864, 256, 24) == 0     # N not a multiple of 32
+    assert lib.mpsr_relu_bitmask(None, 64, 6, None, None) == 1 and b"multiple of 4" in lib.mpsr_last_error()
+    assert lib.mpsr_relu_bitmask(None, 0, 8, None, None) == 0       # empty: no-op
+    assert lib.mpsr_conv1x1_masked_f32(None, 64, 256, None, None, None, None, None, 64, None) == 1
+    assert b"null" in lib.mpsr_last_error()
+    assert lib.mpsr_conv1x1_relu_bitmask_f32(None, 0, 256, None, None, None, 1, None, None, 64, None) == 0
+    assert lib.mpsr_conv2d_relu_masked_f32(None, 1, 12, 12, 64, None, None, None, 64, 3, 3, 4, None, 0, None) == 1
+    assert lib.mpsr_adam_step_lr_dev(None, None, None, None, 0, None, 0.9, 0.999, 1e-8, 1.0, None) == 0
+    assert lib.mpsr_adam_step_lr_dev(None, None, None, None, 4, None, 0.9, 0.999, 1e-8, 1.0, None) == 1
