@@ -1021,6 +1021,7 @@ std::atomic<int> g_wino_policy{0};      // mpsr_set_winograd_policy: MPSR_WINOGR
 std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) / 3 F(3x3,3x3) on atrous sub-grids whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
+std::atomic<int> g_wino3_halo{1};    // mpsr_debug_set_wino3_halo: the tiled F(3x3,3x3) form (block2's atrous layers) in the automatic rule
 
 // Scratch a stream-K launch needs behind `ws`: two partial-tile slabs per workgroup, then one counter per tile.
 inline size_t sk_scratch_floats(int G, int BM, int BN, long long tiles)
@@ -1205,8 +1206,12 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
     const bool can3 = KH == 3 && KW == 3 && dilation > 1 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
                       winograd3_applies(H, W, C, dilation) && ws_floats >= winograd3_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
+    // (tiles of 3x3 outputs: th x th per pixel sub-grid; the automatic rule takes the forms that were measured -- one
+    // tile per sub-grid (block3, 12x12 at dilation 4) and 2 x 2 tiles with halos (block2, 12x12 at dilation 2))
+    const int th = can3 ? H / (3 * dilation) : 1;
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
-                                     (long long)B * dilation * dilation >= 1024 && C >= 64 && N >= 64);
+                                     th <= (g_wino3_halo.load() ? 2 : 1) &&
+                                     (long long)B * dilation * dilation * th * th >= 1024 && C >= 64 && N >= 64);
     return can3 && want3;
 }
 
@@ -1395,6 +1400,7 @@ extern "C" int mpsr_set_conv_math(int mode)
     return MPSR_OK;
 }
 extern "C" int mpsr_get_conv_math(void) { return g_math; }
+extern "C" void mpsr_debug_set_wino3_halo(int on) { g_wino3_halo = on; }
 
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
 // kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,

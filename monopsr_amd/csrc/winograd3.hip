@@ -40,7 +40,8 @@ constexpr unsigned OOB = 0x80000000u;
 struct Wino3Params {
     const float *x, *u, *bias;
     float *y;
-    int B, H, W, C, N, dil, T;  // T = B * dil * dil tiles
+    int B, H, W, C, N, dil, T;  // T = B * dil * dil * th * th tiles
+    int th;                     // 3x3 tiles per sub-grid side: 1 = the sub-grid IS one tile (zero ring), > 1 = tiles with halos
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes;
     // training (data-gradient launches): a tensor shaped like y; an output element is kept where mask[...] > 0 and written
@@ -78,8 +79,12 @@ __device__ __forceinline__ void at3(float m0, float m1, float m2, float m3, floa
 template <int V>
 using IC3 = std::integral_constant<int, V>;
 
-// NPOS = positions of this wave (6 or 7), DG = producer group (0: patches of the even K steps, 1: odd)
-template <int NPOS, int DG>
+// NPOS = positions of this wave (6 or 7), DG = producer group (0: patches of the even K steps, 1: odd).
+// HALO: the pixel sub-grids are larger than one tile (side 3 th, th > 1: ResNet-101 block2's atrous layers, 12x12 at
+// dilation 2 -> 6x6 sub-grids of 2x2 tiles): a tile's 5x5 patch then holds real neighbours -- 25 requests per patch
+// (those outside the sub-grid through an out-of-range offset) and the full transform, B^T d = the zero-ring form on
+// d1..d3 plus 2 d0 in row 0 and d4 in row 4 (9 operations per 1-D pass instead of 7).
+template <int NPOS, int DG, bool HALO>
 __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, const int t0, float *lds)
 {
     using namespace f3;
@@ -93,30 +98,61 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
 
     // ---- A producer: thread = (tile = sub-grid (img, a, b), channel of the step); nine 4-byte requests per patch
     const int lt = 8 * (wave & 3) + (lane >> 3), ch = lane & 7;
+    const int th = HALO ? p.th : 1, tpi = d * d * th * th;  // tiles per image
     unsigned abase;
+    unsigned voffc[3][3];  // HALO: the thread's offset by (row class, column class) of a patch element: first / inner / last
+    // HALO: descriptor moved back by one sub-grid row + column, so that patch element (0, 0) has a non-negative offset
+    const unsigned shift = HALO ? (unsigned)(d * p.W + d) * (unsigned)p.C * 4u : 0u;
+    char *xback = const_cast<char *>(reinterpret_cast<const char *>(p.x)) - shift;
     {
         const int t = t0 + lt;
-        const int img = t / (d * d), rem = t - img * d * d;
-        const int a = rem / d, b = rem - a * d;
-        abase = t < p.T ? (unsigned)(((img * p.H + a) * p.W + b) * p.C + ch) * 4u : OOB;
+        const int img = t / tpi, rem = t - img * tpi;
+        const int sub = rem / (th * th), tt = rem - sub * th * th;
+        const int a = sub / d, b = sub - a * d, ty = tt / th, tx = tt - ty * th;
+        // (+ shift: the offset of patch element (1, 1) = sub-grid pixel (3 ty, 3 tx) from the moved-back base is that of (0, 0))
+        abase = t < p.T ? (unsigned)(((img * p.H + a + 3 * d * ty) * p.W + b + 3 * d * tx) * p.C + ch) * 4u : OOB;
+        const bool rowc[3] = {ty > 0, true, ty < th - 1}, colc[3] = {tx > 0, true, tx < th - 1};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) voffc[u][v] = (t < p.T && rowc[u] && colc[v]) ? abase : OOB;
     }
-    float pa[25];  // 5x5: the 3x3 data arrives in the middle, the transforms expand it in place
+    float pa[25];  // 5x5: the 3x3 data arrives in the middle, the transforms expand it in place (HALO: all 25 arrive)
     auto load_patch1 = [&](int step, int L) __attribute__((always_inline)) {
-        const int j = L / 3, i = L % 3;  // column by column
 #ifdef W3_SKIP_LOAD
         if (step > 1) return;
 #endif
         const bool live = step < nsteps;
-        const __amdgpu_buffer_rsrc_t rr =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, live ? (int)p.xbytes : 0, 0x00020000);
-        const unsigned so = (unsigned)((d * i * p.W + d * j) * p.C + (live ? step : 0) * KC) * 4u;
-        pa[5 * (i + 1) + (j + 1)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, abase, so, 0));
+        if constexpr (HALO) {
+            const int s_ = L / 5, r_ = L % 5;  // column by column
+            const __amdgpu_buffer_rsrc_t rr =
+                __builtin_amdgcn_make_buffer_rsrc(xback, 0, live ? (int)(p.xbytes + shift) : 0, 0x00020000);
+            const unsigned so = (unsigned)((d * r_ * p.W + d * s_) * p.C + (live ? step : 0) * KC) * 4u;
+            pa[5 * r_ + s_] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rr, voffc[r_ == 0 ? 0 : r_ == 4 ? 2 : 1][s_ == 0 ? 0 : s_ == 4 ? 2 : 1],
+                                                            so, 0));
+        } else {
+            const int j = L / 3, i = L % 3;  // column by column
+            const __amdgpu_buffer_rsrc_t rr =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, live ? (int)p.xbytes : 0, 0x00020000);
+            const unsigned so = (unsigned)((d * i * p.W + d * j) * p.C + (live ? step : 0) * KC) * 4u;
+            pa[5 * (i + 1) + (j + 1)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, abase, so, 0));
+        }
     };
-    auto vertical = [&](int j) __attribute__((always_inline)) {  // data column j (0..2) -> all five rows of it
+    auto vertical = [&](int j) __attribute__((always_inline)) {  // data column j (0..2; HALO: patch column j - 1 + 1 = 0..4) -> all five rows of it
 #ifdef W3_SKIP_VALU
         return;
 #endif
         float t0_, t1_, t2_, t3_, t4_;
+        if constexpr (HALO) {  // j = patch column 0..4
+            bt5(pa[5 + j], pa[10 + j], pa[15 + j], t0_, t1_, t2_, t3_, t4_);
+            pa[j] = fmaf(2.f, pa[j], t0_);
+            pa[5 + j] = t1_;
+            pa[10 + j] = t2_;
+            pa[15 + j] = t3_;
+            pa[20 + j] = pa[20 + j] + t4_;
+            return;
+        }
         bt5(pa[5 + j + 1], pa[10 + j + 1], pa[15 + j + 1], t0_, t1_, t2_, t3_, t4_);
         pa[j + 1] = t0_;
         pa[5 + j + 1] = t1_;
@@ -124,12 +160,16 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
         pa[15 + j + 1] = t3_;
         pa[20 + j + 1] = t4_;
     };
-    auto horizontal = [&](int r) __attribute__((always_inline)) {  // row r (0..4): three values -> five
+    auto horizontal = [&](int r) __attribute__((always_inline)) {  // row r (0..4): three values -> five (HALO: five -> five)
 #ifdef W3_SKIP_VALU
         return;
 #endif
         float t0_, t1_, t2_, t3_, t4_;
         bt5(pa[5 * r + 1], pa[5 * r + 2], pa[5 * r + 3], t0_, t1_, t2_, t3_, t4_);
+        if constexpr (HALO) {
+            t0_ = fmaf(2.f, pa[5 * r], t0_);
+            t4_ = pa[5 * r + 4] + t4_;
+        }
         pa[5 * r] = t0_;
         pa[5 * r + 1] = t1_;
         pa[5 * r + 2] = t2_;
@@ -209,12 +249,33 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
     // would collide with the next row's arithmetic only in issue order, not in data: stores of row r use finished values)
     auto request = [&](int step) __attribute__((always_inline)) {
         return [&, step](int slot) __attribute__((always_inline)) {
-            if (slot >= 3 && slot < 12) load_patch1(step, slot - 3);
+            if constexpr (HALO) {  // 25 requests: one per slot, the last slot two
+                load_patch1(step, slot);
+                if (slot == 23) load_patch1(step, 24);
+            } else {
+                if (slot >= 3 && slot < 12) load_patch1(step, slot - 3);
+            }
         };
     };
     auto transform = [&](auto buf_c) __attribute__((always_inline)) {
         return [&](int slot) __attribute__((always_inline)) {
             constexpr int buf = decltype(buf_c)::value;
+            if constexpr (HALO) {  // slots 0..4 the five column transforms, 5, 7, .. 13 the rows, a row's stores behind it
+                if (slot < 5) vertical(slot);
+                else if (slot < 15 && ((slot - 5) & 1) == 0) horizontal((slot - 5) >> 1);
+                if (slot >= 6 && slot < 16) {
+                    const int r = (slot - 6) >> 1;
+                    if (((slot - 6) & 1) == 0) {
+                        store_a(buf, 5 * r);
+                        store_a(buf, 5 * r + 1);
+                        store_a(buf, 5 * r + 2);
+                    } else {
+                        store_a(buf, 5 * r + 3);
+                        store_a(buf, 5 * r + 4);
+                    }
+                }
+                return;
+            }
             if (slot < 3) vertical(slot);
             else if (slot < 13 && ((slot - 3) & 1) == 0) horizontal((slot - 3) >> 1);  // slots 3, 5, 7, 9, 11
             // row r is complete after slot 3 + 2 r: its five stores go to slots 4 + 2 r (three) and 5 + 2 r... the
@@ -237,10 +298,10 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
 #pragma unroll
     for (int j = 0; j < 3; ++j) load_b1(0, j, 0, j);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) load_patch1(DG, i);
+    for (int i = 0; i < (HALO ? 25 : 9); ++i) load_patch1(DG, i);
     if (DG == 0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) vertical(j);
+        for (int j = 0; j < (HALO ? 5 : 3); ++j) vertical(j);
 #pragma unroll
         for (int r = 0; r < 5; ++r) horizontal(r);
 #pragma unroll
@@ -300,8 +361,9 @@ __device__ __forceinline__ void wino3_body(const Wino3Params &p, const int n0, c
                 mwr[q * (16 * NT) + trow * NT] = acc[q][8 * round + e8];
             }
         const int tt = t0 + 16 * round + (tid2 >> 5);
-        const int img = tt / (d * d), rem = tt - img * d * d;
-        const int a = rem / d, b = rem - a * d;
+        const int img = tt / tpi, rem = tt - img * tpi;
+        const int sub = rem / (th * th), tq = rem - sub * th * th;
+        const int a = sub / d + 3 * d * (tq / th), b = sub % d + 3 * d * (tq % th);  // pixel (0, 0) of the tile
         // (the mask values of this thread's 2 x 9 outputs are requested in front of the barrier the exchange needs anyway)
         float mk[2][9];
         if (p.mask) {  // block-uniform
@@ -356,9 +418,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int n0 = nb * f3::NT, t0 = mb * f3::MT;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // three straight-line copies selected once: the K loop never sees a branch on the wave's role
-    if (wave < 4) wino3_body<6, 0>(p, n0, t0, lds);
-    else if (wave < 6) wino3_body<6, 1>(p, n0, t0, lds);
-    else wino3_body<7, 1>(p, n0, t0, lds);
+    if (wave < 4) wino3_body<6, 0, false>(p, n0, t0, lds);
+    else if (wave < 6) wino3_body<6, 1, false>(p, n0, t0, lds);
+    else wino3_body<7, 1, false>(p, n0, t0, lds);
+}
+
+// the same with tiles that have neighbours inside their sub-grid (Wino3Params::th > 1)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3h_conv_kernel(const Wino3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int xcd = blockIdx.x & 7, l_ = blockIdx.x >> 3;
+    const int nb = l_ % p.nblocks;
+    const int mb = (l_ / p.nblocks) * 8 + xcd;
+    if (mb >= p.mblocks) return;  // block-uniform
+    const int n0 = nb * f3::NT, t0 = mb * f3::MT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) wino3_body<6, 0, true>(p, n0, t0, lds);
+    else if (wave < 6) wino3_body<6, 1, true>(p, n0, t0, lds);
+    else wino3_body<7, 1, true>(p, n0, t0, lds);
 }
 
 }  // namespace
@@ -371,25 +448,28 @@ thread_local FilterCacheSlot g_filter_cache_slot;
 
 size_t winograd3_scratch_floats(int C, int N) { return (size_t)f3::NP * N * C; }
 
-// 3x3, dilation d, H = W = 3 d (the sub-grids are 3x3), C % 16 == 0
+// 3x3, dilation d, H = W = 3 d th (the sub-grids are 3 th x 3 th: th x th tiles of 3x3; th = 1: ResNet-101 block3 at
+// output stride 4, th = 2: block2), C % 16 == 0
 bool winograd3_applies(int H, int W, int C, int dilation)
 {
-    return dilation >= 1 && H == 3 * dilation && W == 3 * dilation && C % 16 == 0 && C >= 16;
+    return dilation >= 1 && H == W && H % (3 * dilation) == 0 && H / (3 * dilation) <= 16 && C % 16 == 0 && C >= 16;
 }
 
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
                       float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s, const float *mask)
 {
     using namespace f3;
-    MPSR_REQUIRE(winograd3_applies(H, W, C, dilation), "conv3x3_winograd3: needs H = W = 3 * dilation and C %% 16 == 0");
+    MPSR_REQUIRE(winograd3_applies(H, W, C, dilation),
+                 "conv3x3_winograd3: needs H = W = a multiple of 3 * dilation and C %% 16 == 0");
     if (ws_floats < winograd3_scratch_floats(C, N) || !ws)
         return fail(MPSR_ERR_WORKSPACE, "conv3x3_winograd3: scratch holds %zu floats, needs %zu", ws_floats,
                     winograd3_scratch_floats(C, N));
     const long long xbytes = (long long)B * H * W * C * 4;
     MPSR_REQUIRE(xbytes < 0x7ff00000LL && winograd3_scratch_floats(C, N) * 4 < 0x7ff00000ULL,
                  "conv3x3_winograd3: tensor exceeds the 2 GiB this kernel's offsets address; split the batch");
-    MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino3_conv_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
+    const int th = H / (3 * dilation);
+    const void *kern = th > 1 ? reinterpret_cast<const void *>(wino3h_conv_kernel) : reinterpret_cast<const void *>(wino3_conv_kernel);
+    MPSR_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
     // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer
     float *u = ws;
     bool ready = false;
@@ -410,7 +490,8 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     Wino3Params p;
     p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
-    p.T = B * dilation * dilation;
+    p.th = th;
+    p.T = B * dilation * dilation * th * th;
     p.cblocks = C / KC;
     p.nblocks = ceil_div(N, NT);
     p.mblocks = ceil_div(p.T, MT);
@@ -419,7 +500,8 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     p.ubytes = (unsigned)(winograd3_scratch_floats(C, N) * 4);
     const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd3: grid too large");
-    hipLaunchKernelGGL(wino3_conv_kernel, dim3((unsigned)blocks), dim3(512), LDSF * sizeof(float), s, p);
+    if (th > 1) hipLaunchKernelGGL(wino3h_conv_kernel, dim3((unsigned)blocks), dim3(512), LDSF * sizeof(float), s, p);
+    else hipLaunchKernelGGL(wino3_conv_kernel, dim3((unsigned)blocks), dim3(512), LDSF * sizeof(float), s, p);
     MPSR_CHECK_LAUNCH("wino3_conv_kernel");
     return MPSR_OK;
 }

@@ -449,19 +449,23 @@ def test_fc_few_rows_vs_fp64(M, K, N, has_bias, has_res, relu):
     _close(got, gemm, 1e-5, "few-row FC vs implicit GEMM")
 
 
-@pytest.mark.parametrize("B,dil,C,N,has_bias,relu", [
-    (8, 4, 64, 64, True, True), (3, 4, 32, 40, False, False), (1, 4, 16, 4, True, False), (5, 2, 48, 200, True, True),
-    (64, 4, 256, 256, True, True), (7, 3, 16, 65, True, True), (33, 4, 128, 128, True, True)])
-def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu):
+@pytest.mark.parametrize("B,dil,C,N,has_bias,relu,th", [
+    (8, 4, 64, 64, True, True, 1), (3, 4, 32, 40, False, False, 1), (1, 4, 16, 4, True, False, 1),
+    (5, 2, 48, 200, True, True, 1), (64, 4, 256, 256, True, True, 1), (7, 3, 16, 65, True, True, 1),
+    (33, 4, 128, 128, True, True, 1),
+    # tiles with halos: th x th tiles per pixel sub-grid (block2's conv2 is 12x12 at dilation 2 = 6x6 sub-grids)
+    (64, 2, 128, 128, True, True, 2), (3, 2, 32, 40, False, False, 2), (2, 2, 16, 65, True, True, 3),
+    (5, 3, 48, 24, True, False, 2), (1, 2, 16, 8, False, True, 4)])
+def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     """The Winograd F(3x3,3x3) kernel for atrous 3x3 layers whose pixel sub-grids are 3x3 (csrc/winograd3.hip: H = W =
-    3 * dilation; block3's conv2 is 12x12 at dilation 4): ragged tile / channel counts, the seven-position waves, the
-    real layer shape.  Against float64 (1e-5 of the tensor scale; measured ~5e-6), deterministic, and really another
+    3 * dilation; block3's conv2 is 12x12 at dilation 4) or th x th tiles of 3x3 with halos (H = W = 3 * dilation * th;
+    block2's conv2 is 12x12 at dilation 2): ragged tile / channel counts, the seven-position waves, the real layer shapes.  Against float64 (1e-5 of the tensor scale; measured ~5e-6), deterministic, and really another
     evaluation than the border-class implicit GEMM (which must agree to 1e-5 as well)."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
-    H = 3 * dil
-    rng = np.random.default_rng(B * 1000 + C + N + dil)
+    H = 3 * dil * th
+    rng = np.random.default_rng(B * 1000 + C + N + dil + 7 * th)
     x = rng.standard_normal((B, H, H, C)).astype(np.float32)
     w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
