@@ -1203,14 +1203,15 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
 {
     const int wino = winograd_mode();
     const long long M64 = (long long)B * H * W;
-    const bool can3 = KH == 3 && KW == 3 && dilation > 1 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
+    const bool can3 = KH == 3 && KW == 3 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
                       winograd3_applies(H, W, C, dilation) && ws_floats >= winograd3_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
     // (tiles of 3x3 outputs: th x th per pixel sub-grid; the automatic rule takes the forms that were measured -- one
-    // tile per sub-grid (block3, 12x12 at dilation 4) and 2 x 2 tiles with halos (block2, 12x12 at dilation 2))
+    // tile per sub-grid (block3, 12x12 at dilation 4), 2 x 2 tiles with halos (block2, 12x12 at dilation 2) and the dense
+    // 3x3 layers of 12x12 maps as 4 x 4 tiles (block1: too few 4x4 blocks for the F(4x4) kernel's workgroups))
     const int th = can3 ? H / (3 * dilation) : 1;
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
-                                     th <= (g_wino3_halo.load() ? 2 : 1) &&
+                                     th <= (!g_wino3_halo.load() ? 1 : dilation > 1 ? 2 : 4) && (dilation > 1 || th > 1) &&
                                      (long long)B * dilation * dilation * th * th >= 1024 && C >= 64 && N >= 64);
     return can3 && want3;
 }
