@@ -339,7 +339,7 @@ def roofline_object(net, args, device, ms_per_step):
     fp32 = args.math == "fp32"
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
     kname = "fp32 MFMA 32x32x2 convolution / FC kernels: pw_conv_kernel (wide 1x1 layers and the decoder's tap GEMMs), " \
-            "wino3_conv_kernel (F(3x3,3x3), block3's atrous 3x3), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
+            "wino3_conv_kernel / wino3h_conv_kernel (F(3x3,3x3): block3's atrous 3x3 as one tile per pixel sub-grid, the 3x3 layers of blocks 1-2 as tiles with halos), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
             "conv3_2), conv_igemm_kernel / conv_sk_kernel (blocks 1-2, root, img_fc), fc_rows_kernel, " \
             "conv3x3_narrow_mfma_kernel" if fp32 else \
         "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
@@ -362,7 +362,7 @@ def roofline_object(net, args, device, ms_per_step):
     if fp32:
         out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
                                "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0),
-                               "winograd_f3x3_3x3_atrous_subgrids": kinds.get(4, 0),
+                               "winograd_f3x3_3x3_subgrid_tiles": kinds.get(4, 0),
                                "pointwise_persistent": kinds.get(5, 0), "fc_few_rows": kinds.get(6, 0),
                                "upsampled_conv_tap_gemm": kinds.get(7, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
