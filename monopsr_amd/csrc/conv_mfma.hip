@@ -1210,8 +1210,12 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
     // tile per sub-grid (block3, 12x12 at dilation 4), 2 x 2 tiles with halos (block2, 12x12 at dilation 2) and the dense
     // 3x3 layers of 12x12 maps as 4 x 4 tiles (block1: too few 4x4 blocks for the F(4x4) kernel's workgroups))
     const int th = can3 ? H / (3 * dilation) : 1;
+    // ... and, at batches too small for the F(4x4) kernel's 32-tile workgroups to fill the chip (the reference's own
+    // 32 boxes per image: its rule wants 65536 pixels), the decoder's dense 3x3 layers as up to 16 x 16 tiles of 3x3:
+    // 204 -> 79 us (24x24x256, B = 32), 115 -> 83 us (48x48x128)
+    const int th_max = !g_wino3_halo.load() ? 1 : dilation > 1 ? 2 : conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats) ? 4 : 16;
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
-                                     th <= (!g_wino3_halo.load() ? 1 : dilation > 1 ? 2 : 4) && (dilation > 1 || th > 1) &&
+                                     th <= th_max && (dilation > 1 || th > 1) &&
                                      (long long)B * dilation * dilation * th * th >= 1024 && C >= 64 && N >= 64);
     return can3 && want3;
 }
