@@ -232,35 +232,47 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
 // workgroup per (image, 8-channel block) read 32 of every 128 bytes and took 1.06 ms on conv3_1) -- next to the
 // (upsampled index, weight) pairs of this source row and of every source column.  Item = (source column, tap, channel quad).
 constexpr int kGtMax = 8;  // most upsampled rows (columns) that interpolate from one source row (column)
+constexpr int kGtPf = 6;   // float4 registers per thread that carry the rows a step adds on their way into the ring
+constexpr int kGtItemsA = 6, kGtItemsB = 8;  // most items per thread of the two passes of a step (3 W 8 / 256, 72 w / 256)
 
 struct UpcGradParams {
     const float *dy;
     float *dz;
-    int B, h, w, H, W, N, rows_max;
+    int B, h, w, H, W, N, rows_max, cap;  // cap: rows of the ring, a power of two >= rows_max
     float hscale, wscale;
 };
 
+// One workgroup per (32-channel group, image) WALKS the source rows: the dy rows a source row reaches (the upsampled rows
+// that interpolate from it, one more on each side for the taps) live in a ring of `cap` rows in LDS, [row][x][32 channels]
+// = whole 128-byte lines of the NHWC gradient; a step adds the (about `scale`) rows its successor needs -- requested into
+// registers before the step's arithmetic, written to the ring after it -- so every dy row is fetched ONCE (the first form,
+// one workgroup per source row, fetched each ~3.5 times and waited for its whole window in front of 4 us of arithmetic:
+// 0.58 ms on conv3_1; r04).  Per step, separable: V[dy][x] = sum_ky wy[ky] dy[yq[ky] - dy][x] for the three tap rows, then
+// dz[sy][sx][t] = sum_kx wx[kx] V[dy(t)][xq[kx] - dx(t)].  The (index, weight) tables of every source row and column are
+// made once per workgroup by the forward kernel's own arithmetic.
 __global__ __launch_bounds__(256) void upconv_gather_t_kernel(const UpcGradParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 g4[];  // [rows_max][W][8]
-    __shared__ int yq[kGtMax];
-    __shared__ float yw[kGtMax];
-    __shared__ int ycnt, yrange[2];
+    extern __shared__ __attribute__((aligned(16))) float4 g4[];  // ring [cap][W][8] | V [3][W][8] | tables
     const int tid = threadIdx.x;
-    const int grp = blockIdx.x, sy = blockIdx.y, b = blockIdx.z;
-    int *xq = reinterpret_cast<int *>(g4 + (size_t)p.rows_max * p.W * 8 + (size_t)3 * p.W * 8);  // [w][kGtMax], behind V
+    const int grp = blockIdx.x, b = blockIdx.y;
+    const int rowq = p.W * 8;  // float4 per dy row of this channel group
+    float4 *V = g4 + (size_t)p.cap * rowq;
+    int *xq = reinterpret_cast<int *>(V + (size_t)3 * rowq);  // [w][kGtMax]
     float *xw = reinterpret_cast<float *>(xq + p.w * kGtMax);
-    int *xc = reinterpret_cast<int *>(xw + p.w * kGtMax);
-    // (upsampled index, weight) pairs by the forward kernel's own arithmetic: this source row (thread 0), every source
-    // column (threads 1 .. w).  q interpolates from s iff floor(q scale) is s - 1 or s: only q in
-    // [(s - 1) / scale, (s + 1) / scale] need a look
-    if (tid <= p.w) {
-        const bool row = tid == 0;
-        const int sv = row ? sy : tid - 1, n_in = row ? p.h : p.w, n_out = row ? p.H : p.W;
+    int *xc = reinterpret_cast<int *>(xw + p.w * kGtMax);     // [w]
+    int *yq = xc + ((p.w + 3) & ~3);                           // [h][kGtMax] (16-byte aligned: read as int4)
+    float *yw = reinterpret_cast<float *>(yq + p.h * kGtMax);
+    int *yc = reinterpret_cast<int *>(yw + p.h * kGtMax);     // [h]
+    int *ylo = yc + p.h, *yhi = ylo + p.h;                     // [h]: first / last dy row a source row reaches
+    // (upsampled index, weight) pairs: q interpolates from s iff floor(q scale) is s - 1 or s -- only q in
+    // [(s - 1) / scale, (s + 1) / scale] need a look.  Thread t < h: source row t; h <= t < h + w: source column t - h.
+    for (int t = tid; t < p.h + p.w; t += 256) {
+        const bool row = t < p.h;
+        const int sv = row ? t : t - p.h, n_in = row ? p.h : p.w, n_out = row ? p.H : p.W;
         const float scale = row ? p.hscale : p.wscale;
         const int q_lo = max((int)floorf((float)(sv - 1) / scale) - 1, 0), q_hi = min((int)ceilf((float)(sv + 1) / scale) + 1, n_out - 1);
-        int *oq = row ? yq : xq + sv * kGtMax;
-        float *ow = row ? yw : xw + sv * kGtMax;
+        int *oq = row ? yq + sv * kGtMax : xq + sv * kGtMax;
+        float *ow = row ? yw + sv * kGtMax : xw + sv * kGtMax;
         int c = 0, lo = n_out, hi = -1;
         for (int q = q_lo; q <= q_hi; ++q) {
             const float sq = (float)q * scale;
@@ -275,72 +287,149 @@ __global__ __launch_bounds__(256) void upconv_gather_t_kernel(const UpcGradParam
             }
         }
         if (row) {
-            ycnt = c;
-            yrange[0] = max(lo - 1, 0);
-            yrange[1] = min(hi + 1, p.H - 1);
+            yc[sv] = c;
+            ylo[sv] = c ? max(lo - 1, 0) : 0;
+            yhi[sv] = c ? min(hi + 1, p.H - 1) : -1;
         } else {
             xc[sv] = c;
         }
     }
     __syncthreads();
-    const int rlo = yrange[0], nrows = yrange[1] - rlo + 1;
-    {  // dy rows rlo .. rhi of this image, channels 32 grp .. + 31: 8 float4 per pixel, contiguous; loads issued in
-       // batches of kPf before they are stored (a load -> store loop waits for every round trip in turn)
-        const float *src = p.dy + (((size_t)b * p.H + rlo) * p.W) * p.N + grp * 32;
-        const int total = nrows * p.W * 8;
-        for (int first = 0; first < total; first += kPf * 256) {
-            f32x4 pf[kPf];
+    const float *src = p.dy + ((size_t)b * p.H * p.W) * p.N + grp * 32;  // this image, this channel group
+    const int mask = p.cap - 1;
+    f32x4 pf[kGtPf];
+    // rows [r0, r1] of dy: requests into the registers (items tid, tid + 256, ...), then the ring
+    auto request = [&](int r0, int r1) __attribute__((always_inline)) {
+        const int total = (r1 - r0 + 1) * rowq;
 #pragma unroll
-            for (int j = 0; j < kPf; ++j) {
-                const int i = first + j * 256 + tid;
-                pf[j] = *reinterpret_cast<const f32x4 *>(i < total ? src + (size_t)(i >> 3) * p.N + 4 * (i & 7) : src);
-            }
-#pragma unroll
-            for (int j = 0; j < kPf; ++j) {
-                const int i = first + j * 256 + tid;
-                if (i < total) reinterpret_cast<f32x4 *>(g4)[i] = pf[j];
-            }
+        for (int j = 0; j < kGtPf; ++j) {
+            const int i = j * 256 + tid;
+            const int r = r0 + i / rowq, c = i - (i / rowq) * rowq;
+            pf[j] = *reinterpret_cast<const f32x4 *>(i < total ? src + ((size_t)r * p.W + (c >> 3)) * p.N + 4 * (c & 7) : src);
         }
+    };
+    auto commit = [&](int r0, int r1) __attribute__((always_inline)) {
+        const int total = (r1 - r0 + 1) * rowq;
+#pragma unroll
+        for (int j = 0; j < kGtPf; ++j) {
+            const int i = j * 256 + tid;
+            const int r = r0 + i / rowq, c = i - (i / rowq) * rowq;
+            if (i < total) reinterpret_cast<f32x4 *>(g4)[(size_t)(r & mask) * rowq + c] = pf[j];
+        }
+    };
+    // the first source row's window, kGtPf * 256 float4 at a time
+    int have = -1;  // last dy row in the ring
+    {
+        int hi0 = -1;
+        for (int sy = 0; sy < p.h && hi0 < 0; ++sy) hi0 = yhi[sy];  // (a source row that nothing interpolates from has no window)
+        const int lo0 = 0;
+        const int rows_per = max(1, (kGtPf * 256) / rowq);
+        for (int r = lo0; r <= hi0; r += rows_per) {
+            const int re = min(hi0, r + rows_per - 1);
+            request(r, re);
+            commit(r, re);
+        }
+        have = hi0;
     }
     __syncthreads();
-    // Separable: first the row direction -- V[dy][x][quad] = sum_ky wy[ky] dy[yq[ky] - dy][x] for the three tap rows, into
-    // LDS behind the rows -- then the column direction from V: 2.4x fewer inner iterations than the direct double sum.
-    const int ny = ycnt;
-    float4 *V = g4 + (size_t)p.rows_max * p.W * 8;  // [3][W][8]   (the column table sits behind it)
-    for (int it = tid; it < 3 * p.W * 8; it += 256) {
-        const int d = it / (p.W * 8), r = it - d * (p.W * 8);  // r = x * 8 + quad
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-        for (int ky = 0; ky < ny; ++ky) {
-            const int py = yq[ky] - (d - 1);
-            if (py < 0 || py >= p.H) continue;
-            const float4 v = g4[(size_t)(py - rlo) * p.W * 8 + r];
-            const f32x2 w2 = {yw[ky], yw[ky]};
-            a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
-            a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
-        }
-        V[it] = make_float4(a01.x, a01.y, a23.x, a23.y);
+    float *dzimg = p.dz + ((size_t)b * p.h * p.w) * 9 * p.N + (size_t)grp * 4 * 72;
+    // a thread's items are the same for every source row: decoded once (the divisions were a third of the kernel's
+    // instructions -- it is bound by its vector instructions, not by memory)
+    int a_d[kGtItemsA], a_r[kGtItemsA];
+#pragma unroll
+    for (int k = 0; k < kGtItemsA; ++k) {
+        const int it = tid + 256 * k;
+        a_d[k] = it < 3 * rowq ? it / rowq : -1;
+        a_r[k] = it - max(a_d[k], 0) * rowq;  // x * 8 + quad
     }
-    __syncthreads();
-    float *dzrow = p.dz + (((size_t)b * p.h + sy) * p.w) * 9 * p.N + (size_t)grp * 4 * 72;
-    const int nitems = p.w * 72;  // (source column, tap, channel quad)
-    for (int it = tid; it < nitems; it += 256) {
-        const int sx = it / 72, r = it - sx * 72, t = r >> 3, quad = r & 7;
-        const int d = t / 3, dx = t - d * 3 - 1;
-        const int nx = xc[sx];
-        const int *qix = xq + sx * kGtMax;
-        const float *qwx = xw + sx * kGtMax;
-        const float4 *row = V + (size_t)d * p.W * 8 + quad;
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-        for (int kx = 0; kx < nx; ++kx) {
-            const int px = qix[kx] - dx;
-            if (px < 0 || px >= p.W) continue;
-            const float4 v = row[px * 8];
-            const f32x2 w2 = {qwx[kx], qwx[kx]};
-            a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
-            a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+    int b_sx[kGtItemsB], b_v[kGtItemsB], b_dx[kGtItemsB], b_out[kGtItemsB];
+#pragma unroll
+    for (int k = 0; k < kGtItemsB; ++k) {
+        const int it = tid + 256 * k;
+        // (m = the float4's place in the 1152 contiguous bytes of (source pixel, channel group): consecutive lanes
+        // write consecutive pieces -- a wave's store is eight whole lines)
+        const int sx = it / 72, m = it - sx * 72, blk = m / 18, rem = m - 18 * blk, t = rem >> 1, quad = 2 * blk + (rem & 1);
+        const int d = t / 3;
+        b_sx[k] = it < p.w * 72 ? sx : -1;
+        b_v[k] = d * rowq + quad;
+        b_dx[k] = t - d * 3 - 1;
+        b_out[k] = sx * 9 * p.N + 4 * m;
+    }
+    for (int sy = 0; sy < p.h; ++sy) {
+        // the rows the NEXT source row adds: requested now, in the ring after this row's arithmetic
+        const int next_hi = sy + 1 < p.h ? max(yhi[sy + 1], have) : have;
+        const bool more = next_hi > have;
+        if (more) request(have + 1, next_hi);
+        // (the first four (index, weight) pairs of a row / column as one 16-byte read each and branch-free -- a pair
+        // that does not apply gets weight 0 and a clamped address --, so that an item is two LDS round trips deep
+        // instead of two per pair: the kernel was bound by those dependent reads at two waves per SIMD)
+        const int ny = yc[sy];
+        const int4 yq4 = *reinterpret_cast<const int4 *>(yq + sy * kGtMax);
+        const float4 yw4 = *reinterpret_cast<const float4 *>(yw + sy * kGtMax);
+#pragma unroll
+        for (int k = 0; k < kGtItemsA; ++k) {
+            const int d = a_d[k], r = a_r[k], it = tid + 256 * k;
+            if (d < 0) continue;
+            const int py0 = yq4.x - (d - 1), py1 = yq4.y - (d - 1), py2 = yq4.z - (d - 1), py3 = yq4.w - (d - 1);
+            const float w0 = (ny > 0 && py0 >= 0 && py0 < p.H) ? yw4.x : 0.f, w1 = (ny > 1 && py1 >= 0 && py1 < p.H) ? yw4.y : 0.f;
+            const float w2 = (ny > 2 && py2 >= 0 && py2 < p.H) ? yw4.z : 0.f, w3 = (ny > 3 && py3 >= 0 && py3 < p.H) ? yw4.w : 0.f;
+            const float4 v0 = g4[(size_t)(py0 & mask) * rowq + r], v1 = g4[(size_t)(py1 & mask) * rowq + r];
+            const float4 v2 = g4[(size_t)(py2 & mask) * rowq + r], v3 = g4[(size_t)(py3 & mask) * rowq + r];
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            auto acc = [&](float wv, const float4 &v) __attribute__((always_inline)) {
+                const f32x2 w2_ = {wv, wv};
+                a01 = __builtin_elementwise_fma(w2_, f32x2{v.x, v.y}, a01);
+                a23 = __builtin_elementwise_fma(w2_, f32x2{v.z, v.w}, a23);
+            };
+            // (a slot whose weight is 0 may hold anything, NaN included: select, do not multiply)
+            if (w0 != 0.f) acc(w0, v0);
+            if (w1 != 0.f) acc(w1, v1);
+            if (w2 != 0.f) acc(w2, v2);
+            if (w3 != 0.f) acc(w3, v3);
+            for (int ky = 4; ky < ny; ++ky) {
+                const int py = yq[sy * kGtMax + ky] - (d - 1);
+                if (py < 0 || py >= p.H) continue;
+                acc(yw[sy * kGtMax + ky], g4[(size_t)(py & mask) * rowq + r]);
+            }
+            V[it] = make_float4(a01.x, a01.y, a23.x, a23.y);
         }
-        *reinterpret_cast<float4 *>(dzrow + (size_t)sx * 9 * p.N + (quad >> 1) * 72 + t * 8 + 4 * (quad & 1)) =
-            make_float4(a01.x, a01.y, a23.x, a23.y);
+        __syncthreads();  // V complete; every read of the ring for this source row is done
+        float *dzrow = dzimg + (size_t)sy * p.w * 9 * p.N;
+#pragma unroll
+        for (int k = 0; k < kGtItemsB; ++k) {  // item = (source column, tap, channel quad)
+            const int sx = b_sx[k], dx = b_dx[k];
+            if (sx < 0) continue;
+            const int nx = xc[sx];
+            const int4 q4 = *reinterpret_cast<const int4 *>(xq + sx * kGtMax);
+            const float4 w4 = *reinterpret_cast<const float4 *>(xw + sx * kGtMax);
+            const float4 *row = V + b_v[k];
+            const int px0 = q4.x - dx, px1 = q4.y - dx, px2 = q4.z - dx, px3 = q4.w - dx;
+            const bool ok0 = nx > 0 && px0 >= 0 && px0 < p.W, ok1 = nx > 1 && px1 >= 0 && px1 < p.W;
+            const bool ok2 = nx > 2 && px2 >= 0 && px2 < p.W, ok3 = nx > 3 && px3 >= 0 && px3 < p.W;
+            const float4 v0 = row[(ok0 ? px0 : 0) * 8], v1 = row[(ok1 ? px1 : 0) * 8];
+            const float4 v2 = row[(ok2 ? px2 : 0) * 8], v3 = row[(ok3 ? px3 : 0) * 8];
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            auto acc = [&](float wv, const float4 &v) __attribute__((always_inline)) {
+                const f32x2 w2_ = {wv, wv};
+                a01 = __builtin_elementwise_fma(w2_, f32x2{v.x, v.y}, a01);
+                a23 = __builtin_elementwise_fma(w2_, f32x2{v.z, v.w}, a23);
+            };
+            if (ok0) acc(w4.x, v0);
+            if (ok1) acc(w4.y, v1);
+            if (ok2) acc(w4.z, v2);
+            if (ok3) acc(w4.w, v3);
+            for (int kx = 4; kx < nx; ++kx) {
+                const int px = xq[sx * kGtMax + kx] - dx;
+                if (px < 0 || px >= p.W) continue;
+                acc(xw[sx * kGtMax + kx], row[px * 8]);
+            }
+            *reinterpret_cast<float4 *>(dzrow + b_out[k]) = make_float4(a01.x, a01.y, a23.x, a23.y);
+        }
+        // (as late as possible: the requests have had the whole step to land; overwrites rows below the next window --
+        // cap >= the widest window -- that nobody reads any more since the barrier above)
+        if (more) commit(have + 1, next_hi);
+        have = next_hi;
+        __syncthreads();  // the ring holds the next window; V may be overwritten
     }
 }
 
@@ -535,8 +624,36 @@ static int gather_t_rows(int h, int OH, float hscale)
     }
     return most;
 }
-// LDS of upconv_gather_t_kernel: those rows for 32 channels + the three row-reduced rows V + the column table
-static size_t gather_t_lds_bytes(int rows, int w, int OW) { return (size_t)(rows + 3) * OW * 128 + (size_t)w * (kGtMax * 8 + 4); }
+static int gather_t_cap(int rows)
+{
+    int cap = 1;
+    while (cap < rows) cap *= 2;
+    return cap;
+}
+// LDS of upconv_gather_t_kernel: the ring (cap rows x 32 channels), the three row-reduced rows V, the row / column tables
+static size_t gather_t_lds_bytes(int rows, int h, int w, int OW)
+{
+    return (size_t)(gather_t_cap(rows) + 3) * OW * 128 + (size_t)w * (kGtMax * 8 + 4) + 16 + (size_t)h * (kGtMax * 8 + 12);
+}
+// most dy rows a step adds (the next source row's window beyond this one's)
+static int gather_t_new_rows(int h, int OH, float hscale)
+{
+    int most = 0, have = -1;
+    for (int sy = 0; sy < h; ++sy) {
+        int hi = -1;
+        for (int q = 0; q < OH; ++q) {
+            const float sq = (float)q * hscale;
+            const int r0 = (int)floorf(sq), r1 = r0 + 1 < h - 1 ? r0 + 1 : h - 1;
+            if (r0 == sy || r1 == sy) hi = q;
+        }
+        if (hi >= 0) {
+            const int e = hi + 1 < OH - 1 ? hi + 1 : OH - 1;
+            if (have >= 0 && e - have > most) most = e - have;
+            if (e > have) have = e;
+        }
+    }
+    return most;
+}
 
 bool upconv_bwd_applies(int B, int h, int w, int C, int OH, int OW, int N, int align_corners)
 {
@@ -545,7 +662,9 @@ bool upconv_bwd_applies(int B, int h, int w, int C, int OH, int OW, int N, int a
     const bool scale_ok = (long long)OH <= 3LL * h && (long long)OW <= 3LL * w;
     const float hs = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
     return upconv_applies(B, h, w, C, OH, OW, N, align_corners) && scale_ok && OH <= 65535 && h <= 65535 &&
-           gather_t_lds_bytes(gather_t_rows(h, OH, hs), w, OW) <= 64 * 1024 && pointwise_applies(M, 9 * N, C) &&
+           gather_t_lds_bytes(gather_t_rows(h, OH, hs), h, w, OW) <= 80 * 1024 &&
+           gather_t_new_rows(h, OH, hs) * OW * 8 <= kGtPf * 256 && 3 * OW * 8 <= kGtItemsA * 256 && 72 * w <= kGtItemsB * 256 &&
+           pointwise_applies(M, 9 * N, C) &&
            M * 9 * N * 4 < 0xfffff000LL && M < (1LL << 24);
 }
 
@@ -582,10 +701,11 @@ int conv3x3_upsampled_bwd(const float *x, const float *dy, int B, int h, int w, 
     p.hscale = (align_corners && OH > 1) ? (float)(h - 1) / (float)(OH - 1) : (float)h / (float)OH;
     p.wscale = (align_corners && OW > 1) ? (float)(w - 1) / (float)(OW - 1) : (float)w / (float)OW;
     p.rows_max = gather_t_rows(h, OH, p.hscale);
-    const size_t lds = gather_t_lds_bytes(p.rows_max, w, OW);
+    p.cap = gather_t_cap(p.rows_max);
+    const size_t lds = gather_t_lds_bytes(p.rows_max, h, w, OW);
     MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(upconv_gather_t_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(upconv_gather_t_kernel, dim3((unsigned)(N / 32), (unsigned)h, (unsigned)B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(upconv_gather_t_kernel, dim3((unsigned)(N / 32), (unsigned)B), dim3(256), lds, s, p);
     MPSR_CHECK_LAUNCH("upconv_gather_t_kernel");
     // weight gradient of the tap GEMM, folded back into (N, 9 C)
     MPSR_CHECK_HIP(hipMemsetAsync(dwp, 0, (size_t)9 * N * C * sizeof(float), s));
