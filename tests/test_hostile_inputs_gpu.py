@@ -70,6 +70,9 @@ CASES = [
     ("winograd F(4x4,3x3)", 2, 8, 24, 24, 256, 256, 1),
     ("winograd F(4x4,3x3)", 2, 4, 48, 48, 128, 128, 1),
     ("winograd F(3x3,3x3) atrous", 3, 64, 12, 12, 256, 256, 4),
+    ("winograd F(3x3,3x3) tiles with halos (block2)", 3, 64, 12, 12, 128, 128, 2),
+    ("winograd F(3x3,3x3) tiles with halos (block1)", 3, 64, 12, 12, 64, 64, 1),
+    ("winograd F(3x3,3x3) tiles with halos (decoder, small batch)", 3, 8, 24, 24, 256, 256, 1),
     ("direct implicit GEMM", 0, 8, 24, 24, 256, 256, 1),
 ]
 
