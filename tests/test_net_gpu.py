@@ -457,7 +457,9 @@ def test_fc_few_rows_vs_fp64(M, K, N, has_bias, has_res, relu):
     (64, 2, 128, 128, True, True, 2), (3, 2, 32, 40, False, False, 2), (2, 2, 16, 65, True, True, 3),
     (5, 3, 48, 24, True, False, 2), (1, 2, 16, 8, False, True, 4),
     # ... and dense 3x3 layers (dilation 1): block1's conv2 is 12x12 = 4 x 4 tiles
-    (64, 1, 64, 64, True, True, 4), (3, 1, 32, 40, False, False, 2)])
+    (64, 1, 64, 64, True, True, 4), (3, 1, 32, 40, False, False, 2),
+    # ... up to the decoder's maps at small batches: 24x24 = 8 x 8 tiles, 48x48 = 16 x 16
+    (3, 1, 32, 40, True, True, 8), (2, 1, 64, 64, True, False, 16), (1, 2, 16, 24, True, True, 5)])
 def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     """The Winograd F(3x3,3x3) kernel for atrous 3x3 layers whose pixel sub-grids are 3x3 (csrc/winograd3.hip: H = W =
     3 * dilation; block3's conv2 is 12x12 at dilation 4) or th x th tiles of 3x3 with halos (H = W = 3 * dilation * th;
