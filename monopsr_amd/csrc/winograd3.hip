@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "wino3_filter.h"
+#include "wino3_transforms.h"
 
 namespace {
 
@@ -56,25 +57,8 @@ __global__ __launch_bounds__(256) void wino3_filter_kernel(const float *__restri
     if (i < (long long)N * C) mpsr::wino3_filter_one(w, N, C, u, i);
 }
 
-// scaled B^T applied to (0, x0, x1, x2, 0): 7 operations
-//   t0 = -x0 - 2 x1 + x2,  t1 = 2 x0 + x1 - x2,  t2 = -2 x0 + 3 x1 - x2,  t3 = -x0 + x2,  t4 = 2 x0 - x1 - 2 x2
-__device__ __forceinline__ void bt5(float x0, float x1, float x2, float &t0, float &t1, float &t2, float &t3, float &t4)
-{
-    const float e = x2 - x0, f = x0 - e, g = fmaf(-2.f, x0, -x2);
-    t0 = fmaf(-2.f, x1, e);
-    t1 = x1 + f;
-    t2 = fmaf(3.f, x1, g);
-    t3 = e;
-    t4 = fmaf(-2.f, e, -x1);
-}
-// A^T (3x5) applied to a 5-vector: 7 operations
-__device__ __forceinline__ void at3(float m0, float m1, float m2, float m3, float m4, float &y0, float &y1, float &y2)
-{
-    const float p = m1 + m2, q = m1 - m2;
-    y0 = m0 + p + m3;
-    y1 = fmaf(2.f, m3, q);
-    y2 = fmaf(4.f, m3, p) + m4;
-}
+using mpsr::w3t::bt5;
+using mpsr::w3t::at3;
 
 template <int V>
 using IC3 = std::integral_constant<int, V>;
@@ -442,6 +426,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 namespace mpsr {
 
+// winograd3w.hip: the same layer with one wave owning all 25 positions of its tile block
+bool winograd3w_applies(int B, int H, int W, int C, int N, int dilation);
+long long winograd3w_workgroups(int B, int N, int dilation);
+int launch_winograd3w(const float *x, int B, int H, int W, int C, const float *u, const float *bias, int relu, float *y,
+                      int N, int dilation, hipStream_t s, const float *mask);
+// mpsr_debug_set_wino3_form: -1 = by size, 0 = positions shared by eight waves (this file), 1 = one wave per tile block
+std::atomic<int> g_wino3_form{-1};
+
 thread_local FilterTailJob g_filter_tail_job;
 thread_local FilterTailJob g_filter_tail_done;
 thread_local FilterCacheSlot g_filter_cache_slot;
@@ -487,6 +479,13 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
         hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
         MPSR_CHECK_LAUNCH("wino3_filter_kernel");
     }
+    // one tile per sub-grid and enough of them to give every CU a workgroup of four 400-accumulator waves: the form without
+    // the epilogue exchange (winograd3w.hip); identical bits either way
+    if (th == 1 && winograd3w_applies(B, H, W, C, N, dilation)) {
+        const int form = g_wino3_form.load();
+        if (form == 1 || (form < 0 && winograd3w_workgroups(B, N, dilation) >= 192))
+            return launch_winograd3w(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
+    }
     Wino3Params p;
     p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
@@ -507,3 +506,5 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
 }
 
 }  // namespace mpsr
+
+extern "C" void mpsr_debug_set_wino3_form(int form) { mpsr::g_wino3_form = form; }

@@ -1,0 +1,62 @@
+"""Per-wave cycle stamps of the one-wave-per-tile-block F(3x3,3x3) kernel (needs a -DW3W_TRACE build of
+csrc/winograd3w.hip: tools/build_variant.sh w3wtrace winograd3w.hip -DW3W_TRACE; MPSR_LIB_PATH=abl/w3wtrace.so).
+
+    MPSR_LIB_PATH=abl/w3wtrace.so python tools/wino3w_trace.py [--batch 256]
+
+Prints, for the waves of the first workgroups: prologue, every K step, the wait states behind the loop, epilogue, in
+shader cycles, next to the matrix pipe's own time for a step (100 MFMAs x 64 cycles).
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monopsr_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    args = ap.parse_args()
+    lib = _lib.lib()
+    dev = torch.device("cuda")
+    B, C, N, dil = args.batch, 256, 256, 4
+    H = 3 * dil
+    x = torch.relu(torch.randn((B, H, H, C), device=dev))
+    w = torch.randn((N, 9 * C), device=dev) / (9 * C) ** 0.5
+    bias = torch.randn((N,), device=dev)
+    y = torch.empty((B, H, H, N), device=dev)
+    nws = lib.mpsr_conv2d_scratch_floats(B, H, H, N)
+    ws = torch.empty((nws,), device=dev)
+    lib.mpsr_debug_set_conv_winograd(3)
+    lib.mpsr_debug_set_wino3_form(1)
+    for _ in range(3):
+        _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, H, C, w.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
+                                            N, 3, 3, dil, 1, 0, ws.data_ptr(), nws, _lib.stream()))
+    torch.cuda.synchronize()
+    n = 8 * 4 * 40
+    buf = (ctypes.c_ulonglong * n)()
+    fn = lib.mpsr_debug_wino3w_trace
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert fn(buf, n) == 0
+    print("matrix pipe per K step: 6400 cycles; per wave and launch: %d" % (6400 * (C // 8)))
+    for blk in range(8):
+        for wv in range(4):
+            t = buf[(blk * 4 + wv) * 40:(blk * 4 + wv + 1) * 40]
+            if t[35] == 0:
+                continue
+            steps = [t[2 + s] - t[1 + s] for s in range(C // 8)]
+            print("wg %d wave %d: prologue %6d | K loop %7d (steps min %5d med %5d max %5d; first %5d last %5d) | "
+                  "drain %4d | epilogue %6d | total %7d" % (
+                      blk, wv, t[1] - t[0], t[1 + C // 8] - t[1], min(steps), sorted(steps)[len(steps) // 2], max(steps),
+                      steps[0], steps[-1], t[34] - t[1 + C // 8], t[35] - t[34], t[35] - t[0]))
+    lib.mpsr_debug_set_wino3_form(-1)
+    lib.mpsr_debug_set_conv_winograd(-1)
+
+
+if __name__ == "__main__":
+    main()
