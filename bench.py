@@ -447,7 +447,7 @@ def cfg5_step_object(step, inp, device, steps):
             "points": 2048, "emd": "mpsr_emd_loss (fused: no match tensor), device semantics"}
 
 
-def full_image_path_object(device, boxes=32, images=4, reps=3):
+def full_image_path_object(device, boxes=32, images=8, reps=3):
     """SURVEY 8(f) row 1 / the reference's own step shape (configs/monopsr_model_000.yaml:14-17): ONE 375 x 1242 image +
     32 proposal boxes in -> preprocess, proposal crops, crop trunk AND full-image trunk (on a second stream), feature
     crop + pool, squash / decoder / xyz, heads out (MonoPSRModel.build); and the crop-only step at the same batch of 32."""
@@ -483,6 +483,17 @@ def full_image_path_object(device, boxes=32, images=4, reps=3):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / (reps * n)
     ms = 1e3 * timed(lambda: [model.build(dict(sm)) for sm in samples], images)
+    # the same images in ONE pass (MonoPSRModel.build_batch: one full-image trunk call with batch N, box_ind-routed crops,
+    # one crop-trunk / decoder / heads call over all N x 32 boxes)
+    per_call = {"1": {"ms_per_image": round(ms, 3), "images_per_s": round(1e3 / ms, 1)}}
+    for n in (2, 4, 8):
+        if n > images:
+            break
+        try:
+            msn = 1e3 * timed(lambda: model.build_batch([dict(sm) for sm in samples[:n]]), n)
+            per_call[str(n)] = {"ms_per_image": round(msn, 3), "images_per_s": round(1e3 / msn, 1)}
+        except Exception as e:  # noqa: BLE001
+            per_call[str(n)] = {"error": repr(e)[:200]}
     inp32, _ = make_inputs(B, 1024, 0, device)
     st = Step(net, inp32, 1024)
     ms32 = 1e3 * timed(lambda: [st() for _ in range(images)], images)
@@ -490,6 +501,7 @@ def full_image_path_object(device, boxes=32, images=4, reps=3):
     return {"workload": "375x1242 image + %d boxes -> both trunks, feature crop, squash / decoder / xyz, heads" % B,
             "ms_per_image": round(ms, 3), "images_per_s": round(1e3 / ms, 1), "crops_per_s": round(B * 1e3 / ms, 1),
             "algorithmic_GFLOP_per_image": round(gflop, 1), "algorithmic_TFLOP_per_s": round(gflop / ms, 1),
+            "images_per_call": per_call,
             "crop_only_step_batch_%d" % B: {"ms_per_step": round(ms32, 3), "crops_per_s": round(B * 1e3 / ms32, 1),
                                              "what": "the cfg3 step (synthetic full-image feature crop + Chamfer) at the "
                                                      "reference's 32 boxes per image"}}

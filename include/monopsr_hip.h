@@ -169,7 +169,23 @@ int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float
                          const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                          int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream);
 
-/* Arithmetic of every contraction mpsr_conv2d_nhwc_f32 and the network entry points run (process-wide setting).
+/* Options of ONE call (ABI 5).  The reference's launchers carry no state (tf_nndistance.cpp:168); here the
+ * arithmetic mode and the Winograd policy have process-wide defaults (mpsr_set_conv_math / mpsr_set_winograd_policy
+ * below) and every entry point that takes options can override them for the duration of the call -- calls on different
+ * host threads with different options do not see each other (tests/test_threads_gpu.py).  A zero-initialised struct
+ * inherits the defaults. */
+enum { MPSR_CALL_MATH_INHERIT = 0, MPSR_CALL_MATH_FP32 = 1, MPSR_CALL_MATH_BF16X3 = 2 };
+enum { MPSR_CALL_WINOGRAD_INHERIT = 0, MPSR_CALL_WINOGRAD_AUTO = 1, MPSR_CALL_WINOGRAD_OFF = 2 };
+typedef struct mpsr_conv_opts {
+    int32_t math;            /* MPSR_CALL_MATH_* */
+    int32_t winograd_policy; /* MPSR_CALL_WINOGRAD_* */
+} mpsr_conv_opts;
+int mpsr_conv2d_nhwc_f32_ex(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
+                            const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
+                            int split_k, float *ws, size_t ws_floats, const mpsr_conv_opts *opts, mpsr_stream_t stream);
+
+/* Arithmetic of every contraction mpsr_conv2d_nhwc_f32 and the network entry points run (process-wide DEFAULT;
+ * per call: mpsr_conv_opts / mpsr_net_opts).
  *   MPSR_MATH_FP32   (default) exact fp32 products on v_mfma_f32_32x32x2_f32: what every parity and benchmark
  *                    number of this library refers to unless it says otherwise.
  *   MPSR_MATH_BF16X3 opt-in fast mode: operands split into hi + lo bfloat16 halves on the fly, each product evaluated
@@ -180,7 +196,8 @@ enum { MPSR_MATH_FP32 = 0, MPSR_MATH_BF16X3 = 1 };
 int mpsr_set_conv_math(int mode);
 int mpsr_get_conv_math(void);
 
-/* Whether 3x3 layers may run in a Winograd transform domain (process-wide setting, like the arithmetic above).
+/* Whether 3x3 layers may run in a Winograd transform domain (process-wide DEFAULT, like the arithmetic above; per call:
+ * mpsr_conv_opts / mpsr_net_opts).
  *   MPSR_WINOGRAD_AUTO (default) F(3x3,3x3) on block3's atrous layers, F(4x4,3x3) / F(2x2,3x3) on the dense decoder
  *                      layers wherever they are faster.  Error against float64 of the tensor's SCALE: 5e-6 / 1.5e-5 /
  *                      1e-6 (a direct fp32 convolution: 5e-7) -- far inside the path's 1e-3 budget.  The transforms mix
@@ -431,6 +448,10 @@ typedef struct mpsr_net_opts {
      * so a cache survives a change of arithmetic mode, Winograd policy or batch size without the caller tracking it.
      * NULL: filter_cache_valid alone decides. */
     int32_t *filter_cache_tags;
+    /* ABI 5: arithmetic mode / Winograd policy of this call (MPSR_CALL_MATH_*, MPSR_CALL_WINOGRAD_*; 0 = the process-wide
+     * defaults).  With filter_cache_tags the cache follows a change between calls by itself. */
+    int32_t math;
+    int32_t winograd_policy;
 } mpsr_net_opts;
 
 /* Floats of filter cache that serve every 3x3 layer of `layers` (36 cout cin per dense layer, 25 per atrous one). */
@@ -506,6 +527,14 @@ int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, const float *
                    const float *view_angs, const int *class_idx, const float *mean_lwh, const float *cen_z_offset,
                    const mpsr_head_consts *consts, const float *blob, const mpsr_layer *layers, int n_layers,
                    const mpsr_head_outputs *outs, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
+/* ABI 5: the boxes of several images in one call -- cam_p (n_cams,12), cam_index (B) int32 in [0, n_cams) picks each
+ * box's projection matrix (NULL: every box uses the first).  The reference feeds one image per step
+ * (monopsr_model.py:95-99, one pl_cam_p); N images x 32 boxes in one call read the 150 MB of FC weights once. */
+int mpsr_heads_fwd_cams(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d, const float *cam_p,
+                        int n_cams, const int *cam_index, const float *view_angs, const int *class_idx,
+                        const float *mean_lwh, const float *cen_z_offset, const mpsr_head_consts *consts,
+                        const float *blob, const mpsr_layer *layers, int n_layers, const mpsr_head_outputs *outs,
+                        void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
 
 #ifdef __cplusplus
 }

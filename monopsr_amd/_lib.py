@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPSR_LIB_PATH: development knob for A/B-ing two builds of the library inside one GPU session
 LIB_PATH = os.environ.get("MPSR_LIB_PATH") or os.path.join(_HERE, "libmonopsr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -52,7 +52,18 @@ class NetOpts(ctypes.Structure):
     """struct mpsr_net_opts"""
     _fields_ = [("filter_cache", ctypes.c_void_p), ("filter_cache_floats", ctypes.c_size_t),
                 ("filter_cache_valid", ctypes.c_int32), ("ready_event", ctypes.c_void_p),
-                ("filter_cache_tags", ctypes.POINTER(ctypes.c_int32))]
+                ("filter_cache_tags", ctypes.POINTER(ctypes.c_int32)), ("math", ctypes.c_int32),
+                ("winograd_policy", ctypes.c_int32)]
+
+
+class ConvOpts(ctypes.Structure):
+    """struct mpsr_conv_opts"""
+    _fields_ = [("math", ctypes.c_int32), ("winograd_policy", ctypes.c_int32)]
+
+
+# per-call option values (MPSR_CALL_MATH_*, MPSR_CALL_WINOGRAD_*): None / "inherit" = the process-wide default
+CALL_MATH = {None: 0, "inherit": 0, "fp32": 1, "bf16x3": 2}
+CALL_WINOGRAD = {None: 0, "inherit": 0, "auto": 1, "off": 2}
 
 
 # name -> (restype, argtypes); must list every symbol include/monopsr_hip.h declares (tests/test_cabi.py checks).
@@ -78,6 +89,8 @@ SIGNATURES = {
     "mpsr_max_pool": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_conv2d_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                    c_sz, c_f]),
+    "mpsr_conv2d_nhwc_f32_ex": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
+                                      c_sz, ctypes.POINTER(ConvOpts), c_f]),
     "mpsr_conv2d_scratch_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "mpsr_conv2d_plan": (c_i, [c_i] * 8 + [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
     "mpsr_im2col_root": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f]),
@@ -137,6 +150,8 @@ SIGNATURES = {
     "mpsr_heads_workspace_bytes": (c_sz, [c_i, c_i]),
     "mpsr_heads_fwd": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(HeadConsts), c_f,
                              ctypes.POINTER(Layer), c_i, ctypes.POINTER(HeadOutputs), c_f, c_sz, c_f]),
+    "mpsr_heads_fwd_cams": (c_i, [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(HeadConsts), c_f,
+                                  ctypes.POINTER(Layer), c_i, ctypes.POINTER(HeadOutputs), c_f, c_sz, c_f]),
 }
 
 

@@ -35,15 +35,36 @@ class FilterCache:
         self.tags = (ctypes.c_int32 * part.n)()
         self.filled = False
 
-    def opts(self, key=None, event=None):
+    def opts(self, key=None, event=None, math=None, winograd_policy=None):
+        """Options of one native call.  The caller reports the call's outcome with `mark_filled()` once it has returned
+        MPSR_OK: a failed first call must not leave a cache that later calls trust."""
         o = _lib.NetOpts()
         if self.buf is not None:
             o.filter_cache, o.filter_cache_floats = self.buf.data_ptr(), self.buf.numel()
             o.filter_cache_valid = 1 if self.filled else 0
             o.filter_cache_tags = self.tags
-            self.filled = True
         o.ready_event = event
+        o.math = _lib.CALL_MATH[math]
+        o.winograd_policy = _lib.CALL_WINOGRAD[winograd_policy]
         return o
+
+    def mark_filled(self):
+        """The native call that was handed this cache returned MPSR_OK: its launches (which fill the slices) are
+        queued on the calling stream.  Calls on OTHER streams must not read the slices before those launches have run:
+        the stream that filled the cache is remembered and later callers on another stream wait for its event."""
+        if self.buf is None or self.filled:
+            return
+        self.filled = True
+        self.fill_stream = torch.cuda.current_stream(self.buf.device)
+        self.fill_event = torch.cuda.Event()
+        self.fill_event.record(self.fill_stream)
+
+    def before_call(self):
+        """Orders a call on another stream than the one that filled the cache behind the fill."""
+        if self.filled and getattr(self, "fill_event", None) is not None:
+            cur = torch.cuda.current_stream(self.buf.device)
+            if cur != self.fill_stream:
+                cur.wait_event(self.fill_event)
 
 
 class Workspace:
@@ -81,6 +102,10 @@ class DeviceNet:
         self._fc_cache = {}
         self.fcache = {}          # FilterCache per weight blob, created on first use
         self.heads_stream = None  # second HIP stream of forward_instances (created on first use)
+        # arithmetic mode / Winograd policy of THIS net's calls (mpsr_net_opts, ABI 5): None = the process-wide default,
+        # "fp32" / "bf16x3", "auto" / "off".  Two nets with different settings can run concurrently on two threads.
+        self.math = None
+        self.winograd_policy = None
 
     def _filter_cache(self, which, part):
         """Weights of a DeviceNet never change after packing: the Winograd-transformed filters are computed once."""
@@ -145,9 +170,12 @@ class DeviceNet:
         lib = _lib.lib()
         nbytes = lib.mpsr_trunk_workspace_bytes(B, H, Wd)
         ws = (self.ws_trunk if which == "crop" else self.ws_trunk_full).get(nbytes)
-        opts = self._filter_cache(which, part).opts((B, H, Wd))
+        fc = self._filter_cache(which, part)
+        fc.before_call()
+        opts = fc.opts((B, H, Wd), math=self.math, winograd_policy=self.winograd_policy)
         _lib.check(lib.mpsr_trunk_fwd_ex(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
                                          _lib.ptr(out), _lib.ptr(ws), ws.numel(), ctypes.byref(opts), _lib.stream()))
+        fc.mark_filled()
         return out
 
     # ------------------------------------------------------------------ squash + decoder (+ xyz head)
@@ -173,12 +201,15 @@ class DeviceNet:
         lib = _lib.lib()
         nbytes = lib.mpsr_decoder_workspace_bytes(B, fh, fw, mh, mw)
         ws = self.ws_dec.get(nbytes)
-        opts = self._filter_cache("dec", self.decoder).opts((B, fh, fw, mh, mw, want_feat_map),
-                                       box3d_event.cuda_event if box3d_event is not None else None)
+        fc = self._filter_cache("dec", self.decoder)
+        fc.before_call()
+        opts = fc.opts((B, fh, fw, mh, mw, want_feat_map), box3d_event.cuda_event if box3d_event is not None else None,
+                       math=self.math, winograd_policy=self.winograd_policy)
         _lib.check(lib.mpsr_squash_decoder_fwd_ex(_lib.ptr(crop_feat), _lib.ptr(full_feat), B, fh, fw, mh, mw,
                                                   _lib.ptr(self.decoder.blob), self.decoder.layers, self.decoder.n,
                                                   _lib.ptr(feat_box), _lib.ptr(feat_map), _lib.ptr(xyz), _lib.ptr(ws),
                                                   ws.numel(), ctypes.byref(opts), _lib.stream()))
+        fc.mark_filled()
         return feat_box, feat_map, xyz
 
     # ------------------------------------------------------------------ the whole instance path
@@ -211,16 +242,59 @@ class DeviceNet:
             t.record_stream(main)
         return xyz, out
 
+    # ------------------------------------------------------------------ N images x their boxes in one pass
+    def forward_images(self, images, boxes_2d_norm, box_ind, boxes_2d, cam_p, view_angs, class_idx, mean_lwh,
+                       cen_z_offset, img_roi_size=(48, 48), map_roi_size=(48, 48), resized_full_img_shape=(160, 608),
+                       **head_kw):
+        """The reference's step (one preprocessed image + its boxes: monopsr_model.py:222-237, net_builder.py:44-60,
+        configs/monopsr_model_000.yaml:14-17) for N images at once: images (N,H,W,3) preprocessed, boxes of all images
+        concatenated -- boxes_2d_norm (B,4) normalised by each box's OWN original image size, box_ind (B) int32 = image
+        of the box, boxes_2d (B,4) pixels, cam_p (N,3,4), the per-box scalars (B).  One proposal crop_and_resize routed
+        by box_ind, ONE full-image trunk call with batch N (block3's 1x1 layers then have N x 6080 rows: at N = 1 they
+        fill half the chip), one crop-trunk call with batch B, one feature crop_and_resize routed by box_ind, one
+        squash / decoder / heads call.  -> (inst_xyz_map_local (B,48,48,3), head outputs); every box's outputs equal
+        the single-image call's (each operator is per box / per image)."""
+        if self.full_trunk is None:
+            raise _lib.MpsrError("DeviceNet was built without the full-image trunk")
+        box_ind = box_ind.to(dtype=torch.int32, device=self.device).contiguous()
+        half = (map_roi_size[0] // 2, map_roi_size[1] // 2)
+        main = torch.cuda.current_stream(self.device)
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        side = self.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # the two trunks are independent (net_builder.py:44-52): second stream
+            full_img = resize_bilinear(images, tuple(resized_full_img_shape), align_corners=True)
+            full_feat_map = self.trunk(full_img, "full")
+            large = crop_and_resize(full_feat_map, boxes_2d_norm, box_ind, half)
+            full_feat = max_pool(large, 2, 2, "VALID")
+        crops = crop_and_resize(images, boxes_2d_norm, box_ind, tuple(img_roi_size))
+        crop_feat = self.trunk(crops, "crop")
+        main.wait_stream(side)
+        full_feat.record_stream(main)
+        fb, _, xyz = self.squash_decoder(crop_feat, full_feat, tuple(map_roi_size), want_feat_map=False)
+        out = self.heads_fwd(fb, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset, cam_index=box_ind,
+                             **head_kw)
+        return xyz, out
+
     # ------------------------------------------------------------------ heads
     def heads_fwd(self, feat_box3d, boxes_2d, cam_p, view_angs, class_idx, mean_lwh, cen_z_offset,
                   image_shape=(320, 1216), max_depth=45.0, num_classes=1, num_alpha_bins=12,
-                  cen_y_norm=1.666754, cen_y_class_offset=0.0648):
+                  cen_y_norm=1.666754, cen_y_class_offset=0.0648, cam_index=None):
+        """cam_p (3,4) / (12,): one projection matrix for all boxes (the reference's step: one image); or (n_cams,3,4)
+        with cam_index (B) int32: the boxes of several images in one call (mpsr_heads_fwd_cams)."""
         B = feat_box3d.shape[0]
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         feat = feat_box3d.contiguous().reshape(B, -1)
         boxes_2d = boxes_2d.to(**f32).contiguous()
-        cam_p = cam_p.to(**f32).contiguous().reshape(12)
+        cam_p = cam_p.to(**f32).contiguous().reshape(-1, 12)
+        n_cams = cam_p.shape[0]
+        if cam_index is None:
+            if n_cams != 1:
+                raise _lib.InvalidArgumentError("heads_fwd: %d projection matrices need a cam_index" % n_cams)
+        else:
+            cam_index = cam_index.to(dtype=torch.int32, device=dev).contiguous().reshape(B)
         view = view_angs.to(**f32).contiguous().reshape(B)
         cls = class_idx.to(dtype=torch.int32, device=dev).contiguous().reshape(B)
         mean_lwh = mean_lwh.to(**f32).contiguous()
@@ -240,10 +314,11 @@ class DeviceNet:
         lib = _lib.lib()
         nbytes = lib.mpsr_heads_workspace_bytes(B, feat.shape[1])
         ws = self.ws_heads.get(nbytes)
-        _lib.check(lib.mpsr_heads_fwd(_lib.ptr(feat), B, feat.shape[1], _lib.ptr(boxes_2d), _lib.ptr(cam_p),
-                                      _lib.ptr(view), _lib.ptr(cls), _lib.ptr(mean_lwh), _lib.ptr(z_off),
-                                      ctypes.byref(consts), _lib.ptr(self.heads.blob), self.heads.layers, self.heads.n,
-                                      ctypes.byref(outs), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        _lib.check(lib.mpsr_heads_fwd_cams(_lib.ptr(feat), B, feat.shape[1], _lib.ptr(boxes_2d), _lib.ptr(cam_p), n_cams,
+                                           _lib.ptr(cam_index), _lib.ptr(view), _lib.ptr(cls), _lib.ptr(mean_lwh),
+                                           _lib.ptr(z_off), ctypes.byref(consts), _lib.ptr(self.heads.blob),
+                                           self.heads.layers, self.heads.n, ctypes.byref(outs), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream()))
         out["view_ang"] = view.reshape(B, 1)
         return out
 

@@ -74,6 +74,45 @@ class MonoPSRModel:
                                                      self.is_training)
         return self.build_outputs(features_dict, sample), features_dict
 
+    def build_batch(self, samples):
+        """N images with their boxes in ONE pass (inference, fused heads): `samples` = a list of the dicts `build` takes
+        (`rgb_image` (H_i,W_i,3), `boxes_2d_norm`, `boxes_2d`, `cam_p`, `est_view_angs`, `class_indices`, `mean_lwh`,
+        `prop_cen_z_offset`; box counts and image sizes may differ per image).  The reference's step is one image
+        (monopsr_model.py:222-237, configs/monopsr_model_000.yaml:14-17); here every image is preprocessed as there,
+        then all of them go through DeviceNet.forward_images: one full-image trunk call with batch N, one crop-trunk /
+        decoder / heads call with all boxes.  Returns a list of per-image output dicts (views into the batch
+        tensors), each equal to what `build(sample)` returns for that image."""
+        if not self.fused_heads or self.train_val_test != 'test':
+            raise ValueError("build_batch is the inference path (train_val_test='test', fused_heads=True)")
+        if len(samples) == 0:
+            return []
+        dev = samples[0]['boxes_2d'].device
+        pre = [self.img_preprocessor.preprocess_input(s['rgb_image'].unsqueeze(0), self.image_input_shape,
+                                                      mean_sub_type=self.mean_sub_type) for s in samples]
+        images = torch.cat(pre, 0)
+        counts = [int(s['boxes_2d'].shape[0]) for s in samples]
+        box_ind = torch.cat([torch.full((c,), i, dtype=torch.int32, device=dev) for i, c in enumerate(counts)])
+        cat = lambda k: torch.cat([s[k].reshape(s['boxes_2d'].shape[0], -1) for s in samples], 0)
+        cam_p = torch.stack([s['cam_p'].reshape(3, 4) for s in samples], 0)
+        xyz, out = self.device_net.forward_images(
+            images, cat('boxes_2d_norm'), box_ind, cat('boxes_2d'), cam_p, cat('est_view_angs').reshape(-1),
+            cat('class_indices'), cat('mean_lwh'), cat('prop_cen_z_offset').reshape(-1),
+            img_roi_size=tuple(self.img_roi_size), map_roi_size=tuple(self.map_roi_size),
+            resized_full_img_shape=tuple(self.resized_full_img_shape),
+            image_shape=self.image_input_shape, max_depth=self.depth_range[1],
+            num_classes=len(self.dataset_config.classes), num_alpha_bins=self.dataset_config.num_alpha_bins,
+            cen_y_class_offset=monopsr_output_builder.CEN_Y_CLASS_OFFSET[(self.classes_name, 'kitti')])
+        out[constants.KEY_INST_XYZ_MAP_LOCAL] = xyz
+        results, lo = [], 0
+        for s, c in zip(samples, counts):
+            o = {k: v[lo:lo + c] for k, v in out.items()}
+            o[constants.SAMPLE_LABEL_CLASS_INDICES] = s['class_indices']
+            if s.get('gt_valid_mask_maps') is not None:
+                o[constants.KEY_VALID_MASK_MAPS] = s['gt_valid_mask_maps']
+            results.append(o)
+            lo += c
+        return results
+
     def build_outputs(self, features_dict, sample):
         boxes_2d = sample['boxes_2d']
         cam_p = sample['cam_p'].reshape(3, 4)

@@ -42,6 +42,25 @@ inline hipStream_t as_stream(mpsr_stream_t s) { return reinterpret_cast<hipStrea
         if (!(cond)) return ::mpsr::fail(MPSR_ERR_INVALID_ARG, __VA_ARGS__);       \
     } while (0)
 
+// Per-call overrides of the process-wide arithmetic mode / Winograd policy (mpsr_net_opts.math / .winograd_policy,
+// mpsr_conv2d_nhwc_f32_ex): an entry point runs on its caller's thread from start to end, so a thread-local set for
+// the duration of the call IS per call, and two threads with different options never see each other's.  -1 = none.
+extern thread_local int t_call_math;
+extern thread_local int t_call_wino_policy;
+struct CallOptsGuard {  // sets the overrides for one entry-point call (0 = inherit, otherwise enum value + 1)
+    int prev_math, prev_wino;
+    CallOptsGuard(int math_opt, int wino_opt) : prev_math(t_call_math), prev_wino(t_call_wino_policy)
+    {
+        if (math_opt > 0) t_call_math = math_opt - 1;
+        if (wino_opt > 0) t_call_wino_policy = wino_opt - 1;
+    }
+    ~CallOptsGuard()
+    {
+        t_call_math = prev_math;
+        t_call_wino_policy = prev_wino;
+    }
+};
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -1020,7 +1020,9 @@ std::atomic<int> g_sk_per_cu{0};
 std::atomic<int> g_wino_policy{0};      // mpsr_set_winograd_policy: MPSR_WINOGRAD_AUTO / MPSR_WINOGRAD_OFF
 std::atomic<int> g_wino_override{-1};   // Winograd for eligible 3x3 layers: -1 heuristic, 0 never, 1 F(2x2,3x3) / 2 F(4x4,3x3) / 3 F(3x3,3x3) on atrous sub-grids whenever possible
 std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-workgroup kernel: -1 heuristic, 1, 2
-std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math
+std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math (the default of calls that do not say otherwise)
+inline int cur_math() { return mpsr::t_call_math >= 0 ? mpsr::t_call_math : g_math.load(); }
+inline int cur_wino_policy() { return mpsr::t_call_wino_policy >= 0 ? mpsr::t_call_wino_policy : g_wino_policy.load(); }
 std::atomic<int> g_wino3_halo{1};    // mpsr_debug_set_wino3_halo: the tiled F(3x3,3x3) form (block2's atrous layers) in the automatic rule
 
 // Scratch a stream-K launch needs behind `ws`: two partial-tile slabs per workgroup, then one counter per tile.
@@ -1129,7 +1131,7 @@ int fc_rows(const float *x, long long M, int K, const float *w, const float *bia
 bool conv2d_takes_fc_rows(int H, int W, long long M, int C, int N, int KH, int KW, int split_k)
 {
     const int pw = pointwise_override();
-    return H == 1 && W == 1 && KH == 1 && KW == 1 && split_k <= 1 && pw != 0 && g_math.load() == MATH_FP32 &&
+    return H == 1 && W == 1 && KH == 1 && KW == 1 && split_k <= 1 && pw != 0 && cur_math() == MATH_FP32 &&
            g_tile_override.load() < 0 && g_sched_override.load() < 0 && fc_rows_applies(M, C, N);
 }
 
@@ -1139,7 +1141,7 @@ bool conv2d_takes_fc_rows(int H, int W, long long M, int C, int N, int KH, int K
 bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k)
 {
     const int pw = pointwise_override();
-    if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || g_math.load() != MATH_FP32 || g_tile_override.load() >= 0 ||
+    if (KH != 1 || KW != 1 || split_k > 1 || pw == 0 || cur_math() != MATH_FP32 || g_tile_override.load() >= 0 ||
         !pointwise_applies(M, C, N))
         return false;
     if (pw > 0) return true;
@@ -1183,7 +1185,7 @@ int auto_split_k(int M, int N, int ksteps, const float *ws, size_t ws_floats)
 static int winograd_mode()
 {
     const int wino = g_wino_override.load();
-    return (wino < 0 && g_wino_policy.load() == MPSR_WINOGRAD_OFF) ? 0 : wino;
+    return (wino < 0 && cur_wino_policy() == MPSR_WINOGRAD_OFF) ? 0 : wino;
 }
 
 // True when conv2d() with split_k = 0 would send this 3x3 layer to the F(4x4,3x3) kernel (network.hip asks before it
@@ -1203,7 +1205,7 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
 {
     const int wino = winograd_mode();
     const long long M64 = (long long)B * H * W;
-    const bool can3 = KH == 3 && KW == 3 && split_k == 0 && ws && g_math.load() == MATH_FP32 &&
+    const bool can3 = KH == 3 && KW == 3 && split_k == 0 && ws && cur_math() == MATH_FP32 &&
                       winograd3_applies(H, W, C, dilation) && ws_floats >= winograd3_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
     // (tiles of 3x3 outputs: th x th per pixel sub-grid; the automatic rule takes the forms that were measured -- one
@@ -1230,7 +1232,7 @@ int conv2d_winograd_choice(int B, int H, int W, int C, int N, int KH, int KW, in
     // (the F(4x4) kernel also serves the opt-in bf16x3 mode: in exact fp32 it is faster on these layers than the
     // split-bfloat16 implicit GEMM -- 3.1 vs 3.6 ms for the four of them -- and adds no drift)
     const bool base = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws;
-    const bool can2 = base && g_math.load() == MATH_FP32 && winograd_applies(H, W, C, N) &&
+    const bool can2 = base && cur_math() == MATH_FP32 && winograd_applies(H, W, C, N) &&
                       ws_floats >= winograd_scratch_floats(C, N);
     const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
@@ -1291,7 +1293,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     // border-class tiling: atrous 3x3 layers only (a 1-pixel border ring at dilation 1 saves too little)
     bool use_classes = KH == 3 && KW == 3 && dilation > 1;
     const int class_override = g_class_override.load(), tile_override = g_tile_override.load();
-    const int math = g_math.load();
+    const int math = cur_math();
     if (class_override == 0) use_classes = false;
     if (class_override == 1) use_classes = KH == 3 && KW == 3;
     int sel = tile_override;
@@ -1477,6 +1479,23 @@ extern "C" int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, 
                                     const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
                                     int split_k, float *ws, size_t ws_floats, mpsr_stream_t stream)
 {
+    return mpsr::conv2d(x, B, H, W, C, w, bias, residual, y, N, KH, KW, dilation, relu, split_k, ws, ws_floats,
+                        mpsr::as_stream(stream));
+}
+
+// The same under per-call options: the arithmetic mode and the Winograd policy of THIS call, whatever the process-wide
+// defaults say (the reference's launchers are stateless, tf_nndistance.cpp:168; SURVEY 8(b) "no state").
+extern "C" int mpsr_conv2d_nhwc_f32_ex(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
+                                       const float *residual, float *y, int N, int KH, int KW, int dilation, int relu,
+                                       int split_k, float *ws, size_t ws_floats, const mpsr_conv_opts *opts,
+                                       mpsr_stream_t stream)
+{
+    if (opts) {
+        MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "conv2d: unknown opts.math %d", opts->math);
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+                     "conv2d: unknown opts.winograd_policy %d", opts->winograd_policy);
+    }
+    mpsr::CallOptsGuard guard(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);
     return mpsr::conv2d(x, B, H, W, C, w, bias, residual, y, N, KH, KW, dilation, relu, split_k, ws, ws_floats,
                         mpsr::as_stream(stream));
 }

@@ -172,6 +172,12 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
                                  const mpsr_net_opts *opts, mpsr_stream_t stream)
 {
     MPSR_REQUIRE(B >= 0 && H >= 7 && W >= 7, "trunk_fwd: bad input shape (B=%d H=%d W=%d)", B, H, W);
+    if (opts) {
+        MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "%s: unknown opts.math %d", "trunk_fwd", opts->math);
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+                     "%s: unknown opts.winograd_policy %d", "trunk_fwd", opts->winograd_policy);
+    }
+    mpsr::CallOptsGuard call_opts(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);
     MPSR_REQUIRE(n_layers == MPSR_TRUNK_LAYERS, "trunk_fwd: expected %d layer records, got %d", MPSR_TRUNK_LAYERS,
                  n_layers);
     if (B == 0) return MPSR_OK;
@@ -358,6 +364,12 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
 {
     MPSR_REQUIRE(B >= 0 && fh >= 2 && fw >= 2 && mh >= 2 && mw >= 2 && mh % 2 == 0 && mw % 2 == 0,
                  "squash_decoder_fwd: bad shape");
+    if (opts) {
+        MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "%s: unknown opts.math %d", "squash_decoder_fwd", opts->math);
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+                     "%s: unknown opts.winograd_policy %d", "squash_decoder_fwd", opts->winograd_policy);
+    }
+    mpsr::CallOptsGuard call_opts(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);
     MPSR_REQUIRE(n_layers == MPSR_DECODER_LAYERS, "squash_decoder_fwd: expected %d layer records, got %d",
                  MPSR_DECODER_LAYERS, n_layers);
     if (B == 0) return MPSR_OK;
@@ -490,8 +502,10 @@ namespace {
 struct HeadIn {
     const float *boxes, *cam_p, *view, *mean_lwh, *z_off;
     const int *cls;
+    const int *cam_idx;  // per box: which of the cam_p matrices (boxes of several images in one call), or nullptr: the first
     mpsr_head_consts k;
 };
+__device__ __forceinline__ const float *cam_of(const HeadIn &in, int b) { return in.cam_p + (in.cam_idx ? 12 * in.cam_idx[b] : 0); }
 
 // scalar features shared by both concat rows (monopsr_output_builder.py:147-158,228-240):
 // index 0..3 box coords in film coordinates / half image size, 4 box height / image height, 5 view angle,
@@ -499,7 +513,8 @@ struct HeadIn {
 __device__ __forceinline__ float common_feature(const HeadIn &in, int b, int j)
 {
     const float *bx = in.boxes + 4 * b;
-    const float cu = in.cam_p[2], cv = in.cam_p[6];
+    const float *cam = cam_of(in, b);
+    const float cu = cam[2], cv = cam[6];
     if (j < 4) {
         const float centre = (j & 1) ? cu : cv;
         const float half = ((j & 1) ? in.k.image_w : in.k.image_h) / 2.0f;
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(256) void head_concat_prop_kernel(HeadIn in, const 
     float v = 0.f;
     if (col < nfc) v = imgfc[(size_t)b * imgfc_stride + col];
     else if (col < nfc + ncommon) v = common_feature(in, b, col - nfc);
-    else if (col < nfc + ncommon + 12) v = in.cam_p[col - nfc - ncommon] / kCamNorm[col - nfc - ncommon];
+    else if (col < nfc + ncommon + 12) v = cam_of(in, b)[col - nfc - ncommon] / kCamNorm[col - nfc - ncommon];
     out[i] = v;
 }
 
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(256) void head_prop_outputs_kernel(HeadIn in, const
         if (o.alpha_regs) o.alpha_regs[(size_t)b * nb + j] = p[3 + nb + j];
     }
     const float *bx = in.boxes + 4 * b;
-    const float focal = in.cam_p[0], cv = in.cam_p[6];
+    const float focal = cam_of(in, b)[0], cv = cam_of(in, b)[6];
     const float z = focal * lwh[2] / (bx[2] - bx[0]) + in.z_off[b];
     const float centre_v = (bx[2] + bx[0]) / 2.0f - cv;
     const float y = centre_v * (z / focal) - in.k.cen_y_class_offset;
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadIn in, const float 
     if (b >= B) return;
     const float yo = rout[2 * b], zo = rout[2 * b + 1];
     const float y = prop[2 * b] + yo, z = prop[2 * b + 1] + zo;
-    const float x = z * tanf(in.view[b]) + (-in.cam_p[3] / in.cam_p[0]);
+    const float x = z * tanf(in.view[b]) + (-cam_of(in, b)[3] / cam_of(in, b)[0]);
     if (o.cen_y) o.cen_y[b] = y;
     if (o.cen_y_offs) o.cen_y_offs[b] = yo;
     if (o.cen_z) o.cen_z[b] = z;
@@ -615,6 +630,21 @@ extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, co
                               const mpsr_layer *L, int n_layers, const mpsr_head_outputs *outs, void *workspace,
                               size_t workspace_bytes, mpsr_stream_t stream)
 {
+    return mpsr_heads_fwd_cams(feat_box3d, B, feat_elems, boxes_2d, cam_p, 1, nullptr, view_angs, class_idx, mean_lwh,
+                               cen_z_offset, consts, blob, L, n_layers, outs, workspace, workspace_bytes, stream);
+}
+
+// The boxes of SEVERAL images in one call: cam_p (n_cams,12), cam_index (B) in [0, n_cams) selects each box's projection
+// matrix (nullptr: all boxes use the first).  The reference's step is one image (monopsr_model.py:95, one pl_cam_p); a
+// batch of images is N such steps whose FC weights (150 MB) are then read once instead of N times.
+extern "C" int mpsr_heads_fwd_cams(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d,
+                                   const float *cam_p, int n_cams, const int *cam_index, const float *view_angs,
+                                   const int *class_idx, const float *mean_lwh, const float *cen_z_offset,
+                                   const mpsr_head_consts *consts, const float *blob, const mpsr_layer *L, int n_layers,
+                                   const mpsr_head_outputs *outs, void *workspace, size_t workspace_bytes,
+                                   mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(n_cams >= 1, "heads_fwd: n_cams = %d", n_cams);
     MPSR_REQUIRE(B >= 0 && feat_elems > 0 && feat_elems % 4 == 0, "heads_fwd: bad shape (B=%d feat=%d)", B, feat_elems);
     MPSR_REQUIRE(n_layers == MPSR_HEAD_LAYERS, "heads_fwd: expected %d layer records, got %d", MPSR_HEAD_LAYERS,
                  n_layers);
@@ -644,7 +674,7 @@ extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, co
 
     HeadIn in;
     in.boxes = boxes_2d; in.cam_p = cam_p; in.view = view_angs; in.mean_lwh = mean_lwh; in.z_off = cen_z_offset;
-    in.cls = class_idx; in.k = *consts;
+    in.cls = class_idx; in.cam_idx = cam_index; in.k = *consts;
     int rc;
     // both img_fc layers share the flattened features: one GEMM, N = 2 x 1024, split along K = 18432
     if ((rc = run_layer(blob, L[0], feat_box3d, B, 1, 1, nullptr, imgfc, 0, skws, skn, s))) return rc;

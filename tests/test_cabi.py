@@ -50,7 +50,9 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.Layer) == 6 * 4 + 2 * 8
     assert ctypes.sizeof(_lib.HeadConsts) == 5 * 4 + 2 * 4
     assert ctypes.sizeof(_lib.HeadOutputs) == 11 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.NetOpts) == 8 + 8 + 8 + 8 + 8  # (int32 + padding before the event handle; tags pointer)
+    # (int32 + padding before the event handle; tags pointer; ABI 5: two int32 options)
+    assert ctypes.sizeof(_lib.NetOpts) == 8 + 8 + 8 + 8 + 8 + 4 + 4
+    assert ctypes.sizeof(_lib.ConvOpts) == 8
 
 
 def test_host_side_argument_checks_need_no_gpu():

@@ -493,6 +493,56 @@ def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     assert not torch.equal(got, direct) or C * N < 1024
 
 
+@pytest.mark.parametrize("B,dil,C,N,has_bias,relu,masked", [
+    (8, 4, 64, 64, True, True, False), (3, 4, 32, 40, False, False, False), (1, 4, 16, 4, True, False, False),
+    (5, 2, 48, 200, True, True, False), (64, 4, 256, 256, True, True, False), (7, 3, 16, 65, True, True, False),
+    (33, 4, 128, 128, True, True, False), (2, 1, 32, 129, True, False, False), (9, 4, 16, 300, False, True, False),
+    # data-gradient launches of the training path: the ReLU mask of the layer applied in the store path
+    (8, 4, 64, 64, False, False, True), (3, 4, 32, 40, False, False, True), (64, 4, 256, 256, False, False, True),
+    (7, 3, 16, 65, False, False, True)])
+def test_conv2d_winograd3_wave_owned_form_is_bit_identical(B, dil, C, N, has_bias, relu, masked):
+    """csrc/winograd3w.hip (one wave owns all 25 positions of its 32-tile x 32-channel block: 400 accumulators, the
+    output transform lane-local) against csrc/winograd3.hip (positions shared by eight waves, exchange through LDS): same
+    transformed operands, same accumulation order per output, same output transform -- identical bits, on ragged tile
+    and channel counts (partial 32-tile blocks, partial 128-channel workgroups), every dilation, with and without
+    bias / ReLU / the training path's mask; and <= 1e-5 of the tensor scale against float64."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    H = 3 * dil
+    rng = np.random.default_rng(B * 1000 + C + N + dil)
+    x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    act = np.maximum(rng.standard_normal((B, H, H, N)), 0).astype(np.float32)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    outs = []
+    lib.mpsr_debug_set_conv_winograd(3)
+    try:
+        for form in (0, 1):
+            lib.mpsr_debug_set_wino3_form(form)
+            if masked:
+                ws = torch.empty((lib.mpsr_conv2d_scratch_floats(B, H, H, N),), dtype=torch.float32, device="cuda")
+                got = torch.full((B, H, H, N), 7.0, dtype=torch.float32, device="cuda")
+                xd, wd, ad = _dev(x), _dev(w_ok), _dev(act)
+                _lib.check(lib.mpsr_conv2d_relu_masked_f32(_lib.ptr(xd), B, H, H, C, _lib.ptr(wd), _lib.ptr(ad),
+                                                           _lib.ptr(got), N, 3, 3, dil, _lib.ptr(ws), ws.numel(),
+                                                           _lib.stream()))
+            else:
+                got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+            outs.append(got)
+    finally:
+        lib.mpsr_debug_set_wino3_form(-1)
+        lib.mpsr_debug_set_conv_winograd(-1)
+    assert torch.equal(outs[0], outs[1]), "the two F(3x3,3x3) forms differ"
+    ref = _conv_ref(x, w, bias, None, dil, relu)
+    if masked:
+        ref = torch.where(torch.from_numpy(act) > 0, ref, torch.zeros_like(ref))
+        assert 0.3 < float((outs[1] != 0).float().mean()) < 0.7
+    _close(outs[1], ref, 1e-5, "winograd F(3x3) wave-owned %s" % ((B, dil, C, N),))
+
+
 def test_border_class_tiling_is_bit_identical():
     """Skipping the all-zero taps of an atrous layer must not change a single bit (same products, same order)."""
     from monopsr_amd import _lib
@@ -772,6 +822,87 @@ def test_model_build_full_image_path_vs_oracle():
     out, _ = model.build(sample)
     for key in ("inst_xyz_map_local", "lwh", "alpha_bins", "centroids"):
         _close(out[key], ref[key], 1e-4, key)
+
+
+def test_model_build_batch_of_images_equals_single_image_calls_and_oracle(golden_dir):
+    """MonoPSRModel.build_batch / DeviceNet.forward_images: the reference's step (one image + its boxes,
+    monopsr_model.py:222-237, net_builder.py:44-60, configs/monopsr_model_000.yaml:14-17) for N = 8 images in one pass --
+    one full-image trunk call with batch 8, box_ind-routed proposal and feature crops, one crop-trunk / decoder / heads
+    call over all boxes, a projection matrix per image.  Frames: the real KITTI frame of the cfg1 fixture (with its own
+    label boxes), variants of it at other sizes, and synthetic frames; box counts differ per image.  Every image's
+    outputs must equal its single-image `build` (<= 2e-5 of the tensor scale) and the CPU restatement (<= 1e-4)."""
+    import os
+    from monopsr_amd.core import config_utils
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    from monopsr_amd.core.models.monopsr.monopsr_model import MonoPSRModel
+    fx = np.load(os.path.join(golden_dir, "kitti_cfg1.npz"))
+    frame = fx["full_frame"].astype(np.float32)
+    rows = np.nonzero(fx["frame_index"] == int(fx["full_frame_index"]))[0]
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=31, width_div=2, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
+    net = dn.DeviceNet(weights, width_div=2, full_trunk=True)
+    model = MonoPSRModel(cfg.model_config, cfg.dataset_config, net, 'test')
+    rng = np.random.default_rng(77)
+    frames = [frame, frame[3:, 8:].copy(), frame[:, ::-1].copy(), frame[:-5, :-18].copy()]
+    frames += [rng.integers(0, 256, (375, 1242, 3)).astype(np.float32) for _ in range(4)]
+    counts = [len(rows), 5, 2, 7, 3, 1, 6, 4]
+    samples, host = [], []
+    for i, (img, nb) in enumerate(zip(frames, counts)):
+        H, Wd = img.shape[:2]
+        sample, (_, boxes, cam_p, view, cls, mean_lwh, z_off) = _sample(nb, 100 + i)
+        if i == 0:
+            boxes = fx["boxes_2d"][rows].astype(np.float32)
+            cam_p = fx["cam_p"][rows[0]].astype(np.float32)
+        else:
+            cam_p = (cam_p + rng.uniform(-2, 2, cam_p.shape) * (np.abs(cam_p) > 1)).astype(np.float32)
+        boxes[:, 2] = np.minimum(boxes[:, 2], H - 1)
+        boxes[:, 3] = np.minimum(boxes[:, 3], Wd - 1)
+        norm = (boxes / np.array([H, Wd, H, Wd], np.float32)).astype(np.float32)  # kitti_dataset.py:450
+        sample.update(boxes_2d=_dev(boxes), boxes_2d_norm=_dev(norm), rgb_image=_dev(img), cam_p=_dev(cam_p))
+        samples.append(sample)
+        host.append((img, boxes, norm, cam_p, view, cls, mean_lwh, z_off))
+    batch = model.build_batch([dict(s) for s in samples])
+    assert len(batch) == len(samples)
+    keys = ("inst_xyz_map_local", "lwh", "lwh_offs", "alpha_bins", "alpha_regs", "prop_cen_z", "cen_y", "cen_z", "cen_x",
+            "centroids", "view_ang")
+    for i, s in enumerate(samples):
+        single, _ = model.build(dict(s))
+        for key in keys:
+            assert batch[i][key].shape == single[key].shape, (i, key)
+            _close(batch[i][key], single[key], 2e-5, "image %d %s (batch vs single)" % (i, key))
+    for i in (0, 3):  # the real frame and a resized-input variant against the oracle
+        ref = onet.full_image_path(*host[i], weights)
+        for key in ("inst_xyz_map_local", "lwh", "alpha_bins", "centroids"):
+            _close(batch[i][key], ref[key], 1e-4, "image %d %s (vs oracle)" % (i, key))
+    assert model.build_batch([]) == []
+
+
+def test_heads_with_a_projection_matrix_per_box_equal_per_image_calls():
+    """mpsr_heads_fwd_cams: cam_index routes every box to its image's projection matrix; the concatenated call gives each
+    box the bits of its own single-matrix call (same FC kernels row by row when the batch sizes pick the same kernel;
+    here both are the few-row FC path)."""
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    weights = W.synthetic_weights(seed=5, width_div=4)
+    net = dn.DeviceNet(weights, width_div=4)
+    rng = np.random.default_rng(6)
+    nimg, per = 3, 4
+    B = nimg * per
+    feat = _dev(np.maximum(rng.standard_normal((B, 6, 6, 128)), 0).astype(np.float32))
+    _, boxes, cam_p, view, cls, mean_lwh, z_off = _inputs(B, 7)
+    cams = np.stack([cam_p * (1 + 0.01 * k) for k in range(nimg)]).astype(np.float32)
+    idx = np.repeat(np.arange(nimg), per).astype(np.int32)
+    got = net.heads_fwd(feat, _dev(boxes), _dev(cams), _dev(view), _dev(cls), _dev(mean_lwh), _dev(z_off),
+                        cam_index=_dev(idx))
+    for k in range(nimg):
+        sl = slice(k * per, (k + 1) * per)
+        one = net.heads_fwd(feat[sl], _dev(boxes[sl]), _dev(cams[k]), _dev(view[sl]), _dev(cls[sl]), _dev(mean_lwh[sl]),
+                            _dev(z_off[sl]))
+        for key in ("centroids", "lwh", "alpha_bins", "alpha_regs", "cen_x", "prop_cen_z"):
+            _close(got[key][sl], one[key], 1e-5, "%s image %d" % (key, k))
+    with pytest.raises(ValueError):
+        net.heads_fwd(feat, _dev(boxes), _dev(cams), _dev(view), _dev(cls), _dev(mean_lwh), _dev(z_off))
 
 
 def test_evaluate_predictions_metrics():

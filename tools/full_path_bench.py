@@ -67,10 +67,23 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / (args.reps * args.images)
+    batched = {}
+    for n in (1, 2, 4, 8, 16):
+        if n > args.images:
+            break
+        model.build_batch([dict(s) for s in samples[:n]])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.reps):
+            model.build_batch([dict(s) for s in samples[:n]])
+        e1.record()
+        torch.cuda.synchronize()
+        batched[str(n)] = round(e0.elapsed_time(e1) / (args.reps * n), 3)
     gflop = 2 * 167.1 + B * 12.393  # full-image trunk + per-crop path
     out = {"workload": "full path: 375x1242 image + %d boxes" % B, "ms_per_image": round(ms, 3),
            "images_per_s": round(1e3 / ms, 1), "crops_per_s": round(B * 1e3 / ms, 1),
-           "algorithmic_GFLOP_per_image": round(gflop, 1), "TFLOP_per_s": round(gflop / ms, 1)}
+           "algorithmic_GFLOP_per_image": round(gflop, 1), "TFLOP_per_s": round(gflop / ms, 1),
+           "build_batch_ms_per_image_by_images_per_call": batched}
     if args.graph:
         # the ~250 short launches of one image as ONE graph launch: inputs stay in place (static buffers), the outputs
         # of the captured pass are rewritten by every replay
