@@ -1023,6 +1023,8 @@ std::atomic<int> g_depth_override{-1};  // staging depth of the one-tile-per-wor
 std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math (the default of calls that do not say otherwise)
 inline int cur_math() { return mpsr::t_call_math >= 0 ? mpsr::t_call_math : g_math.load(); }
 inline int cur_wino_policy() { return mpsr::t_call_wino_policy >= 0 ? mpsr::t_call_wino_policy : g_wino_policy.load(); }
+std::atomic<int> g_atrous_wino2{1};  // mpsr_debug_set_atrous_wino2: F(2x2,3x3) on the sub-grids of atrous layers in the automatic rule
+std::atomic<int> g_atrous_wino2_min_pixels{12000};  // (one 40 x 152 map = 6080 pixels: equal or slower there -- too few workgroups; 288 vs 459 us at eight)
 std::atomic<int> g_wino3_halo{1};    // mpsr_debug_set_wino3_halo: the tiled F(3x3,3x3) form (block2's atrous layers) in the automatic rule
 
 // Scratch a stream-K launch needs behind `ws`: two partial-tile slabs per workgroup, then one counter per tile.
@@ -1097,8 +1099,9 @@ int conv3x3_narrow(const float *x, int B, int H, int W, int C, const float *w, c
 // winograd.hip
 size_t winograd_scratch_floats(int C, int N);
 bool winograd_applies(int H, int W, int C, int N);
+bool winograd_applies_dilated(int H, int W, int C, int N, int dilation);
 int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
-                     int N, float *ws, size_t ws_floats, hipStream_t s);
+                     int N, float *ws, size_t ws_floats, hipStream_t s, int dilation);
 // winograd4.hip
 size_t winograd4_scratch_floats(int C, int N);
 bool winograd4_applies(int H, int W, int C, int N);
@@ -1110,6 +1113,7 @@ extern std::atomic<int> g_wino4_split;
 // winograd3.hip
 size_t winograd3_scratch_floats(int C, int N);
 bool winograd3_applies(int H, int W, int C, int dilation);
+double winograd3_executed_flops(int B, int H, int C, int N, int dilation);
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
                       float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s,
                       const float *mask = nullptr);
@@ -1232,13 +1236,21 @@ int conv2d_winograd_choice(int B, int H, int W, int C, int N, int KH, int KW, in
     // (the F(4x4) kernel also serves the opt-in bf16x3 mode: in exact fp32 it is faster on these layers than the
     // split-bfloat16 implicit GEMM -- 3.1 vs 3.6 ms for the four of them -- and adds no drift)
     const bool base = KH == 3 && KW == 3 && dilation == 1 && !residual && split_k <= 1 && ws;
-    const bool can2 = base && cur_math() == MATH_FP32 && winograd_applies(H, W, C, N) &&
+    // F(2x2,3x3) also serves atrous layers whose pixel sub-grids are whole and even-sized (the FULL-image trunk's block2 /
+    // block3: 40 x 152 at dilation 2 / 4 = sub-grids of 20 x 76 / 10 x 38; the crop trunk's 12 x 12 maps were taken by
+    // the F(3x3,3x3) kernels before this rule is asked): 16 products per 2x2 block where the border-class implicit GEMM
+    // executes ~34
+    const bool atrous2 = KH == 3 && KW == 3 && dilation > 1 && !residual && split_k <= 1 && ws &&
+                         winograd_applies_dilated(H, W, C, N, dilation) && M64 * C * 4 < 0x7f000000LL;
+    const bool can2 = (base || atrous2) && cur_math() == MATH_FP32 && winograd_applies_dilated(H, W, C, N, dilation) &&
                       ws_floats >= winograd_scratch_floats(C, N);
     const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
     // (the automatic choice is conv2d_takes_winograd4's -- network.hip asks it too)
     if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
-                         : (M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1 : 0;
+                         : (base && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1
+                         : (atrous2 && g_atrous_wino2.load() && M64 >= g_atrous_wino2_min_pixels.load() && C >= 64 && N >= 64 &&
+                            g_tile_override.load() < 0 && g_class_override.load() < 0) ? 1 : 0;
     if (wino == 2 && can4) return 2;
     if ((wino == 1 || wino == 2) && can2) return 1;
     return 0;
@@ -1277,7 +1289,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     {
         const int wc = conv2d_winograd_choice(B, H, W, C, N, KH, KW, dilation, residual != nullptr, split_k, ws, ws_floats);
         if (wc == 2) return conv3x3_winograd4(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, 0, 0, nullptr, 0);
-        if (wc == 1) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream);
+        if (wc == 1) return conv3x3_winograd(x, B, H, W, C, w, bias, relu, y, N, ws, ws_floats, stream, dilation);
     }
     if (conv2d_takes_pointwise(M64, C, N, KH, KW, split_k))
         return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
@@ -1408,6 +1420,11 @@ extern "C" int mpsr_set_conv_math(int mode)
 }
 extern "C" int mpsr_get_conv_math(void) { return g_math; }
 extern "C" void mpsr_debug_set_wino3_halo(int on) { g_wino3_halo = on; }
+extern "C" void mpsr_debug_set_atrous_wino2(int on, int min_pixels)
+{
+    g_atrous_wino2 = on;
+    if (min_pixels > 0) g_atrous_wino2_min_pixels = min_pixels;
+}
 
 // What mpsr_conv2d_nhwc_f32 does with a layer when the schedule is left to it (split_k = 0, scratch provided, fp32):
 // kind 0 = implicit GEMM (conv_igemm_kernel / conv_sk_kernel), 1 = Winograd F(2x2,3x3), 2 = direct narrow kernel,
@@ -1422,8 +1439,8 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
     const double M = (double)B * H * W;
     // (the same predicate conv2d() asks; the plan assumes the scratch is there)
     if (mpsr::conv2d_takes_winograd3(B, H, W, C, N, KH, KW, dilation, 0, reinterpret_cast<const float *>(16), ~(size_t)0)) {
-        *kind = 4;  // 25 products per 3x3 sub-grid
-        *executed_flops = 2.0 * (double)B * dilation * dilation * 25.0 * C * N;
+        *kind = 4;  // 25 products per 3x3 tile (th x th tiles per pixel sub-grid: the launcher's own count)
+        *executed_flops = mpsr::winograd3_executed_flops(B, H, C, N, dilation);
         return MPSR_OK;
     }
     const int wc = mpsr::conv2d_winograd_choice(B, H, W, C, N, KH, KW, dilation, false, 0,

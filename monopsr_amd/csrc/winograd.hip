@@ -39,7 +39,13 @@ constexpr int kLdsFloats = 2 * 16 * 64 * ROW;
 struct WinoParams {
     const float *x, *u, *bias;
     float *y;
-    int B, H, W, C, N, th, tw, T;  // th x tw tiles per image, T tiles in all
+    int B, H, W, C, N, th, tw, T;  // th x tw tiles per pixel sub-grid, T tiles in all
+    // atrous layers: at dilation d the pixels (d i + a, d j + b) of one (a, b) form an independent dense image of
+    // H / d x W / d pixels (its taps only reach its own pixels; outside it is SAME-padding zeros), so the layer is d^2
+    // dense 3x3 convolutions per image on strided views: tile = (image, sub-grid (a, b), 2x2 block of the sub-grid).
+    // (ResNet-101's block2 / block3 on the FULL image, 40 x 152 at dilation 2 / 4: reference graph resnet_v1.py:116-127,
+    // resnet_utils.py:194-196; the 12 x 12 crop maps take the one-tile-per-sub-grid F(3x3,3x3) kernels instead.)
+    int dil;
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes;
     unsigned long long *trace;  // -DWINO_TRACE builds: per-workgroup timestamps (tools/wino_trace.py)
@@ -74,6 +80,23 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float *__restric
         dst[(size_t)(xi * 4 + 2) * N * KC] = (float)r2;
         dst[(size_t)(xi * 4 + 3) * N * KC] = (float)r3;
     }
+}
+
+// tile -> image, origin pixel of its sub-grid (a, b) and 2x2 block (ty, tx) of the sub-grid
+struct WinoTile {
+    int img, a, b, ty, tx;
+};
+__device__ __forceinline__ WinoTile wino_tile(const WinoParams &p, int t)
+{
+    WinoTile w;
+    const int tps = p.th * p.tw, tpi = tps * p.dil * p.dil;
+    w.img = t / tpi;
+    const int rem = t - w.img * tpi, sub = rem / tps, tt = rem - sub * tps;
+    w.a = sub / p.dil;
+    w.b = sub - w.a * p.dil;
+    w.ty = tt / p.tw;
+    w.tx = tt - w.ty * p.tw;
+    return w;
 }
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -134,16 +157,15 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
     unsigned aoff[16];
     {
         const int t = t0 + ltile;
-        const int tpi = p.th * p.tw;
-        const int img = t / tpi, rem = t - img * tpi;
-        const int ty = rem / p.tw, tx = rem - ty * p.tw;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        const WinoTile wt = wino_tile(p, t < p.T ? t : 0);
+        const int y0 = 2 * wt.ty - 1, x0 = 2 * wt.tx - 1;  // sub-grid coordinates of the patch's corner
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < p.H && x0 + s >= 0 && x0 + s < p.W;
-                aoff[r * 4 + s] = ok ? ((unsigned)((img * p.H + y0 + r) * p.W + x0 + s) * (unsigned)p.C + 4u * quad) * 4u
+                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < 2 * p.th && x0 + s >= 0 && x0 + s < 2 * p.tw;
+                const int yy = wt.a + p.dil * (y0 + r), xx = wt.b + p.dil * (x0 + s);
+                aoff[r * 4 + s] = ok ? ((unsigned)((wt.img * p.H + yy) * p.W + xx) * (unsigned)p.C + 4u * quad) * 4u
                                      : p.xbytes;
             }
     }
@@ -331,7 +353,6 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
     // of the wave's 32, output channel n0 + 32 wn + (lane & 31).
     const int n = n0 + wn * 32 + (lane & 31);
     const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    const int tpi = p.th * p.tw;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int tt = t0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -350,13 +371,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
             y11 = fmaxf(y11, 0.f);
         }
         if (tt < p.T && n < p.N) {
-            const int img = tt / tpi, rem = tt - img * tpi;
-            const int ty = rem / p.tw, tx = rem - ty * p.tw;
-            float *o = p.y + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.N + n;
+            const WinoTile wt = wino_tile(p, tt);
+            float *o = p.y + ((size_t)(wt.img * p.H + wt.a + 2 * p.dil * wt.ty) * p.W + wt.b + 2 * p.dil * wt.tx) * p.N + n;
             o[0] = y00;
-            o[p.N] = y01;
-            o[(size_t)p.W * p.N] = y10;
-            o[(size_t)p.W * p.N + p.N] = y11;
+            o[(size_t)p.dil * p.N] = y01;
+            o[(size_t)p.dil * p.W * p.N] = y10;
+            o[(size_t)p.dil * p.W * p.N + (size_t)p.dil * p.N] = y11;
         }
     }
 #ifdef WINO_TRACE
@@ -399,16 +419,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned aoff[16];
     {
         const int t = t0 + ltile;
-        const int tpi = p.th * p.tw;
-        const int img = t / tpi, rem = t - img * tpi;
-        const int ty = rem / p.tw, tx = rem - ty * p.tw;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        const WinoTile wt = wino_tile(p, t < p.T ? t : 0);
+        const int y0 = 2 * wt.ty - 1, x0 = 2 * wt.tx - 1;  // sub-grid coordinates of the patch's corner
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
-                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < p.H && x0 + sx >= 0 && x0 + sx < p.W;
-                aoff[r * 4 + sx] = ok ? ((unsigned)((img * p.H + y0 + r) * p.W + x0 + sx) * (unsigned)p.C + 4u * quad + 2u * ph) * 4u
+                const bool ok = t < p.T && y0 + r >= 0 && y0 + r < 2 * p.th && x0 + sx >= 0 && x0 + sx < 2 * p.tw;
+                const int yy = wt.a + p.dil * (y0 + r), xx = wt.b + p.dil * (x0 + sx);
+                aoff[r * 4 + sx] = ok ? ((unsigned)((wt.img * p.H + yy) * p.W + xx) * (unsigned)p.C + 4u * quad + 2u * ph) * 4u
                                       : p.xbytes;
             }
     }
@@ -597,7 +616,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dst[16 * 64] = ph == 0 ? y11 : y01;
     }
     __syncthreads();
-    const int tpi = p.th * p.tw;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int tt = t0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -608,11 +626,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             yb = fmaxf(yb, 0.f);
         }
         if (tt < p.T && n < p.N) {
-            const int img = tt / tpi, rem = tt - img * tpi;
-            const int ty = rem / p.tw, tx = rem - ty * p.tw;
-            float *o = p.y + ((size_t)(img * p.H + 2 * ty + ph) * p.W + 2 * tx) * p.N + n;
+            const WinoTile wt = wino_tile(p, tt);
+            float *o = p.y + ((size_t)(wt.img * p.H + wt.a + p.dil * (2 * wt.ty + ph)) * p.W + wt.b + 2 * p.dil * wt.tx) * p.N + n;
             o[0] = ya;
-            o[p.N] = yb;
+            o[(size_t)p.dil * p.N] = yb;
         }
     }
 }
@@ -630,13 +647,19 @@ namespace mpsr {
 size_t winograd_scratch_floats(int C, int N) { return (size_t)16 * N * C; }
 
 bool winograd_applies(int H, int W, int C, int N) { return H % 2 == 0 && W % 2 == 0 && C % KC == 0 && C >= KC && N >= 1; }
+// at dilation d: the d^2 pixel sub-grids of H / d x W / d pixels must be whole and even-sized
+bool winograd_applies_dilated(int H, int W, int C, int N, int dilation)
+{
+    return dilation >= 1 && H % (2 * dilation) == 0 && W % (2 * dilation) == 0 && C % KC == 0 && C >= KC && N >= 1;
+}
 
 std::atomic<int> g_wino_waves{8};  // 4: the one-wave-per-SIMD kernel, 8: the two-waves-per-SIMD variant
 
 int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
-                     int N, float *ws, size_t ws_floats, hipStream_t s)
+                     int N, float *ws, size_t ws_floats, hipStream_t s, int dilation)
 {
-    MPSR_REQUIRE(winograd_applies(H, W, C, N), "conv3x3_winograd: needs even H, W and C %% %d == 0", KC);
+    MPSR_REQUIRE(winograd_applies_dilated(H, W, C, N, dilation),
+                 "conv3x3_winograd: needs H, W multiples of 2 x dilation and C %% %d == 0", KC);
     if (ws_floats < winograd_scratch_floats(C, N) || !ws)
         return fail(MPSR_ERR_WORKSPACE, "conv3x3_winograd: scratch holds %zu floats, needs %zu", ws_floats,
                     winograd_scratch_floats(C, N));
@@ -653,8 +676,9 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
     WinoParams p;
     p.x = x; p.u = ws; p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N;
-    p.th = H / 2; p.tw = W / 2;
-    p.T = B * p.th * p.tw;
+    p.dil = dilation;
+    p.th = H / (2 * dilation); p.tw = W / (2 * dilation);
+    p.T = B * dilation * dilation * p.th * p.tw;
     p.cblocks = C / KC;
     p.nblocks = ceil_div(N, NT);
     p.mblocks = ceil_div(p.T, MT);

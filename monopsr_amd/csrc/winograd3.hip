@@ -447,6 +447,18 @@ bool winograd3_applies(int H, int W, int C, int dilation)
     return dilation >= 1 && H == W && H % (3 * dilation) == 0 && H / (3 * dilation) <= 16 && C % 16 == 0 && C >= 16;
 }
 
+// tiles of a launch (one per 3x3 block of a pixel sub-grid) and the multiply-adds it issues: ONE definition for the
+// launcher below and mpsr_conv2d_plan (bench.py's roofline.executed)
+long long winograd3_tiles(int B, int H, int dilation)
+{
+    const int th = H / (3 * dilation);
+    return (long long)B * dilation * dilation * th * th;
+}
+double winograd3_executed_flops(int B, int H, int C, int N, int dilation)
+{
+    return 2.0 * (double)winograd3_tiles(B, H, dilation) * 25.0 * C * N;
+}
+
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
                       float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s, const float *mask)
 {
@@ -490,7 +502,7 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
     p.th = th;
-    p.T = B * dilation * dilation * th * th;
+    p.T = (int)winograd3_tiles(B, H, dilation);
     p.cblocks = C / KC;
     p.nblocks = ceil_div(N, NT);
     p.mblocks = ceil_div(p.T, MT);

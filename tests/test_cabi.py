@@ -5,6 +5,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "monopsr_hip.h")
 
@@ -87,3 +89,22 @@ def test_relu_bitmask_family_host_side():
     assert lib.mpsr_conv2d_relu_masked_f32(None, 1, 12, 12, 64, None, None, None, 64, 3, 3, 4, None, 0, None) == 1
     assert lib.mpsr_adam_step_lr_dev(None, None, None, None, 0, None, 0.9, 0.999, 1e-8, 1.0, None) == 0
     assert lib.mpsr_adam_step_lr_dev(None, None, None, None, 4, None, 0.9, 0.999, 1e-8, 1.0, None) == 1
+
+
+@pytest.mark.parametrize("B,H,C,N,dil", [(64, 12, 128, 128, 2), (3, 12, 64, 64, 1), (2, 24, 64, 64, 1),
+                                         (8, 12, 256, 256, 4), (2, 48, 64, 64, 1)])
+def test_conv2d_plan_counts_the_tiles_the_f3x3_launch_runs(B, H, C, N, dil):
+    """mpsr_conv2d_plan, kind 4: the F(3x3,3x3) kernels run th x th tiles of 3x3 per pixel sub-grid (th = H / (3 dil):
+    1 for block3's crop maps, 2 for block2, 4 for block1, 8 / 16 for the small-batch decoder) -- the plan's executed
+    multiply-adds are 25 per tile and channel pair for exactly that tile count (one helper shared with the launcher)."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    kind, ex = ctypes.c_int(-1), ctypes.c_double(0)
+    lib.mpsr_debug_set_conv_winograd(3)
+    try:
+        _lib.check(lib.mpsr_conv2d_plan(B, H, H, C, N, 3, 3, dil, ctypes.byref(kind), ctypes.byref(ex)))
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    th = H // (3 * dil)
+    assert kind.value == 4
+    assert ex.value == 2.0 * B * dil * dil * th * th * 25 * C * N

@@ -232,6 +232,53 @@ def test_conv2d_winograd_vs_fp64(B, H, Wd, C, N, has_bias, relu, waves):
     assert not torch.equal(got, direct) or C * N < 1024  # it really is a different evaluation
 
 
+@pytest.mark.parametrize("B,H,Wd,C,N,dil,has_bias,relu", [
+    (1, 40, 152, 256, 256, 4, True, True),    # the full-image trunk's block3 conv2 (40 x 152 at dilation 4: 10 x 38 sub-grids)
+    (1, 40, 152, 128, 128, 2, True, True),    # ... block2 conv2 (dilation 2: 20 x 76 sub-grids)
+    (3, 8, 12, 16, 40, 2, False, False), (2, 12, 6, 32, 65, 3, True, True), (2, 16, 8, 48, 24, 4, True, False),
+    (5, 4, 4, 16, 8, 2, True, True)])
+@pytest.mark.parametrize("waves", [8, 4])
+def test_conv2d_winograd_on_atrous_sub_grids_vs_fp64(B, H, Wd, C, N, dil, has_bias, relu, waves):
+    """F(2x2,3x3) on the pixel sub-grids of an atrous 3x3 layer (csrc/winograd.hip with WinoParams::dil: the d^2
+    sub-grids of H / d x W / d pixels are independent dense images on strided views): the full-image trunk's block2 /
+    block3 layers (reference graph resnet_v1.py:116-127 at output stride 4 on a 160 x 608 input), ragged tile and
+    channel counts, several dilations.  <= 1e-5 of the tensor scale against float64 and against the border-class
+    implicit GEMM, and really another evaluation."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    rng = np.random.default_rng(B * 1000 + C + N + dil)
+    x = rng.standard_normal((B, H, Wd, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = _conv_ref(x, w, bias, None, dil, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    lib.mpsr_debug_set_conv_winograd(1)
+    lib.mpsr_debug_set_wino_waves(waves)
+    try:
+        got = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+        lib.mpsr_debug_set_wino_waves(8)
+    _close(got, ref, 1e-5, "atrous winograd F(2x2) %s, %d waves" % ((B, H, Wd, C, N, dil), waves))
+    lib.mpsr_debug_set_conv_winograd(0)
+    try:
+        direct = dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    _close(got, direct, 1e-5, "atrous winograd vs implicit GEMM")
+    assert not torch.equal(got, direct) or C * N < 1024
+    # the plan reports the kernel the call takes and the products it issues
+    kind, ex = ctypes.c_int(-1), ctypes.c_double(0)
+    lib.mpsr_debug_set_conv_winograd(1)
+    try:
+        _lib.check(lib.mpsr_conv2d_plan(B, H, Wd, C, N, 3, 3, dil, ctypes.byref(kind), ctypes.byref(ex)))
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    assert kind.value == 1 and ex.value == 2.0 * B * (H // 2) * (Wd // 2) * 16 * C * N
+
+
 UPCONV_CASES = [
     # B, h, w, C, OH, OW, N, align_corners, bias, relu
     (2, 12, 12, 128, 24, 24, 128, True, True, True),    # the decoder's 2x align-corners upsampling, narrow
