@@ -610,7 +610,7 @@ def cpu_baseline(weights, host, sample, npts, budget_s=18.0):
 
 
 def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_dev=None, make_trainer=None,
-                         bucket_mib=64, full_trunk=False):
+                         bucket_mib=64, full_trunk=False, allreduce="rccl", decoder_bn="batch"):
     """ms per training step of `batch` instances per rank (crop trunk + decoder + heads trainable, 72.8 M parameters
     in one flat buffer).  With a process group (N > 1) every rank trains its own shard and the flat 291 MB gradient
     goes through core/trainer.ReverseBucketReducer (64 MiB buckets launched from the end of the buffer as backward
@@ -623,11 +623,11 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         cfg = config_utils.default_config()
         if full_trunk:  # both trunks trainable: the 100.3 M-parameter / 401 MB gradient of BASELINE cfg4
             net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=(W.CROP_SCOPE, W.FULL_SCOPE)), device=device,
-                                     decoder_bn="batch", full_trunk=True)
+                                     decoder_bn=decoder_bn, full_trunk=True)
         else:
-            net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn="batch")
+            net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn=decoder_bn)
         tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0,
-                                     bucket_bytes=bucket_mib << 20)
+                                     bucket_bytes=bucket_mib << 20, allreduce=allreduce)
         sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
                       cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"],
                       mean_lwh=inp["mean_lwh"], prop_cen_z_offset=inp["z_off"])
@@ -661,7 +661,10 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
     out = {"params": int(net.params.numel()), "grad_bytes": int(net.grads.numel() * 4), "steps": steps,
            "ranks": world,
            "what": "fwd + configured losses (incl. global-map projection) + bwd + clip + Adam + EMA, fp32; decoder "
-                   "BN: per-rank batch statistics (no cross-rank statistics exchange)"}
+                   "BN: %s" % ("batch statistics pooled over all ranks (fp64 sums all-reduced per layer and direction: the "
+                               "whole step's batch, as the reference's single-process step)" if decoder_bn == "batch_global"
+                               else "per-rank batch statistics (no cross-rank statistics exchange; --decoder-bn "
+                                    "batch_global pools them)")}
     losses = [float(tr.step(sample)) for _ in range(warmup)]
     if world > 1:
         tr.reducer.enabled = False
@@ -673,9 +676,14 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         out.update({"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch * world / dt, 1),
                     "ms_per_step_without_allreduce": round(dt_local * 1e3, 2),
                     "exposed_allreduce_ms": round((dt - dt_local) * 1e3, 2),
-                    "allreduce": "ReverseBucketReducer: %d buckets of <= %d MiB, async, launched as backward reports "
+                    "allreduce": "ReverseBucketReducer (%s): %d buckets of <= %d MiB, async, launched as backward reports "
                                  "layers ready; average, then per-variable clip_by_norm, then Adam" %
-                                 (len(tr.reducer.buckets), tr.reducer.bucket_bytes >> 20),
+                                 ("one all_reduce per bucket" if tr.reducer.mode == "rccl" else
+                                  "reduce_scatter_tensor + all_gather_into_tensor per bucket",
+                                  len(tr.reducer.buckets), tr.reducer.bucket_bytes >> 20),
+                    "allreduce_mode": tr.reducer.mode,
+                    "nccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS",
+                                                                "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None},
                     "gradients": "real (this step's backward), %d floats" % net.grads.numel()})
         # the same buffer all-reduced alone: what the wire costs when nothing overlaps it
         try:
@@ -752,7 +760,7 @@ class Emitter:
 
     def __init__(self, rank, deadline_s):
         import threading
-        self.rank, self.lock, self.done, self.result = rank, threading.Lock(), False, None
+        self.rank, self.lock, self.done, self.result = rank, threading.RLock(), False, None  # (re-entrant: the signal handler runs on the main thread, possibly inside emit())
         self.timer = threading.Timer(deadline_s, self._expired)
         self.timer.daemon = True
         self.deadline_s = deadline_s
@@ -769,7 +777,9 @@ class Emitter:
                 sys.stderr.write("bench.py: rank 0 received signal %d after the headline was measured; emitting it "
                                  "without the unfinished extras\n" % signum)
                 self._flush(reason="terminated_by_signal_%d" % signum)
-                os._exit(0)
+                # non-zero: the run WAS terminated (another rank died); the line carries extras_incomplete and the
+                # measured headline, the status tells the launcher's caller that the extras are missing for a reason
+                os._exit(128 + signum)
             try:
                 signal.signal(signal.SIGTERM, on_term)
             except ValueError:  # not the main thread
@@ -909,6 +919,13 @@ def main():
                     help="training_step with BOTH ResNet-101 trunks trainable (100.3 M parameters: the 401 MB gradient "
                          "BASELINE cfg4 names) on a raw 375x1242 image per rank instead of the crop-trunk-only net")
     ap.add_argument("--no-full-image", action="store_true", help="skip the extra full_image_path object")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "direct"],
+                    help="N > 1: the training step's gradient exchange per bucket -- rccl: one all_reduce (the library "
+                         "picks ring / tree / ...), direct: reduce_scatter + all_gather of 1 / N shards (every peer's "
+                         "own xGMI link once per phase, SURVEY 5)")
+    ap.add_argument("--decoder-bn", default="batch", choices=["batch", "batch_global"],
+                    help="training_step: map-decoder BatchNorm statistics per rank, or pooled over all ranks (the "
+                         "reference's whole-step batch, net_builder.py:78-79,86-87)")
     ap.add_argument("--extras-deadline", type=float, default=900.0,
                     help="seconds after the headline is measured before the watchdog prints it without the "
                          "unfinished extra objects")
@@ -1158,7 +1175,8 @@ def main():
                 tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
                 # N = 1: 2 + 18 steps, so that the line shows the loss past the first Adam steps' transient
                 ts = training_step_object(device, tb, tinp, steps=6 if multi else 18, dist=dist if multi else None,
-                                          red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=args.train_full_trunk)
+                                          red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=args.train_full_trunk,
+                                          allreduce=args.allreduce, decoder_bn=args.decoder_bn)
                 result["training_step"] = ts
             except Exception as e:
                 result["training_step"] = {"error": repr(e)}

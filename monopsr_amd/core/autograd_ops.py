@@ -15,6 +15,7 @@ from monopsr_amd.core import device_net as dn
 # split_k argument of every forward / data-gradient convolution: 0 = the library schedules the launch (Winograd for
 # the decoder's dense 3x3 layers and their data gradients, stream-K for the long-K FC layers): 88 -> 81 ms per step
 _WGRAD_SCRATCH = {}
+dn._SCRATCH_CACHES.append(_WGRAD_SCRATCH)
 _SCHED = 0
 
 
@@ -30,10 +31,37 @@ class LayerRef:
 
 
 class BatchNormState:
-    """Moving statistics of one training-mode BatchNorm (slim.batch_norm defaults: decay 0.999, no scale)."""
+    """Moving statistics of one training-mode BatchNorm (slim.batch_norm defaults: decay 0.999, no scale).
+    `sync_group`: None = statistics over this process's instances; a torch.distributed group (or True for the default
+    group) = over the instances of ALL its ranks -- the reference normalises over the whole step's batch
+    (net_builder.py:78-79,86-87), so a sharded batch must pool its sums to give the same result."""
 
-    def __init__(self, moving_mean, moving_variance, eps=1e-3, decay=0.999):
+    def __init__(self, moving_mean, moving_variance, eps=1e-3, decay=0.999, sync_group=None):
         self.moving_mean, self.moving_variance, self.eps, self.decay = moving_mean, moving_variance, eps, decay
+        self.sync_group = sync_group
+
+    def _group(self):
+        """The process group to pool sums over, or None when there is nothing to pool."""
+        import torch.distributed as dist
+        if self.sync_group is None or not (dist.is_available() and dist.is_initialized()):
+            return None
+        g = None if self.sync_group is True else self.sync_group
+        return (g, dist) if dist.get_world_size(g) > 1 else None
+
+    def all_reduce_sums(self, t):
+        """Sum a small fp64 tensor over the group in place (device tensor; through the host where the backend has no
+        device collectives: gloo in the CPU / shared-GPU tests)."""
+        gd = self._group()
+        if gd is None:
+            return t
+        g, dist = gd
+        if dist.get_backend(g) == "gloo" and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=g)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=g)
+        return t
 
 
 def _relu_grad(dy, y):
@@ -144,6 +172,7 @@ class UnitLink:
 
 
 _MASK_SCRATCH = {}
+dn._SCRATCH_CACHES.append(_MASK_SCRATCH)
 # A/B switch (tools/train_bench.py --unfused-relu-grads): False = every ReLU gradient inside a unit is an elementwise pass
 FUSED_RELU_GRADS = True
 
@@ -268,6 +297,7 @@ class BottleneckFn(torch.autograd.Function):
 
 
 _UPCONV_SCRATCH = {}
+dn._SCRATCH_CACHES.append(_UPCONV_SCRATCH)
 
 
 class UpsampledConv2dFn(torch.autograd.Function):
@@ -361,18 +391,32 @@ class BatchNormReluFn(torch.autograd.Function):
         lib = _lib.lib()
         sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
         _lib.check(lib.mpsr_batch_norm_stats(_lib.ptr(z), M, C, sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
-        d = sums[0] / M
-        mean = z.reshape(M, C)[0].double() + d
-        var = torch.clamp(sums[1] / M - d * d, min=0.0)
+        Mtot = M
+        if st._group() is None:
+            d = sums[0] / M
+            mean = z.reshape(M, C)[0].double() + d
+            var = torch.clamp(sums[1] / M - d * d, min=0.0)
+        else:
+            # the kernel's sums are of (z - z[0]) per rank: un-shift them to plain first / second moments in fp64, pool
+            # [sum z | sum z^2 | count] over the ranks, then mean and (biased) variance of the WHOLE step's batch
+            sh = z.reshape(M, C)[0].double()
+            pooled = torch.cat([sums[0] + M * sh, sums[1] + 2.0 * sh * sums[0] + M * sh * sh,
+                                torch.full((1,), float(M), dtype=torch.float64, device=z.device)])
+            st.all_reduce_sums(pooled)
+            Mtot = pooled[2 * C]
+            mean = pooled[:C] / Mtot
+            var = torch.clamp(pooled[C:2 * C] / Mtot - mean * mean, min=0.0)
         with torch.no_grad():
             st.moving_mean.mul_(st.decay).add_(mean.float(), alpha=1.0 - st.decay)
-            st.moving_variance.mul_(st.decay).add_((var * (M / max(M - 1, 1))).float(), alpha=1.0 - st.decay)
+            unbias = (Mtot / torch.clamp(Mtot - 1, min=1.0)) if torch.is_tensor(Mtot) else M / max(M - 1, 1)
+            st.moving_variance.mul_(st.decay).add_((var * unbias).float(), alpha=1.0 - st.decay)
         mean32 = mean.float().contiguous()
         inv = torch.rsqrt(var + st.eps).float().contiguous()
         y = torch.empty_like(z)
         _lib.check(lib.mpsr_batch_norm_apply(_lib.ptr(z), M, C, _lib.ptr(mean32), _lib.ptr(inv), _lib.ptr(layer.b),
                                              int(layer.relu), _lib.ptr(y), _lib.stream()))
         ctx.layer = layer
+        ctx.count = Mtot  # rows the statistics were taken over (all ranks' when pooled)
         ctx.save_for_backward(z, y if layer.relu else None, mean32, inv)
         return y
 
@@ -387,8 +431,10 @@ class BatchNormReluFn(torch.autograd.Function):
         sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
         _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
                                                  _lib.ptr(inv), sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
-        L.db.add_(sums[0].float())
-        means = (sums / M).float().contiguous()
+        L.db.add_(sums[0].float())  # (this rank's share: the gradient all-reduce pools it like every other parameter's)
+        # the two means of the normalisation's backward are over the rows the statistics came from
+        L.batch_norm.all_reduce_sums(sums)
+        means = (sums / ctx.count).float().contiguous()
         dz = torch.empty_like(z)
         _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
                                             _lib.ptr(inv), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),

@@ -326,6 +326,15 @@ class DeviceNet:
 # ---------------------------------------------------------------------- single-layer helpers (tests, tools)
 
 _SCHED_SCRATCH = {}
+_SCRATCH_CACHES = []  # every per-(device, stream) scratch cache of the package (pinned_stream_scratch walks them)
+
+
+def pinned_stream_scratch(device, stream):
+    """The scratch tensors the caches hold for (device, stream), for a caller that must keep them alive: a captured HIP
+    graph has their addresses baked into its launches -- holding the tensors keeps the memory from being handed to
+    anyone else when a cache later evicts the entry (more than `keep` streams)."""
+    key = (device.index, stream.cuda_stream)
+    return [c[key] for c in [_SCHED_SCRATCH] + _SCRATCH_CACHES if key in c]
 
 
 def stream_scratch(cache, device, floats, keep=8):

@@ -26,16 +26,20 @@ def _im2col_root(img, kpad):
 
 
 class TrainNet:
-    def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False, decoder_bn='frozen'):
+    def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False, decoder_bn='frozen',
+                 bn_group=None):
         """full_trunk: also hold (and train) the full-image ResNet-101 (`weights` must then carry both scopes); its
         layers follow the heads in the flat buffer, so the flat gradient is the reference's whole 100 M-parameter
         set (401 MB at full width)."""
         """decoder_bn: 'frozen' = the map decoder's BatchNorm runs on its moving statistics, folded into the
         convolutions like the trunks' (an inference-mode re-parameterisation); 'batch' = the reference's training
         graph (net_builder.py:76-87, is_training=True): batch statistics over the step's instances, beta trained,
-        moving statistics updated with decay 0.999.  In data-parallel runs the statistics are per rank."""
-        if decoder_bn not in ('frozen', 'batch'):
-            raise ValueError("decoder_bn must be 'frozen' or 'batch'")
+        moving statistics updated with decay 0.999, statistics per rank in a data-parallel run; 'batch_global' = the
+        same with the sums pooled over the ranks of `bn_group` (default group when None): the statistics of the whole
+        step's batch, as the reference's single-process step has them -- a sharded batch then gives the unsharded
+        batch's activations and gradients (2 C fp64 numbers per layer and direction on the wire)."""
+        if decoder_bn not in ('frozen', 'batch', 'batch_global'):
+            raise ValueError("decoder_bn must be 'frozen', 'batch' or 'batch_global'")
         self.decoder_bn = decoder_bn
         self.device = torch.device(device)
         parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
@@ -85,7 +89,7 @@ class TrainNet:
                                             bool(r["relu"])))
         self.n_trunk = len(parts[0][1])
         self.n_dec = len(parts[1][1])
-        if decoder_bn == 'batch':
+        if decoder_bn in ('batch', 'batch_global'):
             # decoder records: squash (2 GEMMs), then one record per spec; BatchNorm layers get the UNFOLDED kernel
             # in their weight slot and beta in their bias slot
             idx = self.n_trunk + 1
@@ -101,7 +105,9 @@ class TrainNet:
                 L.b.copy_(torch.from_numpy(weights[name + "/BatchNorm/beta"].astype(np.float32)).to(self.device))
                 t = lambda a: torch.from_numpy(a.astype(np.float32)).to(self.device)
                 L.batch_norm = ops.BatchNormState(t(weights[name + "/BatchNorm/moving_mean"]),
-                                                  t(weights[name + "/BatchNorm/moving_variance"]), W.DECODER_BN_EPS)
+                                                  t(weights[name + "/BatchNorm/moving_variance"]), W.DECODER_BN_EPS,
+                                                  sync_group=(bn_group if bn_group is not None else True)
+                                                  if decoder_bn == 'batch_global' else None)
 
     # ------------------------------------------------------------------ forward pieces
     fused_units = True  # trunk(): bottleneck units as single autograd nodes (ops.BottleneckFn); False = layer by layer

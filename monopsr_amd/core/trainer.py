@@ -20,10 +20,17 @@ class ReverseBucketReducer:
     layers report their gradients ready -- backward visits layers in roughly reverse buffer order (heads, decoder,
     trunk), so the first buckets are on the wire while the trunk is still back-propagating."""
 
-    def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None, mode="rccl"):
         """layer_spans[i]: the element range(s) of `flat` layer i's backward writes -- one (lo, hi) or a list of them
-        (weight gradient AND bias gradient: a bucket holding any part of either must wait for the layer)."""
-        self.flat, self.group, self.bucket_bytes = flat, group, bucket_bytes
+        (weight gradient AND bias gradient: a bucket holding any part of either must wait for the layer).
+        mode: "rccl" = one all_reduce per bucket (the library's own algorithm choice); "direct" = reduce-scatter of the
+        bucket into 1 / world shards followed by an all-gather (on the fully connected xGMI mesh every rank
+        then sends each peer its shard ONCE per phase over that peer's own link, instead of 2 (world - 1) ring steps
+        bound by one link).  Same sums up to the reduction order; selectable with bench.py --allreduce."""
+        if mode not in ("rccl", "direct"):
+            raise ValueError("reducer mode must be 'rccl' or 'direct'")
+        self.flat, self.group, self.bucket_bytes, self.mode = flat, group, bucket_bytes, mode
+        self._shards = {}
         self.enabled = True  # False: buckets are tracked but nothing is exchanged (timing the step without it)
         n = max(1, bucket_bytes // flat.element_size())
         self.buckets = [(lo, min(lo + n, flat.numel())) for lo in range(0, flat.numel(), n)]
@@ -44,6 +51,7 @@ class ReverseBucketReducer:
         self.pending = [set(m) for m in self.members]
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self.deferred = []
 
     def _active(self):
         return (self.enabled and dist.is_available() and dist.is_initialized()
@@ -59,12 +67,34 @@ class ReverseBucketReducer:
         self.launched[bi] = True
         if self._active():
             lo, hi = self.buckets[bi]
-            self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+            world = dist.get_world_size(self.group)
+            if self.mode == "direct" and (hi - lo) % world == 0:
+                # (the two collectives of one process group run in issue order: the gather reads what the scatter left)
+                shard = self._shards.get(bi)
+                if shard is None:
+                    shard = self._shards[bi] = torch.empty(((hi - lo) // world,), dtype=self.flat.dtype,
+                                                           device=self.flat.device)
+                rs = dist.reduce_scatter_tensor(shard, self.flat[lo:hi], group=self.group, async_op=True)
+                if dist.get_backend(self.group) == "nccl":
+                    # RCCL runs a communicator's collectives in issue order on its own stream: the gather can follow now
+                    # and both overlap the rest of backward
+                    self.works.append(rs)
+                    self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], shard, group=self.group,
+                                                                  async_op=True))
+                else:  # gloo runs asynchronous work items concurrently: the gather is issued once the scatter is done
+                    self.deferred.append((rs, bi))
+            else:  # "rccl", or a last bucket that does not divide into world shards
+                self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
 
     def finish(self, average=True):
         for bi in range(len(self.buckets) - 1, -1, -1):
             if not self.launched[bi]:
                 self._launch(bi)
+        for rs, bi in self.deferred:
+            rs.wait()
+            lo, hi = self.buckets[bi]
+            self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], self._shards[bi], group=self.group,
+                                                          async_op=True))
         for w in self.works:
             w.wait()
         if average and self._active():
@@ -148,6 +178,10 @@ class _StepGraph:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph, stream=self.side):
                     self.loss = tr._eager_step(self.static, lr_t_dev=self.lr_t)
+                # the graph's launches hold the addresses of this stream's scratch buffers: keep the tensors, so that a
+                # cache eviction (more than 8 streams using the package) cannot hand the memory to someone else
+                from monopsr_amd.core import device_net as dn
+                self.pinned = dn.pinned_stream_scratch(tr.net.params.device, self.side)
                 # (capture records, it does not run: this call's step is the first replay)
                 self.graph.replay()
                 loss = self.loss.clone()
@@ -168,7 +202,7 @@ class InstanceTrainer:
     gt_view_angs (B), gt_inst_xyz_maps_local / gt_inst_xyz_maps_global (B,h,w,3), gt_valid_mask_maps (B,h,w,1)."""
 
     def __init__(self, net, model_config, dataset_config, train_config=None, group=None, lr=None, clip_norm=1.0,
-                 bucket_bytes=64 << 20, classes_name='Car'):
+                 bucket_bytes=64 << 20, classes_name='Car', allreduce="rccl"):
         self.net, self.model_config, self.dataset_config = net, model_config, dataset_config
         self.clip_norm, self.classes_name = clip_norm, classes_name
         self.model = MonoPSRModel(model_config, dataset_config, net, 'train', classes_name, fused_heads=False)
@@ -185,7 +219,7 @@ class InstanceTrainer:
             spans.append([((t.data_ptr() - base) // 4, (t.data_ptr() - base) // 4 + t.numel())
                           for t in (L.dw, L.db) if t is not None])
         self.spans = spans
-        self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group)
+        self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group, mode=allreduce)
         for li, L in enumerate(net.layers):
             L.on_grad_ready = (lambda i=li: self.reducer.layer_ready(i))
 
@@ -317,5 +351,13 @@ class InstanceTrainer:
                 L.batch_norm.moving_variance.copy_(torch.from_numpy(
                     t['monopsr_amd/layer_%03d/BatchNorm/moving_variance' % i]).to(dev))
         ema = t.get('monopsr_amd/flat_params/ExponentialMovingAverage')
-        self.optimizer.shadow = None if ema is None else torch.from_numpy(ema).to(dev)
+        opt = self.optimizer
+        if ema is not None and opt.shadow is not None and tuple(opt.shadow.shape) == tuple(ema.shape):
+            # in place: a captured step graph (capture_step) has this tensor's address baked into its lerp launch --
+            # rebinding the attribute would leave the replays averaging into a buffer nobody reads any more
+            opt.shadow.copy_(torch.from_numpy(ema).to(dev))
+        else:
+            opt.shadow = None if ema is None else torch.from_numpy(ema).to(dev)
+            # the moving average appeared, vanished or changed size: a captured graph no longer describes the step
+            self.release_step_graph()
         return self.global_step

@@ -281,3 +281,29 @@ def test_captured_step_trains_like_the_eager_step():
     bad = dict(data[0], rgb_image_crops=data[0]["rgb_image_crops"][:2])
     with pytest.raises(ValueError):
         tr.step(bad)
+    # capture -> restore -> step -> save.  restore() must leave the captured graph's moving-average tensor in
+    # place (its address is baked into the replayed lerp launch): the average keeps moving after a resume and save() /
+    # averaged_params() see it
+    import tempfile
+    with tempfile.TemporaryDirectory() as ckpt:
+        prefix = tr.save(ckpt)
+        shadow_ptr = tr.optimizer.shadow.data_ptr()
+        before = tr.optimizer.shadow.clone()
+        assert tr.restore(prefix) == steps
+        assert tr._graph is not None and tr.optimizer.shadow.data_ptr() == shadow_ptr
+        assert torch.equal(tr.optimizer.shadow, before)
+        float(tr.step(data[0]))
+        torch.cuda.synchronize()
+        moved = float((tr.optimizer.shadow - before).abs().max())
+        assert moved > 0, "the moving average froze after restore()"
+        # it moved by (1 - decay) x (params - average), as one eager update would
+        want = before + (1.0 - 0.9) * (net.params - before)
+        assert float((tr.optimizer.shadow - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        from monopsr_amd.core import tf_checkpoint
+        saved = tf_checkpoint.read_checkpoint(tr.save(ckpt))
+        np.testing.assert_array_equal(saved['monopsr_amd/flat_params/ExponentialMovingAverage'],
+                                      tr.optimizer.shadow.cpu().numpy())
+        # a checkpoint WITHOUT an average rebinds the attribute: the captured graph is dropped, not left replaying
+        tr.optimizer.shadow = None
+        tr.restore(tr.save(ckpt))
+        assert tr._graph is None

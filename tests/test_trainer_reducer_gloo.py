@@ -13,7 +13,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="rccl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -21,7 +21,7 @@ def _worker(rank, world, port, q):
         from monopsr_amd.core.trainer import ReverseBucketReducer
         flat = torch.zeros(1000)
         spans = [(0, 300), (300, 450), (450, 700), (700, 1000)]  # four "layers"
-        red = ReverseBucketReducer(flat, spans, bucket_bytes=250 * 4)
+        red = ReverseBucketReducer(flat, spans, bucket_bytes=250 * 4, mode=mode)
         assert len(red.buckets) == 4
         order = []
         orig = red._launch
@@ -61,6 +61,31 @@ def test_reverse_bucket_reducer_two_ranks():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert all(res.values()), res
+
+
+def test_reverse_bucket_reducer_direct_mode_two_and_three_ranks():
+    """mode="direct": reduce_scatter_tensor + all_gather_into_tensor per bucket (SURVEY 5's mesh-aware exchange) gives the
+    all-reduce's result with the same launch order; at three ranks the 250-element buckets do not divide into shards
+    and fall back to all_reduce bucket by bucket -- same result."""
+    ctx = mp.get_context("spawn")
+    for world in (2, 3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, "direct")) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        res = dict(q.get(timeout=5) for _ in range(world))
+        assert all(res.values()), (world, res)
+
+
+def test_reducer_rejects_an_unknown_mode():
+    import pytest
+    from monopsr_amd.core.trainer import ReverseBucketReducer
+    with pytest.raises(ValueError):
+        ReverseBucketReducer(torch.zeros(8), [(0, 8)], mode="ring")
 
 
 def _bias_worker(rank, world, port, q):
