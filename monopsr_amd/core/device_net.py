@@ -367,8 +367,10 @@ def device_constant(values, device, dtype=torch.float32):
     return t
 
 
-def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1):
-    """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C)."""
+def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False, split_k=1, math=None,
+           winograd_policy=None):
+    """mpsr_conv2d_nhwc_f32 on torch tensors: x (B,H,W,C), w_ok (N, kh*kw*C).  math ("fp32" / "bf16x3") and
+    winograd_policy ("auto" / "off"): options of THIS call (mpsr_conv2d_nhwc_f32_ex); None = the process-wide defaults."""
     x, w_ok = x.contiguous(), w_ok.contiguous()
     B, H, Wd, C = x.shape
     N = w_ok.shape[0]
@@ -382,10 +384,17 @@ def conv2d(x, w_ok, bias=None, residual=None, kh=1, kw=1, dilation=1, relu=False
     else:
         nws = split_k * B * H * Wd * N if split_k > 1 else 0
         ws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
-    _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32(
+    if math is None and winograd_policy is None:
+        _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32(
+            _lib.ptr(x), B, H, Wd, C, _lib.ptr(w_ok), _lib.ptr(bias.contiguous()) if bias is not None else None,
+            _lib.ptr(residual.contiguous()) if residual is not None else None, _lib.ptr(y), N, kh, kw, dilation,
+            int(relu), split_k, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()))
+        return y
+    opts = _lib.ConvOpts(_lib.CALL_MATH[math], _lib.CALL_WINOGRAD[winograd_policy])
+    _lib.check(_lib.lib().mpsr_conv2d_nhwc_f32_ex(
         _lib.ptr(x), B, H, Wd, C, _lib.ptr(w_ok), _lib.ptr(bias.contiguous()) if bias is not None else None,
         _lib.ptr(residual.contiguous()) if residual is not None else None, _lib.ptr(y), N, kh, kw, dilation,
-        int(relu), split_k, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()))
+        int(relu), split_k, _lib.ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(opts), _lib.stream()))
     return y
 
 
