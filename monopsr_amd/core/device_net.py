@@ -172,7 +172,7 @@ class DeviceNet:
         ws = (self.ws_trunk if which == "crop" else self.ws_trunk_full).get(nbytes)
         fc = self._filter_cache(which, part)
         fc.before_call()
-        opts = fc.opts((B, H, Wd), math=self.math, winograd_policy=self.winograd_policy)
+        opts = fc.opts((B, H, Wd), math=getattr(self, 'math', None), winograd_policy=getattr(self, 'winograd_policy', None))
         _lib.check(lib.mpsr_trunk_fwd_ex(_lib.ptr(img), B, H, Wd, _lib.ptr(part.blob), part.layers, part.n,
                                          _lib.ptr(out), _lib.ptr(ws), ws.numel(), ctypes.byref(opts), _lib.stream()))
         fc.mark_filled()
@@ -204,7 +204,7 @@ class DeviceNet:
         fc = self._filter_cache("dec", self.decoder)
         fc.before_call()
         opts = fc.opts((B, fh, fw, mh, mw, want_feat_map), box3d_event.cuda_event if box3d_event is not None else None,
-                       math=self.math, winograd_policy=self.winograd_policy)
+                       math=getattr(self, 'math', None), winograd_policy=getattr(self, 'winograd_policy', None))
         _lib.check(lib.mpsr_squash_decoder_fwd_ex(_lib.ptr(crop_feat), _lib.ptr(full_feat), B, fh, fw, mh, mw,
                                                   _lib.ptr(self.decoder.blob), self.decoder.layers, self.decoder.n,
                                                   _lib.ptr(feat_box), _lib.ptr(feat_map), _lib.ptr(xyz), _lib.ptr(ws),

@@ -591,3 +591,43 @@ def test_wgrad_winograd_domain_vs_direct_and_fp64():
     _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(x.data_ptr(), dy.data_ptr(), B, H, W, C, N, 3, 3, 1, dw2.data_ptr(), None,
                                             None, 0, _lib.stream()))
     assert (dw2 - outs[0][0]).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("B,dil,C,N", [(128, 4, 128, 192), (136, 4, 256, 256), (600, 2, 128, 128)])
+def test_wgrad_winograd3_domain_vs_direct_and_fp64(B, dil, C, N):
+    """The Winograd F(3x3,3x3)-domain weight gradient of the atrous 3x3 layers whose pixel sub-grids are single tiles
+    (csrc/winograd3_wgrad.hip: block3's conv2, 12x12 at dilation 4 -- dU = sum over tiles of (A dY A^T) (.) (B'^T d B'),
+    dg = G'^T dU G'; one 400-accumulator wave per 32 x 32 block) against the border-class direct kernel on layer-sized
+    problems (ragged tile counts: the last slice's steps run past the last tile) and against float64 autograd on a slice
+    of the filters."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    H = W = 3 * dil
+    g = torch.Generator(device="cuda").manual_seed(B + C)
+    x = torch.randn((B, H, W, C), device="cuda", generator=g).clamp_(min=0)
+    dy = torch.randn((B, H, W, N), device="cuda", generator=g)
+    dy = dy * (torch.rand((B, H, W, N), device="cuda", generator=g) > 0.5)  # (a ReLU-masked gradient, as in the step)
+    nws = 64  # (this form needs no scratch: it folds dU back in registers and accumulates into dw)
+    assert lib.mpsr_conv2d_wgrad_scratch_floats(B, H, W, C, N, 3, 3, dil) == 0
+    ws = torch.empty((nws,), device="cuda")
+    outs = []
+    for wino in (0, 1):
+        dw = torch.full((N, 9 * C), 0.25, device="cuda")  # (the kernels ACCUMULATE into dw)
+        db = torch.zeros((N,), device="cuda")
+        lib.mpsr_debug_set_wgrad_winograd(wino)
+        try:
+            _lib.check(lib.mpsr_conv2d_wgrad_ws_f32(x.data_ptr(), dy.data_ptr(), B, H, W, C, N, 3, 3, dil, dw.data_ptr(),
+                                                    db.data_ptr(), ws.data_ptr(), nws, _lib.stream()))
+        finally:
+            lib.mpsr_debug_set_wgrad_winograd(1)
+        outs.append((dw - 0.25, db))
+    scale = outs[0][0].abs().max().item()
+    assert (outs[1][0] - outs[0][0]).abs().max().item() <= 1e-4 * scale
+    assert not torch.equal(outs[1][0], outs[0][0])  # it really is the other evaluation
+    assert (outs[1][1] - outs[0][1]).abs().max().item() <= 1e-4 * outs[0][1].abs().max().item()
+    xd = x.double().permute(0, 3, 1, 2)
+    w = torch.zeros((4, C, 3, 3), dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv2d(xd, w, padding=dil, dilation=dil)
+    (y * dy[..., 7:11].double().permute(0, 3, 1, 2)).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(4, 9 * C)
+    assert (outs[1][0][7:11].double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()

@@ -1,7 +1,8 @@
-"""Audit of the compiled gfx950 code of csrc/winograd3w.hip (no GPU needed: hipcc cross-compiles).
+"""Audit of the compiled gfx950 code of csrc/winograd3w.hip and csrc/winograd3_wgrad.hip (no GPU needed: hipcc
+cross-compiles).
 
-That kernel keeps 256 of its 400 accumulator registers under literal names (a0..a255) inside inline-asm statements, and
-issues its MFMAs from inline asm.  hipcc neither knows that those registers are live between the statements nor pads
+Those kernels keep 256 of their 400 accumulator registers under literal names (a0..a255) inside inline-asm statements, and
+issue their MFMAs from inline asm.  hipcc neither knows that those registers are live between the statements nor pads
 hazards around them, so three properties of the generated code are part of the kernel's correctness and are checked
 here on every build of the test suite:
   1. the compiler never touches the accumulator half of the register file itself (it would only do so to spill vector
@@ -23,30 +24,35 @@ CSRC = os.path.join(ROOT, "monopsr_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.fixture(scope="module")
-def w3w_asm():
+# source file -> (kernel name fragment, MFMA statements of its two unrolled K steps)
+AUDITED = {"winograd3w.hip": ("wino3w_conv_kernel", 200), "winograd3_wgrad.hip": ("wino3_wgrad_kernel", 100)}
+
+
+@pytest.fixture(scope="module", params=sorted(AUDITED))
+def w3w_asm(request):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
+    src = request.param
     tmp = tempfile.mkdtemp(prefix="w3w_audit_")
     try:
-        # the flags of csrc/Makefile's rule for this file
+        # the flags of csrc/Makefile's rule for these files
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-save-temps", "-c",
-               os.path.join(CSRC, "winograd3w.hip"), "-o", os.path.join(tmp, "w3w.o")]
+               os.path.join(CSRC, src), "-o", os.path.join(tmp, "audit.o")]
         subprocess.check_call(cmd, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         path = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
         assert len(path) == 1, os.listdir(tmp)
         with open(os.path.join(tmp, path[0])) as f:
-            yield f.read()
+            yield (f.read(),) + AUDITED[src]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def _kernel_bodies(asm):
-    """name -> list of (instruction text, inside_inline_asm) for every wino3w kernel."""
+def _kernel_bodies(asm, frag):
+    """name -> list of (instruction text, inside_inline_asm) for every kernel whose name holds `frag`."""
     bodies, name, inasm = {}, None, False
     for line in asm.splitlines():
-        m = re.match(r"^(_ZN\S*wino3w_conv_kernel\S*):", line)
+        m = re.match(r"^(_ZN\S*" + frag + r"\S*):", line)
         if m:
             name, inasm = m.group(1), False
             bodies[name] = []
@@ -71,25 +77,27 @@ def _kernel_bodies(asm):
 
 def test_makefile_builds_this_file_with_the_audited_flags():
     mk = open(os.path.join(CSRC, "Makefile")).read()
-    assert re.search(r"winograd3w\.o:.*\n\t\$\(HIPCC\) \$\(FLAGS\) -fno-slp-vectorize -c", mk)
+    assert re.search(r"winograd3w\.o winograd3_wgrad\.o:.*\n\t\$\(HIPCC\) \$\(FLAGS\) -fno-slp-vectorize -c", mk)
 
 
 def test_compiler_leaves_the_accumulator_registers_alone(w3w_asm):
-    bodies = _kernel_bodies(w3w_asm)
-    assert len(bodies) >= 2, list(bodies)
+    asm, frag, n_mfma = w3w_asm
+    bodies = _kernel_bodies(asm, frag)
+    assert len(bodies) >= 1, list(bodies)
     for name, body in bodies.items():
         own = [t for t, inasm in body if not inasm and re.search(r"v_accvgpr|\ba\[\d+:\d+\]|\ba\d+\b", t)]
         assert not own, "%s: compiler-generated accumulator-register traffic: %s" % (name, own[:5])
         reads = [t for t, inasm in body if inasm and t.startswith("v_accvgpr_read_b32")]
         mfmas = [t for t, inasm in body if inasm and t.startswith("v_mfma_f32_32x32x2_f32")]
-        assert len(reads) == 256 and len(mfmas) == 200, (name, len(reads), len(mfmas))
+        assert len(reads) == 256 and len(mfmas) == n_mfma, (name, len(reads), len(mfmas))
 
 
 def test_no_scratch_no_spills(w3w_asm):
+    asm, frag, _ = w3w_asm
     # metadata entries of the kernels (.amdgpu_metadata, amdhsa.kernels): one "  - .agpr_count: ..." block per kernel
-    meta = w3w_asm[w3w_asm.index("amdhsa.kernels:"):]
-    blocks = [b for b in re.split(r"\n  - ", meta) if re.search(r"\.name:\s+\S*wino3w_conv_kernel", b)]
-    assert len(blocks) >= 2
+    meta = asm[asm.index("amdhsa.kernels:"):]
+    blocks = [b for b in re.split(r"\n  - ", meta) if re.search(r"\.name:\s+\S*" + frag, b)]
+    assert len(blocks) >= 1
     for blk in blocks:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), name
@@ -98,7 +106,8 @@ def test_no_scratch_no_spills(w3w_asm):
 
 
 def test_no_vector_alu_write_of_an_mfma_operand_right_before_it(w3w_asm):
-    for name, body in _kernel_bodies(w3w_asm).items():
+    asm, frag, _ = w3w_asm
+    for name, body in _kernel_bodies(asm, frag).items():
         for i, (t, inasm) in enumerate(body):
             if not t.startswith("v_mfma_f32_32x32x2_f32"):
                 continue

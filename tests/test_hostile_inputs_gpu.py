@@ -98,6 +98,13 @@ def test_conv3x3_kernels_on_heavy_tailed_maps(name, wino, B, H, Wd, C, N, dil, r
     tens, elem = errors(got, ref)
     print("%s relu=%d: tensor-scale %.2e, element-wise (|ref| > 1e-3 max) %.2e" % (name, relu, tens, elem))
     assert tens <= 1e-4, (name, tens)
+    # History of this bound (r04 review: "do not move a tolerance again without recording the old one and why"): the test
+    # was first written with 1e-3 for every kernel; the Winograd kernels measured 1.9e-3 .. 4.2e-3 on these maps
+    # (profiles/r04_hostile_inputs.txt) and the bound for them was set to 1e-2 in r04.  r05 looked for a cheaper way out
+    # than the policy switch -- other interpolation points for F(4x4,3x3) / F(3x3,3x3) simulated in float32 on these maps
+    # (profiles/r05_winograd_points.txt): best case 0.6x of the current error, not the 4x needed -- so the bound stays, the
+    # header / README say that the default misses an element-wise 1e-3 here by up to ~4x, and the configuration that
+    # keeps it (MPSR_WINOGRAD_OFF, next test) is timed in the bench line (`winograd_off_mode`).
     assert elem <= (1e-2 if name.startswith("winograd") else 1e-3), (name, elem)
 
 
@@ -200,5 +207,7 @@ def test_decoder_chain_on_heavy_tailed_features(policy):
         tens, elem = errors(got, r)
         print("decoder (%s) %s: tensor-scale %.2e, element-wise %.2e" % (policy, name, tens, elem))
         assert tens <= 1e-4, (name, tens)
-        # (five fp32 layers deep the direct kernels alone measure 8.6e-4 here; with F(4x4,3x3) on conv2_2 / conv3_2 1.2e-3)
+        # (five fp32 layers deep the direct kernels alone measure 8.6e-4 here; with F(4x4,3x3) on conv2_2 / conv3_2 1.2e-3:
+        # the "auto" bound was 1e-3 when the test was written, measured 1.23e-3 (profiles/r04_hostile_inputs.txt) and set
+        # to 2e-3 in r04; see the note in test_conv3x3_kernels_on_heavy_tailed_maps)
         assert elem <= (2e-3 if policy == "auto" else 1e-3), (name, elem)
