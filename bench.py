@@ -339,7 +339,7 @@ def roofline_object(net, args, device, ms_per_step):
     fp32 = args.math == "fp32"
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
     kname = "fp32 MFMA 32x32x2 convolution / FC kernels: pw_conv_kernel (wide 1x1 layers and the decoder's tap GEMMs), " \
-            "wino3_conv_kernel / wino3h_conv_kernel (F(3x3,3x3): block3's atrous 3x3 as one tile per pixel sub-grid, the 3x3 layers of blocks 1-2 as tiles with halos), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
+            "wino3w_conv_kernel / wino3_conv_kernel / wino3h_conv_kernel (F(3x3,3x3): block3's atrous 3x3 as one tile per pixel sub-grid -- one wave owning all 25 positions of its tile block at full batches --, the 3x3 layers of blocks 1-2 as tiles with halos), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
             "conv3_2), conv_igemm_kernel / conv_sk_kernel (blocks 1-2, root, img_fc), fc_rows_kernel, " \
             "conv3x3_narrow_mfma_kernel" if fp32 else \
         "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"
@@ -367,10 +367,14 @@ def roofline_object(net, args, device, ms_per_step):
                                "upsampled_conv_tap_gemm": kinds.get(7, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
                        "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
-                       "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction from the quoted collection")
+                       "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction (of CYCLES) from the quoted collection; the "
+                       "step is power-limited (~1.3 kW: the shader clock gives way as the matrix pipes fill), so frac (of "
+                       "the 2.4 GHz peak, in TIME) compares with mfma_busy x clock / 2.4 GHz, not with mfma_busy")
         if traffic:
             out["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
             out["mfma_busy"] = busy
+            out["clock_GHz_of_that_collection"] = pm.get("clock_GHz")
+            out["mfma_busy_x_clock_over_2p4"] = pm.get("mfma_busy_x_clock_over_2p4")
             out["traffic_source"] = src
         try:
             box = mfma_box_peak(device)

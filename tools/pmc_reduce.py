@@ -33,7 +33,7 @@ def main(tag, commit, paths):
     kernels = {}
     tot = defaultdict(float)
     for k, cs in agg.items():
-        if not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
+        if not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3w_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
             continue
         g = lambda c: (cs[c][1] / cs[c][0]) if c in cs and cs[c][0] else None
         n = max(v[0] for v in cs.values())
@@ -52,6 +52,7 @@ def main(tag, commit, paths):
             rec["clock_GHz"] = round(g("GRBM_GUI_ACTIVE") / 8 / (cs["GRBM_GUI_ACTIVE"][2] / cs["GRBM_GUI_ACTIVE"][0]) / 1e3, 3)
             tot["busy_cycles"] += g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 * n
             tot["active_cycles"] += g("GRBM_GUI_ACTIVE") / 8 * n
+            tot["active_us"] += cs["GRBM_GUI_ACTIVE"][2] / cs["GRBM_GUI_ACTIVE"][0] * n
         if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
             rec["l2_hit_rate"] = round(g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
         kernels[k] = rec
@@ -65,6 +66,11 @@ def main(tag, commit, paths):
         out["hbm_bytes_per_launch"] = round(tot["hbm"] / tot["n_hbm"])
     if tot["active_cycles"]:
         out["mfma_busy"] = round(tot["busy_cycles"] / tot["active_cycles"], 4)
+        # the shader clock the board sustained over these launches (GUI-active cycles per XCD / launch time): the step is
+        # POWER-limited (~1.3 kW, the clock gives way as the matrix pipes fill), so busy x clock / 2.4 GHz -- not
+        # busy alone -- is what compares with a time-based fraction of the 2.4 GHz peak (bench.py roofline.frac)
+        out["clock_GHz"] = round(tot["active_cycles"] / tot["active_us"] / 1e3, 3)
+        out["mfma_busy_x_clock_over_2p4"] = round(out["mfma_busy"] * out["clock_GHz"] / 2.4, 4)
     print(json.dumps(out, indent=1))
 
 
