@@ -367,14 +367,13 @@ def roofline_object(net, args, device, ms_per_step):
                                "upsampled_conv_tap_gemm": kinds.get(7, 0)}
         out["note"] = ("achieved / frac = multiply-adds the matrix pipes execute per launch / launch time (/ peak); "
                        "algorithmic_* count the direct-convolution FLOPs of SURVEY 8(d) for the same launches; "
-                       "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES fraction (of CYCLES) from the quoted collection; the "
-                       "step is power-limited (~1.3 kW: the shader clock gives way as the matrix pipes fill), so frac (of "
-                       "the 2.4 GHz peak, in TIME) compares with mfma_busy x clock / 2.4 GHz, not with mfma_busy")
+                       "mfma_busy is the PMC's SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE from the quoted collection -- the latter "
+                       "advances at a fixed ~2.45 GHz, so it is a fraction of TIME at the nominal clock like frac; the step "
+                       "is power-limited (~1.3 kW package power: the shader clock sits near 2.0-2.1 GHz under the dense "
+                       "kernels), which both figures contain")
         if traffic:
             out["traffic_over_algorithmic"] = round(traffic / (alg_bytes / launches), 3)
             out["mfma_busy"] = busy
-            out["clock_GHz_of_that_collection"] = pm.get("clock_GHz")
-            out["mfma_busy_x_clock_over_2p4"] = pm.get("mfma_busy_x_clock_over_2p4")
             out["traffic_source"] = src
         try:
             box = mfma_box_peak(device)

@@ -27,12 +27,8 @@ def test_roofline_frac_agrees_with_the_pmc_busy_fraction():
     r = _line(bench)
     roof = r["roofline"]
     assert roof["bound"] == "mfma" and 0.0 < roof["frac"] <= 1.0
-    # r05: the step is power-limited -- the clock drops as the matrix pipes fill -- so the time-based fraction
-    # of the 2.4 GHz peak compares with busy (a fraction of CYCLES) x clock / 2.4 GHz; collections older than r05 ran
-    # near 2.4 GHz and carry no clock figure.  The profiled collection runs at lower clocks than the unprofiled line
-    # (MI355X_MICROARCH.md, DVFS), hence the wider band.
-    want = pmc.get("mfma_busy_x_clock_over_2p4", pmc["mfma_busy"])
-    assert abs(roof["frac"] - want) <= 0.04, (roof["frac"], want, pmc["mfma_busy"])
+    # (both are fractions of TIME at the nominal clock: GRBM_GUI_ACTIVE advances at a fixed ~2.45 GHz -- tools/pmc_reduce.py)
+    assert abs(roof["frac"] - pmc["mfma_busy"]) <= 0.02, (roof["frac"], pmc["mfma_busy"])
     assert roof["kernel_ms_per_step"] <= r["ms_per_step"]
     assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
     # the kernels the line names are the kernels the PMC collection saw

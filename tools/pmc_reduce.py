@@ -66,11 +66,13 @@ def main(tag, commit, paths):
         out["hbm_bytes_per_launch"] = round(tot["hbm"] / tot["n_hbm"])
     if tot["active_cycles"]:
         out["mfma_busy"] = round(tot["busy_cycles"] / tot["active_cycles"], 4)
-        # the shader clock the board sustained over these launches (GUI-active cycles per XCD / launch time): the step is
-        # POWER-limited (~1.3 kW, the clock gives way as the matrix pipes fill), so busy x clock / 2.4 GHz -- not
-        # busy alone -- is what compares with a time-based fraction of the 2.4 GHz peak (bench.py roofline.frac)
-        out["clock_GHz"] = round(tot["active_cycles"] / tot["active_us"] / 1e3, 3)
-        out["mfma_busy_x_clock_over_2p4"] = round(out["mfma_busy"] * out["clock_GHz"] / 2.4, 4)
+        # NOTE on units: GRBM_GUI_ACTIVE advances at a fixed ~2.45 GHz on these boards whatever the shader clock does
+        # (every long kernel of every collection gives GUI_ACTIVE / 8 / duration = 2.41-2.46 GHz), while
+        # SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles: mfma_busy is therefore a fraction of TIME at the nominal clock
+        # -- it already contains the clock the power limit takes away -- and compares directly with bench.py's
+        # roofline.frac.  The fraction of a wave's own CYCLES spent issuing MFMAs comes from the kernels' cycle stamps
+        # (tools/wino3w_trace.py: 0.86 for the wave-owned F(3x3,3x3) kernel at 0.73 here).
+        out["gui_active_GHz"] = round(tot["active_cycles"] / tot["active_us"] / 1e3, 3)
     print(json.dumps(out, indent=1))
 
 

@@ -33,10 +33,19 @@ def main():
     ws = torch.empty((nws,), device=dev)
     lib.mpsr_debug_set_conv_winograd(3)
     lib.mpsr_debug_set_wino3_form(1)
-    for _ in range(3):
+    def run():
         _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, H, C, w.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
                                             N, 3, 3, dil, 1, 0, ws.data_ptr(), nws, _lib.stream()))
+    for _ in range(3):
+        run()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) * 1e3 / 20
     n = 8 * 4 * 40
     buf = (ctypes.c_ulonglong * n)()
     fn = lib.mpsr_debug_wino3w_trace
@@ -44,6 +53,13 @@ def main():
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert fn(buf, n) == 0
     print("matrix pipe per K step: 6400 cycles; per wave and launch: %d" % (6400 * (C // 8)))
+    life = [buf[(b * 4 + v) * 40 + 35] - buf[(b * 4 + v) * 40] for b in range(8) for v in range(4)
+            if buf[(b * 4 + v) * 40 + 35]]
+    if life:
+        med = sorted(life)[len(life) // 2]
+        print("launch %.1f us (back to back, events); a wave lives %d shader cycles (s_memtime) -> shader clock >= %.2f GHz "
+              "under this kernel; MFMA issue share of a wave's cycles %.3f, of the launch's time at 2.4 GHz %.3f" % (
+                  launch_us, med, med / launch_us / 1e3, 6400.0 * (C // 8) / med, 6400.0 * (C // 8) / (launch_us * 2400.0)))
     for blk in range(8):
         for wv in range(4):
             t = buf[(blk * 4 + wv) * 40:(blk * 4 + wv + 1) * 40]
