@@ -45,6 +45,7 @@ constexpr int cF(int p) { return p < 21 ? p % 3 : p - 21; }  // ring colour of p
 struct W3gParams {
     const float *x, *dy;
     float *dw;  // (N, 9 C): accumulated into
+    float *db;  // (N) or nullptr: the bias gradient, accumulated into (column sums of dY)
     int H, W, C, N, dil, T;
     int nblocks, cblocks, nslices, steps;  // steps: K steps (of 4 tiles) per slice, even
     FastDiv div_tpi, div_d;
@@ -156,6 +157,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                     rdy, voy, (unsigned)((d * i * p.W + d * j) * p.N) * 4u, 0));
     };
     float pa[25];  // the 5x5 transformed block being built (one at a time)
+    // the bias gradient rides along: position (1, 1) of A dY A^T is the SUM of the tile's nine dY values (row 1 of A is
+    // (1, 1, 1)), so a dY-side thread adds that one register per step; only the workgroups of the first c block do
+    float bsum = 0.f;
+    const bool want_db = p.db != nullptr && c0 == 0;
     // [stage][operand][position][row][slot of the tile: tiles 0, 2, 1, 3]
     float *wr = lds + pr * KT + ((lt & 1) * 2 + (lt >> 1));
     auto store = [&](int stage, auto opc, int pos) __attribute__((always_inline)) {
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pa[5 * i + 2] = t2_;
                 pa[5 * i + 3] = t3_;
                 pa[5 * i + 4] = t4_;
+                if constexpr (op == 0 && i == 1) bsum += t1_;
             }
             if constexpr (o >= 4 && o < 14) {
                 constexpr int i = (o - 4) / 2;
@@ -266,6 +272,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  : "+v"(accV[0]), "+v"(accV[1]), "+v"(accV[2]), "+v"(accV[3]), "+v"(accV[4]), "+v"(accV[5]), "+v"(accV[6]),
                    "+v"(accV[7]), "+v"(accV[8]), "+v"(lane2));
 
+    // ---- bias gradient: the four tile-lanes of a row (lane, lane + 16, + 32, + 48) meet in the first, one atomic per row
+    if (want_db) {  // block-uniform
+        float b = bsum;
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if ((lane2 >> 4) == 0 && n0 + pr < p.N) unsafeAtomicAdd(&p.db[n0 + pr], b);
+    }
+
     // ---- epilogue, lane-local: accumulator element e of every position belongs to row n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     // of the wave's block and column c = lane & 31, so the fold back to the 3x3 filter, G'^T dU G' (G' = the forward's
     // row-scaled G: wino3_filter.h), is register arithmetic on the lane's own 25 values -- and the 9 results go straight
@@ -325,12 +339,12 @@ bool winograd3_wgrad_applies(int B, int H, int W, int C, int N, int KH, int KW, 
 }
 // (no scratch: the kernel accumulates into dw directly)
 int conv3x3_wgrad_winograd3(const float *x, const float *dy, int B, int H, int W, int C, int N, int dilation, float *dw,
-                            hipStream_t s)
+                            float *db, hipStream_t s)
 {
     using namespace w3g;
     MPSR_REQUIRE(winograd3_wgrad_applies(B, H, W, C, N, 3, 3, dilation), "conv3x3_wgrad_winograd3: unsupported shape");
     W3gParams p;
-    p.x = x; p.dy = dy; p.dw = dw;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;
     p.T = B * dilation * dilation;
     p.nblocks = N / 64; p.cblocks = C / 64;

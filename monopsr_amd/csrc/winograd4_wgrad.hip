@@ -324,7 +324,7 @@ int conv3x3_wgrad_winograd4(const float *x, const float *dy, int B, int H, int W
 namespace mpsr {  // winograd3_wgrad.hip: the atrous layers whose pixel sub-grids are single 3x3 tiles (block3's conv2)
 bool winograd3_wgrad_applies(int B, int H, int W, int C, int N, int KH, int KW, int dilation);
 int conv3x3_wgrad_winograd3(const float *x, const float *dy, int B, int H, int W, int C, int N, int dilation, float *dw,
-                            hipStream_t s);
+                            float *db, hipStream_t s);
 }  // namespace mpsr
 
 static int g_wgrad_winograd = 1;  // mpsr_debug_set_wgrad_winograd
@@ -347,9 +347,8 @@ extern "C" int mpsr_conv2d_wgrad_ws_f32(const float *x, const float *dy, int B, 
     }
     // (the F(3x3,3x3) form of block3's atrous layers needs no scratch: it accumulates into dw itself)
     if (g_wgrad_winograd && B > 0 && x && dy && dw && mpsr::winograd3_wgrad_applies(B, H, W, C, N, KH, KW, dilation)) {
-        int rc = mpsr::conv3x3_wgrad_winograd3(x, dy, B, H, W, C, N, dilation, dw, mpsr::as_stream(stream));
-        if (rc) return rc;
-        return db ? mpsr_bias_grad(dy, (long long)B * H * W, N, db, stream) : MPSR_OK;
+        // (the bias gradient rides along: position (1, 1) of A dY A^T is the tile's dY sum)
+        return mpsr::conv3x3_wgrad_winograd3(x, dy, B, H, W, C, N, dilation, dw, db, mpsr::as_stream(stream));
     }
     return mpsr_conv2d_wgrad_f32(x, dy, B, H, W, C, N, KH, KW, dilation, dw, db, stream);
 }

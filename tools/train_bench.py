@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--full-image", action="store_true",
                     help="train BOTH trunks from a raw 375x1242 image + `--batch` boxes (the reference's step shape at "
                          "--batch 32) instead of the crop trunk over a precomputed full-image feature crop")
+    ap.add_argument("--wgrad-winograd", type=int, default=1, choices=[0, 1],
+                    help="A/B: 0 = every weight gradient on the direct kernel (mpsr_debug_set_wgrad_winograd), 1 = the "
+                         "decoder's dense 3x3 layers in the F(4x4,3x3) domain and block3's atrous layers in F(3x3,3x3)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
     args = ap.parse_args()
@@ -55,6 +58,7 @@ def main():
     cfg = config_utils.default_config()
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
+    _lib.lib().mpsr_debug_set_wgrad_winograd(args.wgrad_winograd)
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn)
