@@ -8,10 +8,12 @@
  * images/activations NHWC.
  *
  * Threads: every entry point may be called from any number of threads at once (on different streams, with different
- * scratch); the library keeps no per-call state and the last-error string is thread-local.  The one piece of
- * process-wide configuration is the contraction arithmetic (mpsr_set_conv_math): it is an atomic setting read at every
- * launch, so changing it while another thread is in the middle of a network entry point gives that pass a mix of both
- * arithmetics -- set it before starting work, as bench.py and the tests do.
+ * scratch); the library keeps no per-call state and the last-error string is thread-local.  The contraction arithmetic
+ * and the Winograd policy are OPTIONS OF A CALL since ABI 5 (mpsr_net_opts.math / .winograd_policy, mpsr_conv_opts):
+ * they hold for the duration of that entry point on the calling thread only, so concurrent callers with different
+ * options do not see each other (the reference's launchers are stateless: tf_nndistance.cpp:168).  mpsr_set_conv_math /
+ * mpsr_set_winograd_policy set the process-wide DEFAULTS that calls without options inherit -- atomics read at every
+ * launch: change them before starting work, not while another thread is inside an entry point that relies on them.
  *
  * Each declaration cites the reference interface it replaces (paths under /root/reference/src).
  * The first five keep the argument order of the reference's launcher functions so the reference's TF op
@@ -208,7 +210,8 @@ int mpsr_get_conv_math(void);
  *                      decoder end to end on such features (100x outliers): 1.2e-3, where fp32 arithmetic without any
  *                      Winograd kernel measures 8.6e-4.
  *   MPSR_WINOGRAD_OFF  direct / implicit-GEMM kernels everywhere (the upsampled convolutions keep their exact tap
- *                      GEMM): element-wise 1e-4 on the same inputs, at ~1.4x the step time.  For callers whose
+ *                      GEMM): element-wise 5e-5 .. 1e-4 on the same inputs, at 1.28x the step time (18.2 vs 14.2 ms:
+ *                      bench.py's `winograd_off_mode` object times it and measures both policies' errors).  For callers whose
  *                      activations are heavy-tailed AND who read small outputs individually. */
 enum { MPSR_WINOGRAD_AUTO = 0, MPSR_WINOGRAD_OFF = 1 };
 int mpsr_set_winograd_policy(int policy);
