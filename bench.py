@@ -304,7 +304,8 @@ def mfma_box_peak(device):
 def roofline_object(net, args, device, ms_per_step):
     """The dominant kernel family alone: every conv/FC launch of one step, timed with events on the launch stream.
     `achieved` / `frac` are what the matrix pipes EXECUTE (mpsr_conv2d_plan: the Winograd launches issue 16/36 --
-    36/144 for F(4x4,3x3), 25/81 for F(3x3,3x3) on block3's atrous sub-grids -- of their direct-convolution products and
+    36/144 for F(4x4,3x3), 16/81 for block3's atrous sub-grids as zero-padded tiles, 25/81 for F(3x3,3x3) with halos -- of
+    their direct-convolution products and
     the other atrous layers skip out-of-image taps), so
     0 < frac <= 1 and it is comparable with the PMC's MFMA-busy fraction; the ALGORITHMIC direct-convolution rate of
     SURVEY 8(d) (12.393 GFLOP per crop) is next to it as algorithmic_achieved / algorithmic_frac and may exceed 1."""
@@ -339,7 +340,7 @@ def roofline_object(net, args, device, ms_per_step):
     fp32 = args.math == "fp32"
     peak = PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
     kname = "fp32 MFMA 32x32x2 convolution / FC kernels: pw_conv_kernel (wide 1x1 layers and the decoder's tap GEMMs), " \
-            "wino3w_conv_kernel / wino3_conv_kernel / wino3h_conv_kernel (F(3x3,3x3): block3's atrous 3x3 as one tile per pixel sub-grid -- one wave owning all 25 positions of its tile block at full batches --, the 3x3 layers of blocks 1-2 as tiles with halos), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
+            "wino3z_conv_kernel (block3's atrous 3x3 layers: every 3x3 pixel sub-grid as ONE zero-padded tile in sixteen products, one wave owning all 16 positions of its tile block), wino3h_conv_kernel (F(3x3,3x3) on tiles with halos: the 3x3 layers of blocks 1-2), wino4_conv_kernel (F(4x4,3x3), decoder conv2_2 / " \
             "conv3_2), conv_igemm_kernel / conv_sk_kernel (blocks 1-2, root, img_fc), fc_rows_kernel, " \
             "conv3x3_narrow_mfma_kernel" if fp32 else \
         "conv_igemm_kernel (3x bf16 MFMA 32x32x16 per fp32 product; achieved counts each product once)"

@@ -19,6 +19,7 @@ int conv3x3_winograd4(const float *x, int B, int H, int W, int C, const float *w
                       size_t part_floats);
 size_t winograd4_split_floats(int B, int H, int W, int N);
 extern std::atomic<int> g_wino4_split;
+int winograd3_filter_form(int B, int H, int W, int C, int N, int dilation);  // winograd3.hip
 bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int split_k, const float *ws,
                             size_t ws_floats);
 bool conv2d_takes_pointwise(long long M, int C, int N, int KH, int KW, int split_k);
@@ -244,7 +245,8 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
             // (with a VALID filter cache there is nothing to transform; with one being filled the job writes the slice)
             float *uslice = cache.take(c2);
             const int c2i = (int)(&c2 - layers);
-            const bool cached_u = uslice && cache.valid && (!cache.tags || cache.tags[c2i] == mpsr::FILTER_FORM_WINO3);
+            const int fform = mpsr::winograd3_filter_form(B, d.PH, d.PW, c2.cin, c2.cout, c2.dilation);
+            const bool cached_u = uslice && cache.valid && (!cache.tags || cache.tags[c2i] == fform);
             if (!cached_u &&
                 mpsr::conv2d_takes_pointwise((long long)B * d.PH * d.PW, c1.cin, c1.cout, 1, 1, 0) &&
                 mpsr::conv2d_takes_winograd3(B, d.PH, d.PW, c2.cin, c2.cout, c2.kh, c2.kw, c2.dilation, 0, sk, skn)) {
@@ -252,6 +254,7 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
                 mpsr::g_filter_tail_job.u = uslice ? uslice : sk;
                 mpsr::g_filter_tail_job.N = c2.cout;
                 mpsr::g_filter_tail_job.C = c2.cin;
+                mpsr::g_filter_tail_job.form = fform == mpsr::FILTER_FORM_WINO3Z ? 1 : 0;
             }
             if ((rc = run_layer(blob, c1, cur, B, d.PH, d.PW, nullptr, t1, 0, sk, skn, s))) return rc;
             mpsr::g_filter_tail_job = mpsr::FilterTailJob();  // (not taken: conv2 transforms its filters itself)

@@ -84,7 +84,7 @@ struct PwsParams {
     // tail job: the F(3x3,3x3) filter transform of the 3x3 layer that follows (wino3_filter.h), shared by all workgroups
     const float *fw;
     float *fu;
-    int fN, fC;
+    int fN, fC, fform;  // fform 0: F(3x3,3x3) filters (25 positions), 1: the sixteen-product form
     // MASK instantiations (training, data-gradient launches): a bit of mask[(row >> 5) * N + column] says whether the
     // output element is kept or written as zero -- the ReLU mask of the tensor this gradient belongs to, applied in the
     // store path instead of by an elementwise pass over the result.  Bit b of a word <-> row 32 g + (b & 3) +
@@ -486,7 +486,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.fw) {  // block-uniform
         const long long total = (long long)p.fN * p.fC;
         for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256)
-            mpsr::wino3_filter_one(p.fw, p.fN, p.fC, p.fu, i);
+            if (p.fform) mpsr::wino3z_filter_one(p.fw, p.fN, p.fC, p.fu, i);
+            else mpsr::wino3_filter_one(p.fw, p.fN, p.fC, p.fu, i);
     }
 #ifdef PWS_TRACE
     if (p.trace && lane == 0) {
@@ -668,6 +669,7 @@ static int pointwise_launch(const float *x, long long M, int K, const float *w, 
     p.trace = g_pw_trace;
     // a pending filter-transform job rides on this launch
     p.fw = g_filter_tail_job.w; p.fu = g_filter_tail_job.u; p.fN = g_filter_tail_job.N; p.fC = g_filter_tail_job.C;
+    p.fform = g_filter_tail_job.form;
     if (p.fw) g_filter_tail_done = g_filter_tail_job;
     g_filter_tail_job = FilterTailJob();
     const size_t lds_bytes = (size_t)LDS_B;

@@ -44,12 +44,51 @@ __device__ __forceinline__ void wino3_filter_one(const float *__restrict__ w, in
     }
 }
 
+// The same for the sixteen-product form of a zero-padded 3x3 tile (wino3_transforms.h, winograd3z.hip):
+// U[cb][pos][n][8] = (G g G^T)[pos], pos = 4 u + v, G = [-1/4 1/8 1/4; 1/4 1/8 -1/4; 1/6 1/4 1/6; -1/6 1/4 -1/6].
+namespace f3z {
+constexpr int KC = 8, NP = 16;
+}
+__device__ __forceinline__ void wino3z_filter_one(const float *__restrict__ w, int N, int C, float *__restrict__ u, long long i)
+{
+    const int n = (int)(i / C), c = (int)(i - (long long)n * C);
+    double g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(size_t)n * 9 * C + (size_t)(ky * 3 + kx) * C + c];
+    auto gcol = [](double a, double b, double c2, double *o) {  // G (4x3) applied to one 3-vector (a, b, c2) = (g0, g1, g2)
+        const double u = (c2 - a) / 4.0, s = (a + c2) / 6.0;
+        o[0] = b / 8.0 + u;
+        o[1] = b / 8.0 - u;
+        o[2] = b / 4.0 + s;
+        o[3] = b / 4.0 - s;
+    };
+    double t[4][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        double o[4];
+        gcol(g[0][kx], g[1][kx], g[2][kx], o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r][kx] = o[r];
+    }
+    float *dst = u + ((size_t)(c / f3z::KC) * f3z::NP * N + n) * f3z::KC + (c % f3z::KC);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double o[4];
+        gcol(t[r][0], t[r][1], t[r][2], o);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[(size_t)(r * 4 + s) * N * f3z::KC] = (float)o[s];
+    }
+}
+
 // A filter-transform job handed from a network-level entry point (network.hip) to the next pointwise launch on this
 // thread, and the note that it was done, for conv3x3_winograd3 to find.
 struct FilterTailJob {
     const float *w = nullptr;
     float *u = nullptr;
     int N = 0, C = 0;
+    int form = 0;  // 0: F(3x3,3x3), 25 positions (wino3_filter_one); 1: the sixteen-product form (wino3z_filter_one)
 };
 extern thread_local FilterTailJob g_filter_tail_job;    // pending: consumed by conv1x1_pointwise
 extern thread_local FilterTailJob g_filter_tail_done;   // done by the last pointwise launch: consumed by conv3x3_winograd3
@@ -72,6 +111,6 @@ struct FilterCacheSlot {
         return ok;
     }
 };
-enum { FILTER_FORM_WINO4 = 1, FILTER_FORM_WINO3 = 2, FILTER_FORM_UPCONV = 3 };
+enum { FILTER_FORM_WINO4 = 1, FILTER_FORM_WINO3 = 2, FILTER_FORM_UPCONV = 3, FILTER_FORM_WINO3Z = 4 };
 extern thread_local FilterCacheSlot g_filter_cache_slot;
 }  // namespace mpsr

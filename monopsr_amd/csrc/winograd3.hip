@@ -431,8 +431,32 @@ bool winograd3w_applies(int B, int H, int W, int C, int N, int dilation);
 long long winograd3w_workgroups(int B, int N, int dilation);
 int launch_winograd3w(const float *x, int B, int H, int W, int C, const float *u, const float *bias, int relu, float *y,
                       int N, int dilation, hipStream_t s, const float *mask);
-// mpsr_debug_set_wino3_form: -1 = by size, 0 = positions shared by eight waves (this file), 1 = one wave per tile block
+// winograd3z.hip: the same layer in SIXTEEN products per tile (a one-tile sub-grid reads nothing outside itself: rank 4 per
+// dimension instead of F(3,3)'s 5), one wave owning all 16 positions of its tile block
+int launch_winograd3z(const float *x, int B, int H, int W, int C, const float *u, const float *bias, int relu, float *y,
+                      int N, int dilation, hipStream_t s, const float *mask);
+int launch_winograd3z_filter(const float *w, int N, int C, float *u, hipStream_t s);
+// mpsr_debug_set_wino3_form: -1 = by size, 0 = F(3x3,3x3) with positions shared by eight waves (this file), 1 = F(3x3,3x3)
+// with one wave per tile block (winograd3w.hip), 2 = the sixteen-product form (winograd3z.hip)
 std::atomic<int> g_wino3_form{-1};
+
+// which kernel serves a layer that conv3x3_winograd3 takes: 0 / 1 / 2 as above.  One tile per sub-grid: the sixteen-product
+// form at EVERY batch size -- fewer products and the error of a direct convolution; below ~190 workgroups (B < 192 at
+// dilation 4) its one-wave-per-SIMD workgroups do not fill the chip and it is 5-7 us behind this file's kernel (76 vs 71
+// us per launch at B = 64), which is the price of one algorithm, one error bound, whatever the batch.  Tiles with halos
+// (th > 1) have real neighbours: this file's kernels.
+int winograd3_form(int B, int H, int W, int C, int N, int dilation)
+{
+    const int th = H / (3 * dilation);
+    if (th != 1 || !winograd3w_applies(B, H, W, C, N, dilation)) return 0;
+    const int form = g_wino3_form.load();
+    return (form >= 0 && form <= 2) ? form : 2;
+}
+// ... and the form of the transformed filters that kernel reads (FILTER_FORM_*: the filter cache's tags, the tail job)
+int winograd3_filter_form(int B, int H, int W, int C, int N, int dilation)
+{
+    return winograd3_form(B, H, W, C, N, dilation) == 2 ? FILTER_FORM_WINO3Z : FILTER_FORM_WINO3;
+}
 
 thread_local FilterTailJob g_filter_tail_job;
 thread_local FilterTailJob g_filter_tail_done;
@@ -456,7 +480,8 @@ long long winograd3_tiles(int B, int H, int dilation)
 }
 double winograd3_executed_flops(int B, int H, int C, int N, int dilation)
 {
-    return 2.0 * (double)winograd3_tiles(B, H, dilation) * 25.0 * C * N;
+    const double products = winograd3_form(B, H, H, C, N, dilation) == 2 ? 16.0 : 25.0;
+    return 2.0 * (double)winograd3_tiles(B, H, dilation) * products * C * N;
 }
 
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
@@ -474,30 +499,33 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     const int th = H / (3 * dilation);
     const void *kern = th > 1 ? reinterpret_cast<const void *>(wino3h_conv_kernel) : reinterpret_cast<const void *>(wino3_conv_kernel);
     MPSR_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSF * sizeof(float))));
+    const int form = winograd3_form(B, H, W, C, N, dilation);
+    const int fform = form == 2 ? FILTER_FORM_WINO3Z : FILTER_FORM_WINO3;
     // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer
     float *u = ws;
     bool ready = false;
     if (g_filter_cache_slot.w == w && g_filter_cache_slot.u && g_filter_cache_slot.floats >= winograd3_scratch_floats(C, N)) {
         u = g_filter_cache_slot.u;
-        ready = g_filter_cache_slot.holds(FILTER_FORM_WINO3);
+        ready = g_filter_cache_slot.holds(fform);
     }
     g_filter_cache_slot = FilterCacheSlot();
     // (or the filters were transformed into `u` by the tail job of the preceding pointwise launch)
     ready = ready || (g_filter_tail_done.w == w && g_filter_tail_done.u == u && g_filter_tail_done.N == N &&
-                      g_filter_tail_done.C == C);
+                      g_filter_tail_done.C == C && g_filter_tail_done.form == (form == 2 ? 1 : 0));
     g_filter_tail_done = FilterTailJob();
     if (!ready) {
-        const long long total = (long long)N * C;
-        hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
-        MPSR_CHECK_LAUNCH("wino3_filter_kernel");
+        if (form == 2) {
+            if (int rc = launch_winograd3z_filter(w, N, C, u, s)) return rc;
+        } else {
+            const long long total = (long long)N * C;
+            hipLaunchKernelGGL(wino3_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
+            MPSR_CHECK_LAUNCH("wino3_filter_kernel");
+        }
     }
-    // one tile per sub-grid and enough of them to give every CU a workgroup of four 400-accumulator waves: the form without
-    // the epilogue exchange (winograd3w.hip); identical bits either way
-    if (th == 1 && winograd3w_applies(B, H, W, C, N, dilation)) {
-        const int form = g_wino3_form.load();
-        if (form == 1 || (form < 0 && winograd3w_workgroups(B, N, dilation) >= 192))
-            return launch_winograd3w(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
-    }
+    // one tile per sub-grid and enough of them to give every CU a workgroup of four one-per-SIMD waves: the forms without
+    // the epilogue exchange (winograd3z.hip: sixteen products; winograd3w.hip: F(3x3,3x3), identical bits to this file's)
+    if (form == 2) return launch_winograd3z(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
+    if (form == 1) return launch_winograd3w(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
     Wino3Params p;
     p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.dil = dilation;

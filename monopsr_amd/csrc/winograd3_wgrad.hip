@@ -1,21 +1,23 @@
 // Weight gradient of the atrous 3x3 layers whose pixel sub-grids are single 3x3 tiles (ResNet-101 block3's conv2 at output
 // stride 4: 12x12 maps at dilation 4, 23 layers per training step; reference: TensorFlow autodiff of
-// object_detection/nets/resnet_v1.py:116-127 under monopsr/core/trainer.py:71-81) in the Winograd F(3x3,3x3) domain.
+// object_detection/nets/resnet_v1.py:116-127 under monopsr/core/trainer.py:71-81) in the transform domain of the
+// SIXTEEN-product form of a zero-padded tile (wino3_transforms.h; forward: winograd3z.hip).
 //
-//   forward    Y (3x3) = A^T [ sum_c (G' g G'^T) (.) (B'^T d B') ] A          (winograd3.hip / winograd3w.hip; ' = row-scaled)
-//   gradient   dg = G'^T [ sum over tiles of (A dY A^T) (.) (B'^T d B') ] G'
-// i.e. per element position p (25 of them) one GEMM over the tiles t (one tile per pixel sub-grid: B x dilation^2 of them)
-//   dU_p[n][c] = sum_t Yh_p[t][n] * V_p[t][c],        Yh = A dY A^T (3x3 -> 5x5),  V = B'^T d B' (the forward's transform)
-// 25 products per (channel pair, tile) where the border-class direct weight gradient (backward.hip) executes 49: half the
-// matrix work of 23 x 237 us of the training step.  Both operands are transformed on the fly, neither reaches HBM; the
-// fold back G'^T dU G' is lane-local (below) and the tile slices meet in dw itself through fp32 atomics.
+//   forward    Y (3x3) = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A                (4x4 element positions)
+//   gradient   dg = G^T [ sum over tiles of (A dY A^T) (.) (B^T d B) ] G
+// i.e. per element position p (16 of them) one GEMM over the tiles t (one tile per pixel sub-grid: B x dilation^2 of them)
+//   dU_p[n][c] = sum_t Yh_p[t][n] * V_p[t][c],        Yh = A dY A^T (3x3 -> 4x4),  V = B^T d B (the forward's transform)
+// 16 products per (channel pair, tile) where the border-class direct weight gradient (backward.hip) executes 49: a third
+// of the matrix work of 23 x 237-258 us of the training step.  Both operands are transformed on the fly, neither reaches
+// HBM; the fold back G^T dU G is lane-local (below) and the tile slices meet in dw itself through fp32 atomics.
 //
-// Kernel form = winograd3w.hip's: ONE WAVE OWNS ALL 25 POSITIONS of a 32 (n) x 32 (c) block -- 400 accumulator registers,
-// 16 positions under literal names in the accumulator half of the register file, one wave per SIMD -- so a workgroup (4
-// waves = 64 n x 64 c) transforms each operand patch ONCE for two blocks: 2 patches per thread and K step of 4 tiles for 50
-// MFMAs per wave (an eight-wave 32 x 32 form as winograd4_wgrad.hip's pays 2 patches per 25).  Operands in LDS as
-// [stage][Yh | V][position][row][4 tiles], the tiles of a row ordered (0, 2, 1, 3): lane (row, k half h) reads the 8 bytes
-// at 8 h = its k of both MFMAs of the step; double buffered (2 x 51 KB), one barrier per step.
+// Kernel form = winograd3z.hip's: ONE WAVE OWNS ALL 16 POSITIONS of a 32 (n) x 32 (c) block -- 256 accumulator registers
+// under literal names in the accumulator half of the register file, one wave per SIMD -- so a workgroup (4 waves = 64 n x
+// 64 c) transforms each operand patch ONCE for two blocks: 2 patches per thread and K step of 4 tiles for 32 MFMAs per
+// wave.  Operands in LDS as [stage][Yh | V][position][row][4 tiles], the tiles of a row ordered (0, 2, 1, 3): lane (row,
+// k half h) reads the 8 bytes at 8 h = its k of both MFMAs of the step; double buffered, one barrier per step.  The patches
+// of the step after next are requested in the first slots of a step into the OTHER of two register sets: a full step of
+// lead (the vector half of the register file is nearly empty here).
 #include <type_traits>
 #include <utility>
 
@@ -30,16 +32,17 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using mpsr::FastDiv;
 using mpsr::fdiv;
-using mpsr::w3t::bt5;
+using mpsr::w3t::a4z;
+using mpsr::w3t::bt4z;
 
 namespace w3g {
-constexpr int KT = 4, NP = 25;
+constexpr int KT = 4, NP = 16;
 constexpr int POSF = 64 * KT;        // floats per position of one operand (64 rows x 4 tiles)
-constexpr int OPF = NP * POSF;       // one operand of a stage (6400 floats = 25.6 KB)
+constexpr int OPF = NP * POSF;       // one operand of a stage (4096 floats = 16 KB)
 constexpr int STAGEF = 2 * OPF;      // Yh then V
-constexpr int LDSF = 2 * STAGEF;     // 25600 floats = 102.4 KB
+constexpr int LDSF = 2 * STAGEF;     // 16384 floats = 64 KB
 constexpr unsigned OOB = 0x80000000u;
-constexpr int cF(int p) { return p < 21 ? p % 3 : p - 21; }  // ring colour of position p's fragments (4 pairs)
+constexpr int cF(int p) { return p < 12 ? p % 3 : p - 12; }  // ring colour of position p's fragments (4 pairs)
 }  // namespace w3g
 
 struct W3gParams {
@@ -70,7 +73,6 @@ __device__ __forceinline__ void static_for(F &&f)
 #define W3G_MFMA_A(q, a, b)                                                                                 \
     asm volatile("v_mfma_f32_32x32x2_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(16 * (q)), \
                  "i"(16 * (q) + 15))
-#define W3G_MFMA_V(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define W3G_ZERO16(b)                                                                                                     \
     asm volatile("v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\t"          \
                  "v_accvgpr_write_b32 a%c3, 0\n\tv_accvgpr_write_b32 a%c4, 0\n\tv_accvgpr_write_b32 a%c5, 0\n\t"          \
@@ -100,17 +102,6 @@ __device__ __forceinline__ void static_for(F &&f)
     "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
     "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
 
-// A (5x3, the transpose of the forward's A^T) applied to a 3-vector: 5 operations
-__device__ __forceinline__ void a5(float d0, float d1, float d2, float &o0, float &o1, float &o2, float &o3, float &o4)
-{
-    const float e = d0 + d2;
-    o0 = d0;
-    o1 = e + d1;
-    o2 = e - d1;
-    o3 = fmaf(2.f, d1, fmaf(4.f, d2, d0));
-    o4 = d2;
-}
-
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino3_wgrad_kernel(const W3gParams p)
 {
     using namespace w3g;
@@ -133,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lt = lane >> 4, pr = 16 * wave + (lane & 15);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, (int)p.dybytes, 0x00020000);
-    float rawy[9], rawx[9];  // column by column: raw[3 j + i] = sub-grid pixel (row i, column j)
+    float rawy[2][9], rawx[2][9];  // [step parity][3 j + i] = sub-grid pixel (row i, column j) of the step's dY block / x patch
     // byte offsets of this thread's dY block / x patch of K step `step` (out of range past the slice's last step or the last
     // tile: zeros), computed once per step; then the nine requests of each
     unsigned voy = 0, vox = 0;
@@ -146,19 +137,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         voy = in ? (unsigned)(pix * p.N + n0 + pr) * 4u : OOB;
         vox = in ? (unsigned)(pix * p.C + c0 + pr) * 4u : OOB;
     };
-    auto request = [&](auto Lc, auto xc) __attribute__((always_inline)) {
-        constexpr int L = decltype(Lc)::value, j = L / 3, i = L % 3;
+    auto request = [&](auto setc, auto Lc, auto xc) __attribute__((always_inline)) {
+        constexpr int set = decltype(setc)::value, L = decltype(Lc)::value, j = L / 3, i = L % 3;
         constexpr bool X = decltype(xc)::value != 0;
         if constexpr (X)
-            rawx[L] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                    rx, vox, (unsigned)((d * i * p.W + d * j) * p.C) * 4u, 0));
+            rawx[set][L] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         rx, vox, (unsigned)((d * i * p.W + d * j) * p.C) * 4u, 0));
         else
-            rawy[L] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                    rdy, voy, (unsigned)((d * i * p.W + d * j) * p.N) * 4u, 0));
+            rawy[set][L] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         rdy, voy, (unsigned)((d * i * p.W + d * j) * p.N) * 4u, 0));
     };
-    float pa[25];  // the 5x5 transformed block being built (one at a time)
-    // the bias gradient rides along: position (1, 1) of A dY A^T is the SUM of the tile's nine dY values (row 1 of A is
-    // (1, 1, 1)), so a dY-side thread adds that one register per step; only the workgroups of the first c block do
+    float pa[16];  // the 4x4 transformed block being built (one at a time): pa[4 u + v]
+    // the bias gradient rides along: sum of the tile's nine dY values = w^T (A dY A^T) w with w = (0, 0, 5/6, -1/6) (rows 2, 3
+    // of A are S +- 3/2 d1: (o2 - o3) / 2 + (o2 + o3) / 3 = d0 + d1 + d2); only the workgroups of the first c block add it
     float bsum = 0.f;
     const bool want_db = p.db != nullptr && c0 == 0;
     // [stage][operand][position][row][slot of the tile: tiles 0, 2, 1, 3]
@@ -167,43 +158,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int op = decltype(opc)::value;
         wr[stage * STAGEF + op * OPF + pos * POSF] = pa[pos];
     };
-    // duties of slot m of a K step: the dY block in slots 0..13, the x patch in 14..27 (3 columns, then a row every other
-    // slot with its five stores behind it), the 18 requests of the step after next from slot 28 on
+    // duties of slot m of a K step whose stage is `st` (= the step's parity): the dY block of the NEXT step (register set
+    // st ^ 1) in slots 0..11, its x patch in 12..23 (3 columns, then a row every other slot with its four stores behind it),
+    // both into stage st ^ 1; the 18 requests of the step after next into register set st, one per slot from slot 0 on
     auto duty = [&](int s, auto stc, auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value, nst = decltype(stc)::value ^ 1;
+        constexpr int m = decltype(mc)::value, st = decltype(stc)::value, nst = st ^ 1;
         static_for<2>([&](auto opc) __attribute__((always_inline)) {
-            constexpr int op = decltype(opc)::value, o = m - 14 * op;
+            constexpr int op = decltype(opc)::value, o = m - 12 * op;
             if constexpr (o >= 0 && o < 3) {
-                if constexpr (op == 0) a5(rawy[3 * o], rawy[3 * o + 1], rawy[3 * o + 2], pa[o + 1], pa[5 + o + 1], pa[10 + o + 1], pa[15 + o + 1], pa[20 + o + 1]);
-                else bt5(rawx[3 * o], rawx[3 * o + 1], rawx[3 * o + 2], pa[o + 1], pa[5 + o + 1], pa[10 + o + 1], pa[15 + o + 1], pa[20 + o + 1]);
+                if constexpr (op == 0) a4z(rawy[nst][3 * o], rawy[nst][3 * o + 1], rawy[nst][3 * o + 2], pa[o], pa[4 + o], pa[8 + o], pa[12 + o]);
+                else bt4z(rawx[nst][3 * o], rawx[nst][3 * o + 1], rawx[nst][3 * o + 2], pa[o], pa[4 + o], pa[8 + o], pa[12 + o]);
             }
-            if constexpr (o >= 3 && o < 13 && ((o - 3) & 1) == 0) {
+            if constexpr (o >= 3 && o < 11 && ((o - 3) & 1) == 0) {
                 constexpr int i = (o - 3) / 2;
-                float t0_, t1_, t2_, t3_, t4_;
-                if constexpr (op == 0) a5(pa[5 * i + 1], pa[5 * i + 2], pa[5 * i + 3], t0_, t1_, t2_, t3_, t4_);
-                else bt5(pa[5 * i + 1], pa[5 * i + 2], pa[5 * i + 3], t0_, t1_, t2_, t3_, t4_);
-                pa[5 * i] = t0_;
-                pa[5 * i + 1] = t1_;
-                pa[5 * i + 2] = t2_;
-                pa[5 * i + 3] = t3_;
-                pa[5 * i + 4] = t4_;
-                if constexpr (op == 0 && i == 1) bsum += t1_;
+                float t0_, t1_, t2_, t3_;
+                if constexpr (op == 0) a4z(pa[4 * i], pa[4 * i + 1], pa[4 * i + 2], t0_, t1_, t2_, t3_);
+                else bt4z(pa[4 * i], pa[4 * i + 1], pa[4 * i + 2], t0_, t1_, t2_, t3_);
+                pa[4 * i] = t0_;
+                pa[4 * i + 1] = t1_;
+                pa[4 * i + 2] = t2_;
+                pa[4 * i + 3] = t3_;
+                if constexpr (op == 0 && i == 2) bsum = fmaf(25.f / 36.f, t2_, fmaf(-5.f / 36.f, t3_, bsum));
+                if constexpr (op == 0 && i == 3) bsum = fmaf(-5.f / 36.f, t2_, fmaf(1.f / 36.f, t3_, bsum));
             }
-            if constexpr (o >= 4 && o < 14) {
+            if constexpr (o >= 4 && o < 12) {
                 constexpr int i = (o - 4) / 2;
                 if constexpr (((o - 4) & 1) == 0) {
-                    store(nst, opc, 5 * i);
-                    store(nst, opc, 5 * i + 1);
-                    store(nst, opc, 5 * i + 2);
+                    store(nst, opc, 4 * i);
+                    store(nst, opc, 4 * i + 1);
                 } else {
-                    store(nst, opc, 5 * i + 3);
-                    store(nst, opc, 5 * i + 4);
+                    store(nst, opc, 4 * i + 2);
+                    store(nst, opc, 4 * i + 3);
                 }
             }
         });
-        if constexpr (m == 28) locate(s + 2);
-        if constexpr (m >= 28 && m < 37) request(ICG<m - 28>{}, ICG<0>{});
-        if constexpr (m >= 37 && m < 46) request(ICG<m - 37>{}, ICG<1>{});
+        if constexpr (m == 0) locate(s + 2);
+        if constexpr (m < 9) request(stc, ICG<m>{}, ICG<0>{});
+        if constexpr (m >= 9 && m < 18) request(stc, ICG<m - 9>{}, ICG<1>{});
     };
 
     // ---- fragments: lane (row = lane & 31 of the wave's block, k half h = lane >> 5) reads tiles (h, 2 + h) as 8 bytes
@@ -216,32 +207,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         fb[cF(q)] = *reinterpret_cast<const f32x2 *>(rdv_ + stage * STAGEF + q * POSF);
     };
 
-    f32x16 accV[9];  // positions 16..24, in the vector half of the register file (0..15: a[0:255] by name)
     auto mfma = [&](auto qc, float av, float bv) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value;
-        if constexpr (q < 16) {
-            W3G_MFMA_A(q, av, bv);
-        } else {
-            f32x16 &ac = accV[q - 16];
-            W3G_MFMA_V(ac, av, bv);
-        }
+        W3G_MFMA_A(q, av, bv);
     };
 
-    // ---- prologue
+    // ---- prologue: patches of steps 0 and 1 requested, accumulators cleared, step 0 transformed into stage 0
     locate(0);
-    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(Lc, ICG<0>{}); });
-    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(Lc, ICG<1>{}); });
+    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(ICG<0>{}, Lc, ICG<0>{}); });
+    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(ICG<0>{}, Lc, ICG<1>{}); });
+    locate(1);
+    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(ICG<1>{}, Lc, ICG<0>{}); });
+    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(ICG<1>{}, Lc, ICG<1>{}); });
     W3G_CLAIM_ACC();
     static_for<16>([&](auto qc) __attribute__((always_inline)) { W3G_ZERO16(16 * decltype(qc)::value); });
+    {   // (the transform half of the duties of a step "-1" with stage 1: register set 0 into stage 0)
+        static_for<2>([&](auto opc) __attribute__((always_inline)) {
+            constexpr int op = decltype(opc)::value;
+            static_for<3>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int o = decltype(jc)::value;
+                if constexpr (op == 0) a4z(rawy[0][3 * o], rawy[0][3 * o + 1], rawy[0][3 * o + 2], pa[o], pa[4 + o], pa[8 + o], pa[12 + o]);
+                else bt4z(rawx[0][3 * o], rawx[0][3 * o + 1], rawx[0][3 * o + 2], pa[o], pa[4 + o], pa[8 + o], pa[12 + o]);
+            });
+            static_for<4>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                float t0_, t1_, t2_, t3_;
+                if constexpr (op == 0) a4z(pa[4 * i], pa[4 * i + 1], pa[4 * i + 2], t0_, t1_, t2_, t3_);
+                else bt4z(pa[4 * i], pa[4 * i + 1], pa[4 * i + 2], t0_, t1_, t2_, t3_);
+                pa[4 * i] = t0_;
+                pa[4 * i + 1] = t1_;
+                pa[4 * i + 2] = t2_;
+                pa[4 * i + 3] = t3_;
+                if constexpr (op == 0 && i == 2) bsum = fmaf(25.f / 36.f, t2_, fmaf(-5.f / 36.f, t3_, bsum));
+                if constexpr (op == 0 && i == 3) bsum = fmaf(-5.f / 36.f, t2_, fmaf(1.f / 36.f, t3_, bsum));
+            });
 #pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accV[q][e] = 0.f;
-    // (the duties of a step transform into the OTHER stage: stage 1 here, written as stage 0 of step "-1")
-    static_for<28>([&](auto mc) __attribute__((always_inline)) { duty(-1, ICG<1>{}, mc); });
-    locate(1);
-    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(Lc, ICG<0>{}); });
-    static_for<9>([&](auto Lc) __attribute__((always_inline)) { request(Lc, ICG<1>{}); });
+            for (int i = 0; i < 16; ++i) store(0, opc, i);
+        });
+    }
     __syncthreads();
     load_f(0, ICG<0>{});
     load_f(0, ICG<1>{});
@@ -249,13 +252,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- K loop: slot m = MFMA j = m % 2 of position q = m / 2
     auto kstep = [&](int s, auto stc) __attribute__((always_inline)) {
         constexpr int st = decltype(stc)::value;
-        static_for<50>([&](auto mc) __attribute__((always_inline)) {
+        static_for<2 * NP>([&](auto mc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value, q = m / 2, j = m % 2;
             const float av = j == 0 ? fa[cF(q)].x : fa[cF(q)].y;
             const float bv = j == 0 ? fb[cF(q)].x : fb[cF(q)].y;
             mfma(ICG<q>{}, av, bv);
             if constexpr (j == 0) {
-                if constexpr (m == 46) __syncthreads();
+                if constexpr (m == 2 * (NP - 2)) __syncthreads();
                 if constexpr (q + 2 < NP) load_f(st, ICG<(q + 2) % NP>{});
                 else load_f(st ^ 1, ICG<(q + 2) % NP>{});
             }
@@ -268,9 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         kstep(s + 1, ICG<1>{});
     }
     int lane2 = lane;
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+v"(accV[0]), "+v"(accV[1]), "+v"(accV[2]), "+v"(accV[3]), "+v"(accV[4]), "+v"(accV[5]), "+v"(accV[6]),
-                   "+v"(accV[7]), "+v"(accV[8]), "+v"(lane2));
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(lane2));
 
     // ---- bias gradient: the four tile-lanes of a row (lane, lane + 16, + 32, + 48) meet in the first, one atomic per row
     if (want_db) {  // block-uniform
@@ -281,37 +282,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- epilogue, lane-local: accumulator element e of every position belongs to row n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    // of the wave's block and column c = lane & 31, so the fold back to the 3x3 filter, G'^T dU G' (G' = the forward's
-    // row-scaled G: wino3_filter.h), is register arithmetic on the lane's own 25 values -- and the 9 results go straight
-    // into dw with fp32 atomics (16 tile slices meet there): 144 atomics per lane where a dU scratch took 400, no memset,
-    // no second kernel
+    // of the wave's block and column c = lane & 31, so the fold back to the 3x3 filter, G^T dU G (G = the forward's 4x3:
+    // wino3_filter.h), is register arithmetic on the lane's own 16 values -- and the 9 results go straight into dw with fp32
+    // atomics (16 tile slices meet there): 144 atomics per lane, no scratch, no memset, no second kernel
     const int cc = c0 + 32 * ni + (lane2 & 31);
-    auto gt = [](float m0, float m1, float m2, float m3, float m4, float &o0, float &o1, float &o2) __attribute__((always_inline)) {
-        const float h = 0.5f * m1, s = m2 * (1.f / 6.f), u = m3 * (1.f / 6.f);  // G'^T (3x5) applied to a 5-vector
-        o0 = fmaf(0.5f, m0, h) + (s + u);
-        o1 = fmaf(2.f, u, h - s);
-        o2 = fmaf(4.f, u, h + s) + m4;
+    auto gt = [](float m0, float m1, float m2, float m3, float &o0, float &o1, float &o2) __attribute__((always_inline)) {
+        const float d01 = m0 - m1, s01 = m0 + m1, d23 = m2 - m3, s23 = m2 + m3;  // G^T (3x4) applied to a 4-vector
+        const float t = d23 * (1.f / 6.f);
+        o0 = fmaf(-0.25f, d01, t);
+        o1 = fmaf(0.125f, s01, 0.25f * s23);
+        o2 = fmaf(0.25f, d01, t);
     };
     static_for<16>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
-        float t[3][5];
+        float t[3][4];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {  // over the rows u of column j: positions 5 u + j
-            float col[5];
+        for (int j = 0; j < 4; ++j) {  // over the rows u of column j: positions 4 u + j
+            float col[4];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int q = 5 * r + j;
-                if (q < 16) W3G_READ_ACC(col[r], 16 * q + e);
-                else col[r] = accV[q >= 16 ? q - 16 : 0][e];
-            }
-            gt(col[0], col[1], col[2], col[3], col[4], t[0][j], t[1][j], t[2][j]);
+            for (int r = 0; r < 4; ++r) W3G_READ_ACC(col[r], 16 * (4 * r + j) + e);
+            gt(col[0], col[1], col[2], col[3], t[0][j], t[1][j], t[2][j]);
         }
         const int n = n0 + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * (lane2 >> 5);
         float *dst = p.dw + (size_t)n * 9 * p.C + cc;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float o[3];
-            gt(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], o[0], o[1], o[2]);
+            gt(t[a][0], t[a][1], t[a][2], t[a][3], o[0], o[1], o[2]);
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
 #ifdef W3G_NO_ATOMICS  // (timing experiment only: wrong results)

@@ -107,4 +107,5 @@ def test_conv2d_plan_counts_the_tiles_the_f3x3_launch_runs(B, H, C, N, dil):
         lib.mpsr_debug_set_conv_winograd(-1)
     th = H // (3 * dil)
     assert kind.value == 4
-    assert ex.value == 2.0 * B * dil * dil * th * th * 25 * C * N
+    # 25 products per F(3x3,3x3) tile; a sub-grid that is ONE tile (th = 1) runs the sixteen-product form (winograd3z.hip)
+    assert ex.value == 2.0 * B * dil * dil * th * th * (16 if th == 1 else 25) * C * N

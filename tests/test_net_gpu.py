@@ -547,12 +547,15 @@ def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     # data-gradient launches of the training path: the ReLU mask of the layer applied in the store path
     (8, 4, 64, 64, False, False, True), (3, 4, 32, 40, False, False, True), (64, 4, 256, 256, False, False, True),
     (7, 3, 16, 65, False, False, True)])
-def test_conv2d_winograd3_wave_owned_form_is_bit_identical(B, dil, C, N, has_bias, relu, masked):
-    """csrc/winograd3w.hip (one wave owns all 25 positions of its 32-tile x 32-channel block: 400 accumulators, the
-    output transform lane-local) against csrc/winograd3.hip (positions shared by eight waves, exchange through LDS): same
-    transformed operands, same accumulation order per output, same output transform -- identical bits, on ragged tile
-    and channel counts (partial 32-tile blocks, partial 128-channel workgroups), every dilation, with and without
-    bias / ReLU / the training path's mask; and <= 1e-5 of the tensor scale against float64."""
+def test_conv2d_winograd3_wave_owned_forms(B, dil, C, N, has_bias, relu, masked):
+    """The three kernels of an atrous 3x3 layer whose pixel sub-grids are single tiles (mpsr_debug_set_wino3_form):
+    0 = csrc/winograd3.hip (F(3x3,3x3), a tile's 25 positions shared by eight waves, exchange through LDS), 1 =
+    csrc/winograd3w.hip (the same products with one wave owning all 25 positions of its 32-tile x 32-channel block: 400
+    accumulators, lane-local output transform) -- same transformed operands, same accumulation order, same output
+    transform: IDENTICAL BITS; 2 = csrc/winograd3z.hip, the default: the zero-padded tile in SIXTEEN products (rank 4 per
+    dimension, wino3_transforms.h) -- another algorithm, held to 2e-6 of the tensor scale against float64 (measured
+    3e-7: the error of a direct convolution; F(3x3,3x3) 3e-6).  Ragged tile and channel counts (partial 32-tile blocks,
+    partial 128-channel workgroups), every dilation, with and without bias / ReLU / the training path's mask."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     from monopsr_amd.core import weights as W
@@ -567,7 +570,7 @@ def test_conv2d_winograd3_wave_owned_form_is_bit_identical(B, dil, C, N, has_bia
     outs = []
     lib.mpsr_debug_set_conv_winograd(3)
     try:
-        for form in (0, 1):
+        for form in (0, 1, 2, -1):
             lib.mpsr_debug_set_wino3_form(form)
             if masked:
                 ws = torch.empty((lib.mpsr_conv2d_scratch_floats(B, H, H, N),), dtype=torch.float32, device="cuda")
@@ -582,12 +585,23 @@ def test_conv2d_winograd3_wave_owned_form_is_bit_identical(B, dil, C, N, has_bia
     finally:
         lib.mpsr_debug_set_wino3_form(-1)
         lib.mpsr_debug_set_conv_winograd(-1)
-    assert torch.equal(outs[0], outs[1]), "the two F(3x3,3x3) forms differ"
+    assert torch.equal(outs[0], outs[1]), "the two F(3x3,3x3) kernels differ"
+    assert torch.equal(outs[2], outs[3]), "the default is not the sixteen-product form"
+    assert not torch.equal(outs[2], outs[0]) or C * N < 1024  # it really is another evaluation
     ref = _conv_ref(x, w, bias, None, dil, relu)
     if masked:
         ref = torch.where(torch.from_numpy(act) > 0, ref, torch.zeros_like(ref))
         assert 0.3 < float((outs[1] != 0).float().mean()) < 0.7
-    _close(outs[1], ref, 1e-5, "winograd F(3x3) wave-owned %s" % ((B, dil, C, N),))
+    _close(outs[1], ref, 1e-5, "winograd F(3x3,3x3) wave-owned %s" % ((B, dil, C, N),))
+    _close(outs[2], ref, 2e-6, "sixteen-product form %s" % ((B, dil, C, N),))
+    # the plan counts the products of the kernel the call takes
+    kind, ex = ctypes.c_int(-1), ctypes.c_double(0)
+    lib.mpsr_debug_set_conv_winograd(3)
+    try:
+        _lib.check(lib.mpsr_conv2d_plan(B, H, H, C, N, 3, 3, dil, ctypes.byref(kind), ctypes.byref(ex)))
+    finally:
+        lib.mpsr_debug_set_conv_winograd(-1)
+    assert kind.value == 4 and ex.value == 2.0 * B * dil * dil * 16 * C * N
 
 
 def test_border_class_tiling_is_bit_identical():

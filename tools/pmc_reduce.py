@@ -33,7 +33,7 @@ def main(tag, commit, paths):
     kernels = {}
     tot = defaultdict(float)
     for k, cs in agg.items():
-        if not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3w_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
+        if not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3w_conv") or k.startswith("wino3z_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
             continue
         g = lambda c: (cs[c][1] / cs[c][0]) if c in cs and cs[c][0] else None
         n = max(v[0] for v in cs.values())

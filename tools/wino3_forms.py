@@ -1,5 +1,7 @@
-"""The two forms of the F(3x3,3x3) atrous kernel side by side (mpsr_debug_set_wino3_form): 0 = a tile's 25 positions
-shared by eight waves (csrc/winograd3.hip), 1 = one wave owns all 25 (csrc/winograd3w.hip).
+"""The kernels of the atrous 3x3 layers whose pixel sub-grids are single tiles, side by side (mpsr_debug_set_wino3_form):
+0 = F(3x3,3x3), a tile's 25 positions shared by eight waves (csrc/winograd3.hip), 1 = F(3x3,3x3), one wave owns all 25
+(csrc/winograd3w.hip: identical bits to 0), 2 = the SIXTEEN-product form of a zero-padded tile, one wave owns all 16
+(csrc/winograd3z.hip).
 
     python tools/wino3_forms.py [--batches 32,64,128,256] [--rounds 5] [--reps 20] [--relu-input]
 
@@ -46,12 +48,12 @@ def main():
         bias = torch.randn((N,), device=dev)
         nws = lib.mpsr_conv2d_scratch_floats(B, H, H, N)
         ws = torch.empty((nws,), device=dev)
-        outs, times = {}, {0: [], 1: []}
+        outs, times = {}, {0: [], 1: [], 2: []}
 
         def run(y):
             _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, H, C, w.data_ptr(), bias.data_ptr(), None,
                                                 y.data_ptr(), N, 3, 3, dil, 1, 0, ws.data_ptr(), nws, _lib.stream()))
-        for form in (0, 1):
+        for form in (0, 1, 2):
             lib.mpsr_debug_set_wino3_form(form)
             y = torch.full((B, H, H, N), float("nan"), device=dev)
             run(y)
@@ -61,9 +63,9 @@ def main():
         ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(),
                                          w.view(N, 3, 3, C).permute(0, 3, 1, 2).double(), bias.double(),
                                          padding=dil, dilation=dil).relu().permute(0, 2, 3, 1)
-        err = [float((outs[f].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) for f in (0, 1)]
+        err = [float((outs[f].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) for f in (0, 1, 2)]
         for _ in range(args.rounds):
-            for form in (0, 1):
+            for form in (0, 1, 2):
                 lib.mpsr_debug_set_wino3_form(form)
                 y = outs[form]
                 run(y)
@@ -76,10 +78,11 @@ def main():
                 torch.cuda.synchronize()
                 times[form].append(e0.elapsed_time(e1) * 1e3 / args.reps)
         flop = 2.0 * B * dil * dil * 25 * C * N
-        med = {f: sorted(times[f])[len(times[f]) // 2] for f in (0, 1)}
-        print("B %4d  identical bits %s  err vs fp64 %.2e / %.2e | shared positions %7.1f us %6.1f TF/s | one wave per "
-              "block %7.1f us %6.1f TF/s" % (B, same, err[0], err[1], med[0], flop / med[0] / 1e6, med[1],
-                                             flop / med[1] / 1e6), flush=True)
+        med = {f: sorted(times[f])[len(times[f]) // 2] for f in (0, 1, 2)}
+        print("B %4d  identical bits (0 vs 1) %s  err vs fp64 %.2e / %.2e / %.2e | shared positions %7.1f us %6.1f TF/s | one "
+              "wave per block %7.1f us %6.1f TF/s | sixteen products %7.1f us (%6.1f TF/s of its own 16-product work)" % (
+                  B, same, err[0], err[1], err[2], med[0], flop / med[0] / 1e6, med[1], flop / med[1] / 1e6, med[2],
+                  flop * 16 / 25 / med[2] / 1e6), flush=True)
     lib.mpsr_debug_set_wino3_form(-1)
     lib.mpsr_debug_set_conv_winograd(-1)
 
