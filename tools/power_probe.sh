@@ -14,6 +14,10 @@ wait $PID; tail -1 /tmp/step.log
 echo "# the F(3x3,3x3) kernels back to back on all-zero / post-ReLU / dense N(0,1) activations (same filters): us per launch"
 for a in "--zero-input" "--relu-input" ""; do echo "activations: ${a:-dense}"; python tools/wino3_forms.py --batches 256 $a --rounds 3 2>&1 | grep "^B"; done
 if [ -f abl/w3wtrace.so ]; then
-  echo "# cycle stamps of the wave-owned kernel (-DW3W_TRACE build) against its launch time"
-  MPSR_LIB_PATH=abl/w3wtrace.so python tools/wino3w_trace.py 2>&1 | grep -E "launch|matrix pipe|wg 0 wave 0"
+  echo "# cycle stamps of the wave-owned F(3x3,3x3) kernel (-DW3W_TRACE build) against its launch time"
+  MPSR_LIB_PATH=abl/w3wtrace.so python tools/wino3w_trace.py --form 1 2>&1 | grep -E "launch|matrix pipe|wg 0 wave 0"
+fi
+if [ -f abl/w3ztrace.so ]; then
+  echo "# ... and of the sixteen-product kernel (-DW3Z_TRACE build)"
+  MPSR_LIB_PATH=abl/w3ztrace.so python tools/wino3w_trace.py --form 2 2>&1 | grep -E "launch|matrix pipe|wg 0 wave 0"
 fi

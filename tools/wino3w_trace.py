@@ -1,7 +1,8 @@
-"""Per-wave cycle stamps of the one-wave-per-tile-block F(3x3,3x3) kernel (needs a -DW3W_TRACE build of
-csrc/winograd3w.hip: tools/build_variant.sh w3wtrace winograd3w.hip -DW3W_TRACE; MPSR_LIB_PATH=abl/w3wtrace.so).
+"""Per-wave cycle stamps of the one-wave-per-tile-block kernels of block3's atrous layers (need a trace build:
+tools/build_variant.sh w3wtrace winograd3w.hip -DW3W_TRACE -fno-slp-vectorize   (F(3x3,3x3), 25 positions, --form 1)
+tools/build_variant.sh w3ztrace winograd3z.hip -DW3Z_TRACE -fno-slp-vectorize   (sixteen-product form, --form 2)).
 
-    MPSR_LIB_PATH=abl/w3wtrace.so python tools/wino3w_trace.py [--batch 256]
+    MPSR_LIB_PATH=abl/w3ztrace.so python tools/wino3w_trace.py --form 2 [--batch 256]
 
 Prints, for the waves of the first workgroups: prologue, every K step, the wait states behind the loop, epilogue, in
 shader cycles, next to the matrix pipe's own time for a step (100 MFMAs x 64 cycles).
@@ -20,6 +21,7 @@ from monopsr_amd import _lib  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--form", type=int, default=1, choices=[1, 2])
     args = ap.parse_args()
     lib = _lib.lib()
     dev = torch.device("cuda")
@@ -32,7 +34,8 @@ def main():
     nws = lib.mpsr_conv2d_scratch_floats(B, H, H, N)
     ws = torch.empty((nws,), device=dev)
     lib.mpsr_debug_set_conv_winograd(3)
-    lib.mpsr_debug_set_wino3_form(1)
+    lib.mpsr_debug_set_wino3_form(args.form)
+    step_cycles = 6400 if args.form == 1 else 4096  # MFMAs of a K step x 64
     def run():
         _lib.check(lib.mpsr_conv2d_nhwc_f32(x.data_ptr(), B, H, H, C, w.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
                                             N, 3, 3, dil, 1, 0, ws.data_ptr(), nws, _lib.stream()))
@@ -48,18 +51,18 @@ def main():
     launch_us = e0.elapsed_time(e1) * 1e3 / 20
     n = 8 * 4 * 40
     buf = (ctypes.c_ulonglong * n)()
-    fn = lib.mpsr_debug_wino3w_trace
+    fn = lib.mpsr_debug_wino3w_trace if args.form == 1 else lib.mpsr_debug_wino3z_trace
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert fn(buf, n) == 0
-    print("matrix pipe per K step: 6400 cycles; per wave and launch: %d" % (6400 * (C // 8)))
+    print("matrix pipe per K step: %d cycles; per wave and launch: %d" % (step_cycles, step_cycles * (C // 8)))
     life = [buf[(b * 4 + v) * 40 + 35] - buf[(b * 4 + v) * 40] for b in range(8) for v in range(4)
             if buf[(b * 4 + v) * 40 + 35]]
     if life:
         med = sorted(life)[len(life) // 2]
         print("launch %.1f us (back to back, events); a wave lives %d shader cycles (s_memtime) -> shader clock >= %.2f GHz "
               "under this kernel; MFMA issue share of a wave's cycles %.3f, of the launch's time at 2.4 GHz %.3f" % (
-                  launch_us, med, med / launch_us / 1e3, 6400.0 * (C // 8) / med, 6400.0 * (C // 8) / (launch_us * 2400.0)))
+                  launch_us, med, med / launch_us / 1e3, float(step_cycles) * (C // 8) / med, float(step_cycles) * (C // 8) / (launch_us * 2400.0)))
     for blk in range(8):
         for wv in range(4):
             t = buf[(blk * 4 + wv) * 40:(blk * 4 + wv + 1) * 40]
