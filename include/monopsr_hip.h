@@ -272,6 +272,24 @@ int mpsr_conv2d_wgrad_ws_f32(const float *x, const float *dy, int B, int H, int 
  * dx = mpsr_conv2d_nhwc_f32(dy, ..., w = wd, N := C, C := N) with the same KH, KW, dilation. */
 int mpsr_conv2d_dgrad_pack(const float *w, int N, int KH, int KW, int C, float *wd, mpsr_stream_t stream);
 
+/* The re-layout of ALL the layers of a training step in one launch (the reference's step differentiates every layer of
+ * the graph in one session.run: core/trainer.py:76-81, builders/optimizer_builder.py:61-80; here the weights only
+ * change in the optimizer step, so their data-gradient layouts are made once per step, not once per layer launch).
+ * A job = one layer: w (N, T = KH*KW, C) -> wd (C, T, Nd) with Nd >= N (a filter padded to Nd output channels: rows
+ * N..Nd-1 read as zero).  The caller describes the jobs once (`chunk0` is filled in by the library), builds the table
+ * on the host, copies its mpsr_dgrad_pack_table_bytes() bytes to device memory and from then on issues
+ * mpsr_conv2d_dgrad_pack_batch(table_dev, n_chunks) whenever the weights changed.  Pointers inside the table are
+ * device pointers and must stay valid; the table holds no other state. */
+typedef struct mpsr_pack_job {
+    const float *w;
+    float *wd;
+    int32_t N, Nd, T, C;
+    int64_t chunk0;
+} mpsr_pack_job;
+size_t mpsr_dgrad_pack_table_bytes(const mpsr_pack_job *jobs, int n_jobs); /* 0 = bad jobs */
+int mpsr_dgrad_pack_table_build(const mpsr_pack_job *jobs, int n_jobs, void *table_host, long long *n_chunks);
+int mpsr_conv2d_dgrad_pack_batch(const void *table_dev, long long n_chunks, mpsr_stream_t stream);
+
 /* Fused activation + bias gradient in one pass over dy (M,N): g = (y > 0 ? dy : 0) when y != NULL else dy;
  * dx = g when dx != NULL (may alias dy); db[n] += sum_m g[m][n] when db != NULL (zeroed by the caller). */
 int mpsr_act_bias_grad(const float *dy, const float *y, float *dx, float *db, long long M, int N,

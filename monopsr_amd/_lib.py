@@ -61,6 +61,12 @@ class ConvOpts(ctypes.Structure):
     _fields_ = [("math", ctypes.c_int32), ("winograd_policy", ctypes.c_int32)]
 
 
+class PackJob(ctypes.Structure):
+    """struct mpsr_pack_job"""
+    _fields_ = [("w", ctypes.c_void_p), ("wd", ctypes.c_void_p), ("N", ctypes.c_int32), ("Nd", ctypes.c_int32),
+                ("T", ctypes.c_int32), ("C", ctypes.c_int32), ("chunk0", ctypes.c_int64)]
+
+
 # per-call option values (MPSR_CALL_MATH_*, MPSR_CALL_WINOGRAD_*): None / "inherit" = the process-wide default
 CALL_MATH = {None: 0, "inherit": 0, "fp32": 1, "bf16x3": 2}
 CALL_WINOGRAD = {None: 0, "inherit": 0, "auto": 1, "off": 2}
@@ -98,6 +104,10 @@ SIGNATURES = {
     "mpsr_conv2d_wgrad_scratch_floats": (c_sz, [c_i] * 8),
     "mpsr_conv2d_wgrad_ws_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_sz, c_f]),
     "mpsr_conv2d_dgrad_pack": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "mpsr_dgrad_pack_table_bytes": (c_sz, [ctypes.POINTER(PackJob), c_i]),
+    "mpsr_dgrad_pack_table_build": (c_i, [ctypes.POINTER(PackJob), c_i, ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_longlong)]),
+    "mpsr_conv2d_dgrad_pack_batch": (c_i, [c_f, ctypes.c_longlong, c_f]),
     "mpsr_act_bias_grad": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f]),
     "mpsr_bias_grad": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f]),
     "mpsr_relu_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_f]),

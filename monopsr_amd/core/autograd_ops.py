@@ -147,16 +147,69 @@ def _deposit_weight_grad(L, x, g):
         ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete
 
 
+class DgradBank:
+    """The data-gradient layouts (mpsr_conv2d_dgrad_pack) of ALL layers in one flat buffer, refreshed by ONE launch
+    per step (mpsr_conv2d_dgrad_pack_batch) instead of one launch per layer inside backward (105 launches of ~5 us
+    and as many gaps per step).  The weights only change in the optimizer step: the trainer calls refresh() before
+    backward and invalidate() after it; while `fresh`, the _data_grad* helpers read a layer's `wd` view instead of
+    packing.  Anything else that runs backward (tests, a caller's own loop) never sees a stale layout: without
+    refresh() the per-layer path runs as before."""
+
+    def __init__(self, layers, device):
+        lib = _lib.lib()
+        sizes = []
+        for L in layers:
+            n4 = L.cout + (-L.cout) % 4
+            sizes.append(L.cin * L.kh * L.kw * n4)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 63) // 64 * 64)  # 256-byte aligned slices (16-byte loads in the kernels)
+        self.flat = torch.empty((offs[-1],), dtype=torch.float32, device=device)
+        jobs = (_lib.PackJob * len(layers))()
+        for i, L in enumerate(layers):
+            n4 = L.cout + (-L.cout) % 4
+            L.wd = self.flat[offs[i]:offs[i] + sizes[i]].view(L.cin, L.kh * L.kw * n4)
+            L.dgrad_bank = self
+            jobs[i].w, jobs[i].wd = L.w.data_ptr(), L.wd.data_ptr()
+            jobs[i].N, jobs[i].Nd, jobs[i].T, jobs[i].C = L.cout, n4, L.kh * L.kw, L.cin
+        nbytes = lib.mpsr_dgrad_pack_table_bytes(jobs, len(layers))
+        if not nbytes:
+            raise _lib.InvalidArgumentError("DgradBank: bad layer table")
+        import ctypes
+        host = torch.zeros(((nbytes + 7) // 8,), dtype=torch.int64)
+        n_chunks = ctypes.c_longlong(0)
+        _lib.check(lib.mpsr_dgrad_pack_table_build(jobs, len(layers), host.data_ptr(), ctypes.byref(n_chunks)))
+        self.table = host.to(device)
+        self.n_chunks = int(n_chunks.value)
+        self.fresh = False
+
+    def refresh(self):
+        _lib.check(_lib.lib().mpsr_conv2d_dgrad_pack_batch(_lib.ptr(self.table), self.n_chunks, _lib.stream()))
+        self.fresh = True
+
+    def invalidate(self):
+        self.fresh = False
+
+
+def _dgrad_filter(L, C, N4, pad, device):
+    """wd (C, taps x N4) of layer L: its slice of a fresh DgradBank, else packed here."""
+    bank = getattr(L, "dgrad_bank", None)
+    if bank is not None and bank.fresh and C == L.cin:
+        return L.wd
+    w4 = F.pad(L.w, (0, 0, 0, pad)) if pad else L.w
+    wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd),
+                                                 _lib.stream()))
+    return wd
+
+
 def _data_grad(L, g, C, residual=None):
     """dX of one layer = the forward convolution of g with the taps flipped and the channel roles swapped
     (mpsr_conv2d_dgrad_pack); `residual` (same shape as dX) is added in that convolution's epilogue -- the gradient of
     another branch that read the same tensor, for free instead of by an elementwise launch."""
     g4, pad = _pad4(L, g)
     N4 = L.cout + pad
-    w4 = F.pad(L.w, (0, 0, 0, pad)) if pad else L.w
-    wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=g.device)
-    _lib.check(_lib.lib().mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd),
-                                                 _lib.stream()))
+    wd = _dgrad_filter(L, C, N4, pad, g.device)
     return dn.conv2d(g4, wd, None, residual, L.kh, L.kw, L.dilation, False, split_k=_SCHED)
 
 
@@ -204,8 +257,7 @@ def _data_grad_masked(L, g, x, residual, bits=None):
     if bits is None:
         bits = dn.stream_scratch(_MASK_SCRATCH, x.device, lib.mpsr_relu_bitmask_words(M, C))
         _lib.check(lib.mpsr_relu_bitmask(_lib.ptr(x), M, C, _lib.ptr(bits), s))
-    wd = torch.empty((C, N), dtype=torch.float32, device=g.device)
-    _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(L.w), N, 1, 1, C, _lib.ptr(wd), s))
+    wd = _dgrad_filter(L, C, N, 0, g.device)
     dx = torch.empty_like(x)
     _lib.check(lib.mpsr_conv1x1_masked_f32(_lib.ptr(g), M, N, _lib.ptr(wd), None, _lib.ptr(residual), _lib.ptr(bits),
                                            _lib.ptr(dx), C, s))
@@ -219,10 +271,8 @@ def _data_grad_relu_masked(L, g, y_in):
     g4, pad = _pad4(L, g)
     N4 = L.cout + pad
     C = y_in.shape[3]
-    w4 = F.pad(L.w, (0, 0, 0, pad)) if pad else L.w
     s = _lib.stream()
-    wd = torch.empty((C, L.kh * L.kw * N4), dtype=torch.float32, device=g.device)
-    _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4.contiguous()), N4, L.kh, L.kw, C, _lib.ptr(wd), s))
+    wd = _dgrad_filter(L, C, N4, pad, g.device)
     B, H, W, _ = g4.shape
     ws = dn.stream_scratch(dn._SCHED_SCRATCH, g.device, lib.mpsr_conv2d_scratch_floats(B, H, W, C))
     dx = torch.empty_like(y_in)

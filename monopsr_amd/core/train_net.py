@@ -27,7 +27,7 @@ def _im2col_root(img, kpad):
 
 class TrainNet:
     def __init__(self, weights, device="cuda", width_div=1, with_heads=True, full_trunk=False, decoder_bn='frozen',
-                 bn_group=None):
+                 bn_group=None, dgrad_bank=True):
         """full_trunk: also hold (and train) the full-image ResNet-101 (`weights` must then carry both scopes); its
         layers follow the heads in the flat buffer, so the flat gradient is the reference's whole 100 M-parameter
         set (401 MB at full width)."""
@@ -89,6 +89,10 @@ class TrainNet:
                                             bool(r["relu"])))
         self.n_trunk = len(parts[0][1])
         self.n_dec = len(parts[1][1])
+        # data-gradient layouts of every layer, made by one launch per step (the trainer refreshes it before backward)
+        # (dgrad_bank=False: each layer's layout is packed inside backward, one launch per layer -- the A/B of
+        # tools/train_bench.py --dgrad-bank 0)
+        self.dgrad_bank = ops.DgradBank(self.layers, self.device) if (dgrad_bank and self.device.type == "cuda") else None
         if decoder_bn in ('batch', 'batch_global'):
             # decoder records: squash (2 GEMMs), then one record per spec; BatchNorm layers get the UNFOLDED kernel
             # in their weight slot and beta in their bias slot

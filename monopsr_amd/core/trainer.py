@@ -271,7 +271,14 @@ class InstanceTrainer:
         self.net.zero_grad()
         out = self.forward(sample)
         self.losses_dict, loss = self.loss(out, sample)
-        loss.backward()
+        bank = getattr(self.net, "dgrad_bank", None)
+        if bank is not None:
+            bank.refresh()  # the weights are this step's until apply_gradients: one launch packs every layer
+        try:
+            loss.backward()
+        finally:
+            if bank is not None:
+                bank.invalidate()
         self.reducer.finish(average=True)
         if self.clip_norm:
             self.clip_per_variable()

@@ -3,7 +3,10 @@
 // epsilon 1e-3, followed by ReLU).  Inference folds the moving statistics into the convolution (core/weights.py);
 // these kernels are what a training step needs instead.  All of them stream an (M, C) activation once, float4 per
 // thread; per-channel reductions are per-thread float partials -> workgroup sums in double -> one fp64 atomic per
-// channel per workgroup (<= 512 workgroups, so the same-address atomics stay cheap).
+// channel per workgroup.  The reducing kernels run as ONE 1024-thread workgroup per CU with FOUR rows per thread in
+// flight: with one 16-byte load outstanding per thread and 512 workgroups of 256 they streamed at 2.3-3.6 TB/s where
+// the elementwise passes next to them reach 6+ (r05: 1.13 of the training step's 51 ms on the four decoder layers), and
+// more workgroups cost more in same-address fp64 atomics than they gain (2048 x 256: 97 -> 197 us on bn_stats).
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
@@ -11,18 +14,19 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 512;
+constexpr int kRThreads = 1024;  // the reducing kernels
+constexpr int kMaxBlocks = 256;
 
 struct RowMap {  // thread -> (float4 column group, first row, row stride) for an (M, C) matrix, C % 4 == 0, C <= 1024
     int groups, rstride, cg, r0;
-    __device__ RowMap(int C) : groups(C >> 2), rstride(kThreads / (C >> 2)), cg(threadIdx.x % (C >> 2)),
+    __device__ RowMap(int C) : groups(C >> 2), rstride(kRThreads / (C >> 2)), cg(threadIdx.x % (C >> 2)),
                                r0(threadIdx.x / (C >> 2)) {}
 };
 
 // column sums of two per-thread float4 partials -> fp64 atomics into a[], b[]
 __device__ __forceinline__ void reduce_columns(const RowMap &m, float4 sa, float4 sb, double *a, double *b)
 {
-    __shared__ float4 pa[kThreads], pb[kThreads];
+    __shared__ float4 pa[kRThreads], pb[kRThreads];
     pa[threadIdx.x] = sa;
     pb[threadIdx.x] = sb;
     __syncthreads();
@@ -42,7 +46,7 @@ __device__ __forceinline__ void reduce_columns(const RowMap &m, float4 sa, float
 }
 
 // sum[c] += sum_m z, sumsq[c] += sum_m (z - shift[c])^2 ... shift = z of row 0 keeps the variance well conditioned
-__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restrict__ z, long long M, int C,
+__global__ __launch_bounds__(kRThreads) void bn_stats_kernel(const float *__restrict__ z, long long M, int C,
                                                             long long rows_per_block, double *__restrict__ sum,
                                                             double *__restrict__ sumsq)
 {
@@ -51,12 +55,20 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restr
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     if (m.r0 < m.rstride) {
         const float4 sh = reinterpret_cast<const float4 *>(z)[m.cg];  // row 0 of this column group
-        for (long long r = m0 + m.r0; r < m1; r += m.rstride) {
-            float4 v = reinterpret_cast<const float4 *>(z)[(size_t)r * m.groups + m.cg];
+        const float4 *zp = reinterpret_cast<const float4 *>(z);
+        auto acc = [&](float4 v) __attribute__((always_inline)) {
             v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        };
+        long long r = m0 + m.r0;
+        const long long st = m.rstride;
+        for (; r + 3 * st < m1; r += 4 * st) {
+            const float4 v0 = zp[(size_t)r * m.groups + m.cg], v1 = zp[(size_t)(r + st) * m.groups + m.cg],
+                         v2 = zp[(size_t)(r + 2 * st) * m.groups + m.cg], v3 = zp[(size_t)(r + 3 * st) * m.groups + m.cg];
+            acc(v0); acc(v1); acc(v2); acc(v3);
         }
+        for (; r < m1; r += st) acc(zp[(size_t)r * m.groups + m.cg]);
     }
     reduce_columns(m, s, q, sum, sumsq);
 }
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restr
 }
 
 // g = dy * (y > 0) (or dy);  sum_g[c] += sum_m g,  sum_gz[c] += sum_m g * zhat,  zhat = (z - mean) * inv_std
-__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float *__restrict__ dy,
+__global__ __launch_bounds__(kRThreads) void bn_bwd_reduce_kernel(const float *__restrict__ dy,
                                                                  const float *__restrict__ y,
                                                                  const float *__restrict__ z, long long M, int C,
                                                                  long long rows_per_block,
@@ -94,18 +106,34 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float *__
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     if (m.r0 < m.rstride) {
         const float4 mu = reinterpret_cast<const float4 *>(mean)[m.cg], is = reinterpret_cast<const float4 *>(inv_std)[m.cg];
-        for (long long r = m0 + m.r0; r < m1; r += m.rstride) {
-            const size_t o = (size_t)r * m.groups + m.cg;
-            float4 g = reinterpret_cast<const float4 *>(dy)[o];
+        const float4 *gp = reinterpret_cast<const float4 *>(dy), *yp = reinterpret_cast<const float4 *>(y),
+                     *zp = reinterpret_cast<const float4 *>(z);
+        auto acc = [&](float4 g, float4 a, float4 v) __attribute__((always_inline)) {
             if (y) {
-                const float4 a = reinterpret_cast<const float4 *>(y)[o];
                 g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
                 g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
             }
-            const float4 v = reinterpret_cast<const float4 *>(z)[o];
             s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
             q.x += g.x * (v.x - mu.x) * is.x; q.y += g.y * (v.y - mu.y) * is.y;
             q.z += g.z * (v.z - mu.z) * is.z; q.w += g.w * (v.w - mu.w) * is.w;
+        };
+        long long r = m0 + m.r0;
+        const long long st = m.rstride;
+        for (; r + 3 * st < m1; r += 4 * st) {
+            float4 g[4], a[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = (size_t)(r + k * st) * m.groups + m.cg;
+                g[k] = gp[o];
+                a[k] = y ? yp[o] : g[k];
+                v[k] = zp[o];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc(g[k], a[k], v[k]);
+        }
+        for (; r < m1; r += st) {
+            const size_t o = (size_t)r * m.groups + m.cg;
+            acc(gp[o], y ? yp[o] : gp[o], zp[o]);
         }
     }
     reduce_columns(m, s, q, sum_g, sum_gz);
@@ -146,10 +174,18 @@ int check_mc(const char *op, long long M, int C)
 
 inline void slicing(long long M, int &blocks, long long &rows)
 {
-    long long b = (M + 63) / 64;
+    long long b = (M + 255) / 256;
     if (b > kMaxBlocks) b = kMaxBlocks;
     rows = (M + b - 1) / b;
     blocks = (int)((M + rows - 1) / rows);
+}
+
+// zero two fp64 arrays of C: one fill when the caller keeps them back to back (a (2, C) tensor), else two
+inline hipError_t zero_pair(double *a, double *b, int C, hipStream_t s)
+{
+    if (b == a + C) return hipMemsetAsync(a, 0, sizeof(double) * 2 * C, s);
+    if (hipError_t e = hipMemsetAsync(a, 0, sizeof(double) * C, s)) return e;
+    return hipMemsetAsync(b, 0, sizeof(double) * C, s);
 }
 
 inline int stream_grid(long long n4) { return (int)((n4 + kThreads - 1) / kThreads < 65536 ? (n4 + kThreads - 1) / kThreads : 65536); }
@@ -162,12 +198,11 @@ extern "C" int mpsr_batch_norm_stats(const float *z, long long M, int C, double 
     if (int rc = check_mc("batch_norm_stats", M, C)) return rc;
     MPSR_REQUIRE(z && sum && sumsq_shifted && ((uintptr_t)z & 15) == 0, "batch_norm_stats: null or misaligned pointer");
     hipStream_t s = mpsr::as_stream(stream);
-    MPSR_CHECK_HIP(hipMemsetAsync(sum, 0, sizeof(double) * C, s));
-    MPSR_CHECK_HIP(hipMemsetAsync(sumsq_shifted, 0, sizeof(double) * C, s));
+    MPSR_CHECK_HIP(zero_pair(sum, sumsq_shifted, C, s));
     int blocks;
     long long rows;
     slicing(M, blocks, rows);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(kThreads), 0, s, z, M, C, rows, sum, sumsq_shifted);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(kRThreads), 0, s, z, M, C, rows, sum, sumsq_shifted);
     MPSR_CHECK_LAUNCH("bn_stats_kernel");
     return MPSR_OK;
 }
@@ -191,12 +226,11 @@ extern "C" int mpsr_batch_norm_grad_sums(const float *dy, const float *y, const 
     if (int rc = check_mc("batch_norm_grad_sums", M, C)) return rc;
     MPSR_REQUIRE(dy && z && mean && inv_std && sum_g && sum_gz, "batch_norm_grad_sums: null pointer");
     hipStream_t s = mpsr::as_stream(stream);
-    MPSR_CHECK_HIP(hipMemsetAsync(sum_g, 0, sizeof(double) * C, s));
-    MPSR_CHECK_HIP(hipMemsetAsync(sum_gz, 0, sizeof(double) * C, s));
+    MPSR_CHECK_HIP(zero_pair(sum_g, sum_gz, C, s));
     int blocks;
     long long rows;
     slicing(M, blocks, rows);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kThreads), 0, s, dy, y, z, M, C, rows, mean, inv_std,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kRThreads), 0, s, dy, y, z, M, C, rows, mean, inv_std,
                        sum_g, sum_gz);
     MPSR_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return MPSR_OK;

@@ -517,6 +517,47 @@ def test_instance_trainer_step_reduces_loss():
     assert not empty, empty
 
 
+def test_dgrad_bank_is_the_per_layer_pack_of_every_layer_bit_for_bit():
+    """mpsr_conv2d_dgrad_pack_batch (one launch per step for all layers: narrow heads padded to 4 output channels,
+    FC layers with padded K, 1x1 / 3x3 / 7x7 taps) against mpsr_conv2d_dgrad_pack layer by layer; the trainer's
+    backward reads the bank only between refresh() and invalidate(), and a step with the bank gives the data
+    gradients of a step without it (same kernels on the same bits)."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import autograd_ops as ops
+    from monopsr_amd.core import train_net
+    from monopsr_amd.core import weights as W
+    net = train_net.TrainNet(W.synthetic_weights(seed=131, width_div=4), width_div=4)
+    bank = net.dgrad_bank
+    assert bank is not None and not bank.fresh
+    net.params.normal_(generator=torch.Generator(device="cuda").manual_seed(132))
+    bank.flat.fill_(float("nan"))
+    bank.refresh()
+    assert bank.fresh
+    lib = _lib.lib()
+    narrow = 0
+    for L in net.layers:
+        pad = (-L.cout) % 4
+        narrow += pad > 0
+        n4 = L.cout + pad
+        w4 = F.pad(L.w, (0, 0, 0, pad)).contiguous() if pad else L.w
+        ref = torch.empty((L.cin, L.kh * L.kw * n4), dtype=torch.float32, device="cuda")
+        _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w4), n4, L.kh, L.kw, L.cin, _lib.ptr(ref), _lib.stream()))
+        assert L.wd.shape == ref.shape and torch.equal(L.wd, ref), (L.cin, L.cout, L.kh)
+        assert ops._dgrad_filter(L, L.cin, n4, pad, ref.device) is L.wd
+    assert narrow >= 1  # (the 3-channel xyz head)
+    bank.invalidate()
+    L = net.layers[5]
+    assert ops._dgrad_filter(L, L.cin, L.cout, 0, torch.device("cuda")) is not L.wd
+    # a stale bank is never read: change the weights, run a backward outside the trainer, compare with a fresh pack
+    net.params.mul_(2.0)
+    g = torch.randn((2, 12, 12, L.cout), device="cuda")
+    dx = ops._data_grad(L, g, L.cin)
+    bank.refresh()
+    dx2 = ops._data_grad(L, g, L.cin)
+    bank.invalidate()
+    assert torch.equal(dx, dx2)
+
+
 def test_clip_by_norm_segments_matches_per_tensor_clip():
     """mpsr_clip_by_norm_segments over the trainer's chunk table == tf.clip_by_norm tensor by tensor."""
     from monopsr_amd.core import config_utils, train_net, trainer

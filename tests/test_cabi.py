@@ -55,6 +55,7 @@ def test_struct_layouts_match_the_header():
     # (int32 + padding before the event handle; tags pointer; ABI 5: two int32 options)
     assert ctypes.sizeof(_lib.NetOpts) == 8 + 8 + 8 + 8 + 8 + 4 + 4
     assert ctypes.sizeof(_lib.ConvOpts) == 8
+    assert ctypes.sizeof(_lib.PackJob) == 8 + 8 + 4 * 4 + 8
 
 
 def test_host_side_argument_checks_need_no_gpu():

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--wgrad-winograd", type=int, default=1, choices=[0, 1],
                     help="A/B: 0 = every weight gradient on the direct kernel (mpsr_debug_set_wgrad_winograd), 1 = the "
                          "decoder's dense 3x3 layers in the F(4x4,3x3) domain and block3's atrous layers in F(3x3,3x3)")
+    ap.add_argument("--dgrad-bank", type=int, default=1, choices=[0, 1],
+                    help="A/B: 0 = the data-gradient layout of each layer packed inside backward (one launch per "
+                         "layer), 1 = all layers by one launch per step (autograd_ops.DgradBank)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
     args = ap.parse_args()
@@ -61,7 +64,7 @@ def main():
     _lib.lib().mpsr_debug_set_wgrad_winograd(args.wgrad_winograd)
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
-                             decoder_bn=args.decoder_bn)
+                             decoder_bn=args.decoder_bn, dgrad_bank=bool(args.dgrad_bank))
     net.linked_units = not args.unlinked_units
     if args.unfused_relu_grads:
         from monopsr_amd.core import autograd_ops
