@@ -9,6 +9,12 @@
 
 #include "common.h"
 
+namespace mpsr {
+// thin_conv.hip
+bool thin_wgrad_applies(int B, int H, int W, int C, int N, int KH, int KW, int dilation);
+int thin_wgrad(const float *x, const float *dy, int B, int H, int W, int C, float *dw, float *db, hipStream_t s);
+}  // namespace mpsr
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -550,6 +556,9 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     MPSR_REQUIRE(C % 4 == 0 && N % 4 == 0, "conv2d_wgrad: C=%d and N=%d must be multiples of 4", C, N);
     if (B == 0) return MPSR_OK;
     MPSR_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    // a head with (at most) four output channels: reduce over the pixels on the vector ALU (thin_conv.hip)
+    if (mpsr::thin_wgrad_applies(B, H, W, C, N, KH, KW, dilation))
+        return mpsr::thin_wgrad(x, dy, B, H, W, C, dw, db, mpsr::as_stream(stream));
     const long long M = (long long)B * H * W;
     MPSR_REQUIRE(M * C * 4 < 0xfffff000LL && M * N * 4 < 0xfffff000LL, "conv2d_wgrad: tensor exceeds 4 GiB");
     // the kernel decodes pixel indices with 24-bit multiplies and a float reciprocal

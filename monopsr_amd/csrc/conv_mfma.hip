@@ -1124,6 +1124,11 @@ int pointwise_override();
 int conv1x1_pointwise(const float *x, long long M, int K, const float *w, const float *bias, const float *residual,
                       int relu, float *y, int N, hipStream_t s);
 
+// thin_conv.hip
+bool thin_input_conv_applies(int B, int H, int W, int C, int N, int KH, int KW, int dilation);
+int thin_input_conv(const float *x, int B, int H, int W, const float *w, const float *bias, int relu, float *y, int N,
+                    hipStream_t s);
+
 bool fc_rows_applies(long long M, int K, int N);
 int fc_rows(const float *x, long long M, int K, const float *w, const float *bias, const float *residual, int relu,
             float *y, int N, hipStream_t s);
@@ -1278,6 +1283,11 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0 && !residual && split_k <= 1 &&
         g_tile_override.load() < 0 && ((uintptr_t)w & 3) == 0)
         return conv3x3_narrow(x, B, H, W, C, w, bias, relu, y, N, stream, 0);
+    // ... and 3x3 layers with FOUR input channels (the data gradient of that head: dy padded to 4 channels -> 128) are
+    // output-bandwidth-bound: 36 multiply-adds per output element on the vector ALU (thin_conv.hip)
+    if (!residual && split_k <= 1 && g_tile_override.load() < 0 && cur_math() == MATH_FP32 &&
+        thin_input_conv_applies(B, H, W, C, N, KH, KW, dilation))
+        return thin_input_conv(x, B, H, W, w, bias, relu, y, N, stream);
     // atrous 3x3 layers whose pixel sub-grids are 3x3 (block3's conv2: 12x12 at dilation 4): every sub-grid is one
     // Winograd F(3x3,3x3) tile with an all-zero halo -- 25 products where the border-class implicit GEMM executes 49
     // (winograd3.hip).  fp32 mode only (the bf16x3 implicit GEMM is faster than fp32 Winograd there).
@@ -1457,6 +1467,11 @@ extern "C" int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int K
     }
     if (KH == 3 && KW == 3 && dilation == 1 && N <= 4 && C % 32 == 0) {
         *kind = 2;
+        *executed_flops = 2.0 * M * 9.0 * C * N;
+        return MPSR_OK;
+    }
+    if (mpsr::thin_input_conv_applies(B, H, W, C, N, KH, KW, dilation)) {
+        *kind = 2;  // (the same family: a direct vector-ALU kernel, here with the thin side on the input)
         *executed_flops = 2.0 * M * 9.0 * C * N;
         return MPSR_OK;
     }

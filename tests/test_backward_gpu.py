@@ -558,6 +558,62 @@ def test_dgrad_bank_is_the_per_layer_pack_of_every_layer_bit_for_bit():
     assert torch.equal(dx, dx2)
 
 
+@pytest.mark.parametrize("B,C,N", [(256, 18432, 1024), (8, 4608, 256), (6, 4608, 256), (4, 4100, 27)])
+def test_wide_fc_data_gradient_vs_float64(B, C, N):
+    """dX of a few-row FC layer with a wide input (img_fc): autograd_ops._data_grad runs it transposed (rows = input
+    features) when B % 4 == 0; every form against g @ w in float64."""
+    from monopsr_amd.core import autograd_ops as ops
+    gen = torch.Generator(device="cuda").manual_seed(B + C)
+    w = torch.randn((N, C), device="cuda", generator=gen) / np.sqrt(N)
+    g = torch.randn((B, 1, 1, N), device="cuda", generator=gen)
+    L = ops.LayerRef(w, None, None, None, C, N, 1, 1, 1, False)
+    dx = ops._data_grad(L, g, C)
+    assert dx.shape == (B, 1, 1, C) and dx.is_contiguous()
+    ref = g.view(B, N).double() @ w.double()
+    err = float((dx.view(B, C).double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 48, 48, 128), (3, 12, 12, 64), (1, 7, 10, 256), (5, 24, 24, 128), (1, 62, 62, 64)])
+def test_thin_side_gradients_of_the_xyz_head_vs_float64(B, H, W, C):
+    """csrc/thin_conv.hip: weight gradient (4 x 9 x C, + bias gradient) and data gradient (4 -> C channels) of a 3x3
+    layer with four output channels -- the xyz-map head padded to 4 -- against float64 autograd, and against the general
+    kernels (mpsr_debug_set_thin_conv(0)) on the same inputs; ragged strips (H not a multiple of 6), several images per
+    wave, dw accumulating into what is already there."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    lib = _lib.lib()
+    gen = torch.Generator(device="cuda").manual_seed(1000 * B + H + C)
+    x = torch.randn((B, H, W, C), device="cuda", generator=gen)
+    dy = torch.randn((B, H, W, 4), device="cuda", generator=gen)
+    dy[..., 3] = 0  # (the padded channel of the real head; the kernels do not rely on it)
+    w = torch.randn((4, 9 * C), device="cuda", generator=gen) / np.sqrt(9 * C)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wdd = w.double().view(4, 3, 3, C).permute(0, 3, 1, 2).requires_grad_(True)
+    F.conv2d(xd, wdd, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    dw_ref = wdd.grad.permute(0, 2, 3, 1).reshape(4, 9 * C)
+    dx_ref = xd.grad.permute(0, 2, 3, 1)
+    db_ref = dy.double().sum((0, 1, 2))
+    out = {}
+    for thin in (1, 0):
+        lib.mpsr_debug_set_thin_conv(thin)
+        try:
+            dw = torch.full((4, 9 * C), 0.5, device="cuda")
+            db = torch.full((4,), -2.0, device="cuda")
+            _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(dy), B, H, W, C, 4, 3, 3, 1, _lib.ptr(dw),
+                                                 _lib.ptr(db), _lib.stream()))
+            wd = torch.empty((C, 9 * 4), device="cuda")
+            _lib.check(lib.mpsr_conv2d_dgrad_pack(_lib.ptr(w), 4, 3, 3, C, _lib.ptr(wd), _lib.stream()))
+            dx = dn.conv2d(dy, wd, None, None, 3, 3, 1, False)
+        finally:
+            lib.mpsr_debug_set_thin_conv(1)
+        out[thin] = (dw - 0.5, db + 2.0, dx)
+        for got, ref, name in ((dw - 0.5, dw_ref, "dw"), (db + 2.0, db_ref, "db"), (dx, dx_ref, "dx")):
+            err = float((got.double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-5, (thin, name, err)
+    assert float((out[1][2] - out[0][2]).abs().max()) < 1e-4 * float(out[0][2].abs().max())
+
+
 def test_clip_by_norm_segments_matches_per_tensor_clip():
     """mpsr_clip_by_norm_segments over the trainer's chunk table == tf.clip_by_norm tensor by tensor."""
     from monopsr_amd.core import config_utils, train_net, trainer
