@@ -111,6 +111,6 @@ struct FilterCacheSlot {
         return ok;
     }
 };
-enum { FILTER_FORM_WINO4 = 1, FILTER_FORM_WINO3 = 2, FILTER_FORM_UPCONV = 3, FILTER_FORM_WINO3Z = 4 };
+enum { FILTER_FORM_WINO4 = 1, FILTER_FORM_WINO3 = 2, FILTER_FORM_UPCONV = 3, FILTER_FORM_WINO3Z = 4, FILTER_FORM_WINO2 = 5 };
 extern thread_local FilterCacheSlot g_filter_cache_slot;
 }  // namespace mpsr

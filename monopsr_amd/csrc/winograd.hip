@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wino3_filter.h"
 
 namespace {
 
@@ -668,13 +669,22 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
                                                                           ? reinterpret_cast<const void *>(wino_conv8_kernel)
                                                                           : reinterpret_cast<const void *>(wino_conv_kernel)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
-    {
+    // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer: the
+    // full-image trunk's atrous layers run here (F(2x2,3x3) on their pixel sub-grids), 27 filter transforms per call
+    float *u = ws;
+    bool ready = false;
+    if (g_filter_cache_slot.w == w && g_filter_cache_slot.u && g_filter_cache_slot.floats >= winograd_scratch_floats(C, N)) {
+        u = g_filter_cache_slot.u;
+        ready = g_filter_cache_slot.holds(FILTER_FORM_WINO2);
+    }
+    g_filter_cache_slot = FilterCacheSlot();
+    if (!ready) {
         const long long total = (long long)N * C;
-        hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, ws);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, C, u);
         MPSR_CHECK_LAUNCH("wino_filter_kernel");
     }
     WinoParams p;
-    p.x = x; p.u = ws; p.bias = bias; p.y = y;
+    p.x = x; p.u = u; p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.C = C; p.N = N;
     p.dil = dilation;
     p.th = H / (2 * dilation); p.tw = W / (2 * dilation);
