@@ -162,7 +162,7 @@ int mpsr_max_pool(const float *in, int B, int H, int W, int C, int k, int s, int
  * A fully-connected layer is H=W=KH=KW=1.
  * mpsr_conv2d_plan reports, for a layer left to the library (split_k = 0, scratch given), which kernel serves it
  * (*kind: 0 implicit GEMM, 1 Winograd F(2x2,3x3), 2 direct narrow-N kernel, 3 Winograd F(4x4,3x3), 4 Winograd
- * F(3x3,3x3) on the sub-grids of an atrous layer, 5 persistent pointwise kernel, 6 few-row fully-connected kernel) and the multiply-add FLOPs that kernel issues --
+ * F(3x3,3x3) -- or its sixteen-product form where a sub-grid is one zero-padded tile -- on the sub-grids of an atrous layer, 5 persistent pointwise kernel, 6 few-row fully-connected kernel) and the multiply-add FLOPs that kernel issues --
  * for throughput accounting (bench.py's roofline.executed), not needed to run anything. */
 size_t mpsr_conv2d_scratch_floats(int B, int H, int W, int N);
 int mpsr_conv2d_plan(int B, int H, int W, int C, int N, int KH, int KW, int dilation, int *kind,
@@ -200,17 +200,19 @@ int mpsr_get_conv_math(void);
 
 /* Whether 3x3 layers may run in a Winograd transform domain (process-wide DEFAULT, like the arithmetic above; per call:
  * mpsr_conv_opts / mpsr_net_opts).
- *   MPSR_WINOGRAD_AUTO (default) F(3x3,3x3) on block3's atrous layers, F(4x4,3x3) / F(2x2,3x3) on the dense decoder
- *                      layers wherever they are faster.  Error against float64 of the tensor's SCALE: 5e-6 / 1.5e-5 /
- *                      1e-6 (a direct fp32 convolution: 5e-7) -- far inside the path's 1e-3 budget.  The transforms mix
- *                      the values of a whole input patch, so a SMALL output next to a very large activation carries
- *                      an error relative to the large one: on maps with 1 % of the entries 1000x the rest, elements
- *                      down to 1e-3 of the tensor's maximum were measured 2e-3 .. 4e-3 off relative to THEMSELVES
- *                      (F(4x4,3x3); F(3x3,3x3) 2e-3; the direct kernels 1e-4; tests/test_hostile_inputs_gpu.py).  The
- *                      decoder end to end on such features (100x outliers): 1.2e-3, where fp32 arithmetic without any
- *                      Winograd kernel measures 8.6e-4.
+ *   MPSR_WINOGRAD_AUTO (default) block3's atrous layers (one zero-padded 3x3 tile per pixel sub-grid) in sixteen
+ *                      products per tile, F(3x3,3x3) on the tiles-with-halos of blocks 1-2, F(4x4,3x3) / F(2x2,3x3) on
+ *                      the dense decoder layers wherever they are faster.  Error against float64 of the tensor's
+ *                      SCALE: 3e-7 / 3e-6 / 1.5e-5 / 1e-6 (a direct fp32 convolution: 2.5e-7 .. 5e-7) -- far inside the
+ *                      path's 1e-3 budget.  The transforms mix the values of a whole input patch, so a SMALL output
+ *                      next to a very large activation carries an error relative to the large one: on maps with 1 % of
+ *                      the entries 1000x the rest, elements down to 1e-3 of the tensor's maximum were measured
+ *                      2e-3 .. 4e-3 off relative to THEMSELVES under F(4x4,3x3), 0.5e-3 .. 2e-3 under F(3x3,3x3) with
+ *                      halos, 2e-4 in the sixteen-product form (the direct kernels 1e-4;
+ *                      tests/test_hostile_inputs_gpu.py).  The decoder end to end on such features (100x outliers):
+ *                      1.2e-3, where fp32 arithmetic without any Winograd kernel measures 8.6e-4.
  *   MPSR_WINOGRAD_OFF  direct / implicit-GEMM kernels everywhere (the upsampled convolutions keep their exact tap
- *                      GEMM): element-wise 5e-5 .. 1e-4 on the same inputs, at 1.28x the step time (18.2 vs 14.2 ms:
+ *                      GEMM): element-wise 5e-5 .. 1e-4 on the same inputs, at 1.33x the step time (17.8 vs 13.4 ms:
  *                      bench.py's `winograd_off_mode` object times it and measures both policies' errors).  For callers whose
  *                      activations are heavy-tailed AND who read small outputs individually. */
 enum { MPSR_WINOGRAD_AUTO = 0, MPSR_WINOGRAD_OFF = 1 };

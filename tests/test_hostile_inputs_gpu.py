@@ -9,7 +9,9 @@ operators), never the library itself.
 Measured (MI355X, r04) and asserted: the direct kernels, the pointwise kernel and the upsampled-conv tap GEMM keep every
 such element within 1e-3 of ITSELF (measured 1e-5 .. 2e-4).  The Winograd kernels do not on 1000x outliers: their
 transforms mix a whole patch, so a small output next to a huge activation carries an error relative to the huge one --
-F(4x4,3x3) 2e-3 .. 4e-3, F(3x3,3x3) 2e-3, bounded here at 1e-2, while their tensor-scale error stays at 7e-6.  The rule
+F(4x4,3x3) 2e-3 .. 4e-3, F(3x3,3x3) 2e-3, bounded here at 1e-2, while their tensor-scale error stays at 7e-6 (r05:
+block3's atrous layers left that group -- their zero-padded tiles run in sixteen products with constants {1, 1.5, 2}:
+2e-4 element-wise, held to 1e-3 again).  The rule
 that follows (include/monopsr_hip.h, mpsr_set_winograd_policy): MPSR_WINOGRAD_AUTO is the default -- the tensor-scale
 error is what the path's 1e-3 budget is about, and end to end on heavy-tailed features (100x outliers, last test) the
 decoder's small outputs are 1.2e-3 off where fp32 arithmetic alone, without any Winograd kernel, is 8.6e-4 off; a
@@ -17,7 +19,8 @@ caller that needs the last factor on every small output under such inputs select
 checks restores the direct kernels' 1e-4 per layer.
 
 Kernels covered: Winograd F(4x4,3x3) (csrc/winograd4.hip: transform constants up to 8 and 1/24, the decoder's conv2_2 /
-conv3_2), F(3x3,3x3) on atrous sub-grids (csrc/winograd3.hip, block3's conv2), the upsampled-conv tap GEMM + gather
+conv3_2), block3's conv2 on its atrous sub-grids (csrc/winograd3z.hip: sixteen products per zero-padded tile),
+F(3x3,3x3) on tiles with halos (csrc/winograd3.hip: blocks 1-2, small-batch decoder), the upsampled-conv tap GEMM + gather
 (csrc/upconv.hip, conv2_1 / conv3_1), the persistent pointwise kernel, and the whole decoder chain end to end.
 """
 import numpy as np
@@ -69,7 +72,7 @@ def _conv_ref(x, w, bias, rate=1, relu=True):
 CASES = [
     ("winograd F(4x4,3x3)", 2, 8, 24, 24, 256, 256, 1),
     ("winograd F(4x4,3x3)", 2, 4, 48, 48, 128, 128, 1),
-    ("winograd F(3x3,3x3) atrous", 3, 64, 12, 12, 256, 256, 4),
+    ("sixteen-product zero-padded tiles (block3, atrous)", 3, 64, 12, 12, 256, 256, 4),
     ("winograd F(3x3,3x3) tiles with halos (block2)", 3, 64, 12, 12, 128, 128, 2),
     ("winograd F(3x3,3x3) tiles with halos (block1)", 3, 64, 12, 12, 64, 64, 1),
     ("winograd F(3x3,3x3) tiles with halos (decoder, small batch)", 3, 8, 24, 24, 256, 256, 1),
@@ -104,7 +107,9 @@ def test_conv3x3_kernels_on_heavy_tailed_maps(name, wino, B, H, Wd, C, N, dil, r
     # than the policy switch -- other interpolation points for F(4x4,3x3) / F(3x3,3x3) simulated in float32 on these maps
     # (profiles/r05_winograd_points.txt): best case 0.6x of the current error, not the 4x needed -- so the bound stays, the
     # header / README say that the default misses an element-wise 1e-3 here by up to ~4x, and the configuration that
-    # keeps it (MPSR_WINOGRAD_OFF, next test) is timed in the bench line (`winograd_off_mode`).
+    # keeps it (MPSR_WINOGRAD_OFF, next test) is timed in the bench line (`winograd_off_mode`).  Later in r05 block3's
+    # case ("winograd F(3x3,3x3) atrous" until then, 1.4e-3 .. 2e-3 measured, bound 1e-2) moved to the sixteen-product
+    # kernel, measures 2.1e-4 .. 2.4e-4 (profiles/r05_hostile_inputs.txt) and is held to the original 1e-3 again.
     assert elem <= (1e-2 if name.startswith("winograd") else 1e-3), (name, elem)
 
 
@@ -137,7 +142,8 @@ def test_winograd_policy_off_restores_elementwise_accuracy(B, H, Wd, C, N, dil, 
     finally:
         _lib.set_winograd_policy("auto")
     print("plan kind %d: auto tensor %.2e element %.2e | off tensor %.2e element %.2e" % ((kind,) + auto + off))
-    assert auto[0] <= 1e-4 and auto[1] <= 1e-2
+    # (kind 4 at one tile per sub-grid is the sixteen-product kernel: 4.1e-4 measured, inside 1e-3 without the switch)
+    assert auto[0] <= 1e-4 and auto[1] <= (1e-3 if kind == 4 else 1e-2)
     assert off[0] <= 1e-5 and off[1] <= 1e-3
 
 
