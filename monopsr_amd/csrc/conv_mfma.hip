@@ -1024,7 +1024,7 @@ std::atomic<int> g_math{MATH_FP32};  // mpsr_set_conv_math (the default of calls
 inline int cur_math() { return mpsr::t_call_math >= 0 ? mpsr::t_call_math : g_math.load(); }
 inline int cur_wino_policy() { return mpsr::t_call_wino_policy >= 0 ? mpsr::t_call_wino_policy : g_wino_policy.load(); }
 std::atomic<int> g_atrous_wino2{1};  // mpsr_debug_set_atrous_wino2: F(2x2,3x3) on the sub-grids of atrous layers in the automatic rule
-std::atomic<int> g_atrous_wino2_min_pixels{12000};  // (one 40 x 152 map = 6080 pixels: equal or slower there -- too few workgroups; 288 vs 459 us at eight)
+std::atomic<int> g_atrous_wino2_min_pixels{12000};  // (two 40 x 152 maps; 288 vs 459 us at eight; the 256-channel layers from ONE map on: conv2d_winograd_choice)
 std::atomic<int> g_wino3_halo{1};    // mpsr_debug_set_wino3_halo: the tiled F(3x3,3x3) form (block2's atrous layers) in the automatic rule
 
 // Scratch a stream-K launch needs behind `ws`: two partial-tile slabs per workgroup, then one counter per tile.
@@ -1114,6 +1114,7 @@ extern std::atomic<int> g_wino4_split;
 size_t winograd3_scratch_floats(int C, int N);
 bool winograd3_applies(int H, int W, int C, int dilation);
 double winograd3_executed_flops(int B, int H, int C, int N, int dilation);
+int winograd3_form(int B, int H, int W, int C, int N, int dilation);
 int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu,
                       float *y, int N, int dilation, float *ws, size_t ws_floats, hipStream_t s,
                       const float *mask = nullptr);
@@ -1224,10 +1225,14 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
     // ... and, at batches too small for the F(4x4) kernel's 32-tile workgroups to fill the chip (the reference's own
     // 32 boxes per image: its rule wants 65536 pixels), the decoder's dense 3x3 layers as up to 16 x 16 tiles of 3x3:
     // 204 -> 79 us (24x24x256, B = 32), 115 -> 83 us (48x48x128)
+    // enough tiles to fill the chip -- except where the sixteen-product kernel serves the layer (one tile per sub-grid):
+    // it cuts small launches along K (winograd3z.hip, SPLIT) and is ahead of the implicit GEMM at every batch measured
+    // (29-32 us against 45-48 at 4 .. 32 instances, 38 against 72 at 48)
+    const long long min_tiles = (can3 && th == 1 && winograd3_form(B, H, W, C, N, dilation) == 2) ? 1 : 1024;
     const int th_max = !g_wino3_halo.load() ? 1 : dilation > 1 ? 2 : conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats) ? 4 : 16;
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
                                      th <= th_max && (dilation > 1 || th > 1) &&
-                                     (long long)B * dilation * dilation * th * th >= 1024 && C >= 64 && N >= 64);
+                                     (long long)B * dilation * dilation * th * th >= min_tiles && C >= 64 && N >= 64);
     return can3 && want3;
 }
 
@@ -1251,10 +1256,13 @@ int conv2d_winograd_choice(int B, int H, int W, int C, int N, int KH, int KW, in
                       ws_floats >= winograd_scratch_floats(C, N);
     const bool can4 = base && winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) &&
                       M64 * C * 4 < 0x7f000000LL;
+    // (one 40 x 152 map = 6080 pixels = 96 workgroups: the kernel cuts such launches along K -- winograd.hip, SPLIT --
+    // and is then ahead on the 256-channel layers, 61 vs 94 us; the 128-channel ones are equal, 35 us, and stay)
+    const long long atrous2_min = C >= 256 ? std::min(6000, g_atrous_wino2_min_pixels.load()) : g_atrous_wino2_min_pixels.load();
     // (the automatic choice is conv2d_takes_winograd4's -- network.hip asks it too)
     if (wino < 0) wino = split_k != 0 ? 0 : (base && conv2d_takes_winograd4(B, H, W, C, N, ws, ws_floats)) ? 2
                          : (base && M64 >= 65536 && C >= 64 && N >= 64 && g_tile_override.load() < 0) ? 1
-                         : (atrous2 && g_atrous_wino2.load() && M64 >= g_atrous_wino2_min_pixels.load() && C >= 64 && N >= 64 &&
+                         : (atrous2 && g_atrous_wino2.load() && M64 >= atrous2_min && C >= 64 && N >= 64 &&
                             g_tile_override.load() < 0 && g_class_override.load() < 0) ? 1 : 0;
     if (wino == 2 && can4) return 2;
     if ((wino == 1 || wino == 2) && can2) return 1;

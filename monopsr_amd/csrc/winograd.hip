@@ -50,6 +50,12 @@ struct WinoParams {
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes;
     unsigned long long *trace;  // -DWINO_TRACE builds: per-workgroup timestamps (tools/wino_trace.py)
+    // SPLIT instantiation of the eight-wave kernel (launches too small to fill the chip: one full image): K slices;
+    // slice k runs channel steps [k * steps, (k + 1) * steps) and stores PARTIAL outputs into part + k * yfloats
+    // (winograd3z.hip: winograd_finish_slices adds them in order, + bias, ReLU)
+    float *part;
+    int nslices, steps;
+    size_t yfloats;
 };
 
 // U[cb][pos][n][KC] = (G g G^T)[pos] for filter g = w[n][(ky*3+kx)*C + c], c = cb*KC + j.  One thread per (n, c).
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoParams p)
 // a wave keeps HALF the positions (4 of the 8 of each group: 128 accumulator registers); the fill is split the same
 // way -- a thread loads / transforms / stores 2 of its slot's 4 channels and 4 of a group's 8 filter rows -- and the
 // output transform, being linear, is done as two partial sums that the wave pair exchanges through LDS once.
+template <bool SPLIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv8_kernel(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -402,8 +409,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float *Bs = lds + 16 * MT * ROW;   // [16][NT][ROW]
     const int xcd = blockIdx.x & 7, l_ = blockIdx.x >> 3;
     const int nb = l_ % p.nblocks;
-    const int mb = (l_ / p.nblocks) * 8 + xcd;
+    int l2_ = l_ / p.nblocks, slice = 0;
+    if constexpr (SPLIT) {
+        slice = l2_ % p.nslices;
+        l2_ /= p.nslices;
+    }
+    const int mb = l2_ * 8 + xcd;
     if (mb >= p.mblocks) return;  // block-uniform
+    // (a slice's channel steps are reached by shifting the operands' byte offsets: the loop below counts from 0)
+    const unsigned a_slice = SPLIT ? (unsigned)(slice * p.steps) * KC * 4u : 0u;
     const int n0 = nb * NT, t0 = mb * MT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -428,14 +442,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int sx = 0; sx < 4; ++sx) {
                 const bool ok = t < p.T && y0 + r >= 0 && y0 + r < 2 * p.th && x0 + sx >= 0 && x0 + sx < 2 * p.tw;
                 const int yy = wt.a + p.dil * (y0 + r), xx = wt.b + p.dil * (x0 + sx);
-                aoff[r * 4 + sx] = ok ? ((unsigned)((wt.img * p.H + yy) * p.W + xx) * (unsigned)p.C + 4u * quad + 2u * ph) * 4u
+                aoff[r * 4 + sx] = ok ? ((unsigned)((wt.img * p.H + yy) * p.W + xx) * (unsigned)p.C + 4u * quad + 2u * ph) * 4u + a_slice
                                       : p.xbytes;
             }
     }
     // ---- B loader: thread = (filter row n, channel quad); it handles positions 4 ph .. 4 ph + 3 of a group
     const unsigned bstride = (unsigned)p.N * KC * 4u;
     const unsigned boff = n0 + (slot_id >> 2) < p.N
-        ? (unsigned)((n0 + (slot_id >> 2)) * KC + 4 * (slot_id & 3)) * 4u + 4u * (unsigned)ph * bstride : p.ubytes;
+        ? (unsigned)((n0 + (slot_id >> 2)) * KC + 4 * (slot_id & 3)) * 4u + 4u * (unsigned)ph * bstride +
+              (SPLIT ? (unsigned)(slice * p.steps) * 16u * bstride : 0u)
+        : p.ubytes;
 
     f32x2 pa[16];
     float4 pb[4];
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //                                                       26-29 request filter rows of g0(k+2)
     // (measured: spreading the requests over both halves is worth 4 % of the kernel; vmcnt retires in order, so a
     // store is never placed behind younger requests than the ones it needs)
-    const int nsteps = p.cblocks;
+    const int nsteps = SPLIT ? p.steps : p.cblocks;
 #pragma unroll
     for (int i = 0; i < 16; ++i) load_a1(1, nsteps > 1, i);
     compute(G0{}, [&](int slot) {
@@ -591,7 +607,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();  // every wave is done reading the A / B tiles
     float *xch = lds + (size_t)wq * (2 * 2 * 16 * 64);  // [target ph][value][element][lane]
     const int n = n0 + wn * 32 + (lane & 31);
-    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    const float bias = (!SPLIT && p.bias && n < p.N) ? p.bias[n] : 0.f;  // (SPLIT: partial sums; bias / ReLU in the finish)
+    float *ybase = SPLIT ? p.part + (size_t)slice * p.yfloats : p.y;
     float mine[16][2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -622,13 +639,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tt = t0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         const float *src = xch + (size_t)(ph * 2) * 16 * 64 + e * 64 + lane;
         float ya = mine[e][0] + src[0] + bias, yb = mine[e][1] + src[16 * 64] + bias;
-        if (p.relu) {
+        if (!SPLIT && p.relu) {
             ya = fmaxf(ya, 0.f);
             yb = fmaxf(yb, 0.f);
         }
         if (tt < p.T && n < p.N) {
             const WinoTile wt = wino_tile(p, tt);
-            float *o = p.y + ((size_t)(wt.img * p.H + wt.a + p.dil * (2 * wt.ty + ph)) * p.W + wt.b + 2 * p.dil * wt.tx) * p.N + n;
+            float *o = ybase + ((size_t)(wt.img * p.H + wt.a + p.dil * (2 * wt.ty + ph)) * p.W + wt.b + 2 * p.dil * wt.tx) * p.N + n;
             o[0] = ya;
             o[(size_t)p.dil * p.N] = yb;
         }
@@ -656,6 +673,11 @@ bool winograd_applies_dilated(int H, int W, int C, int N, int dilation)
 
 std::atomic<int> g_wino_waves{8};  // 4: the one-wave-per-SIMD kernel, 8: the two-waves-per-SIMD variant
 
+// winograd3z.hip: K slices of a small launch and the launch that adds them
+int winograd_slices(long long blocks, int want_blocks, int cblocks, int min_steps, size_t part_floats, size_t y_floats);
+int winograd_finish_slices(const float *part, const float *bias, float *y, size_t y_floats, int nslices, int N, int relu,
+                           hipStream_t s);
+
 int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w, const float *bias, int relu, float *y,
                      int N, float *ws, size_t ws_floats, hipStream_t s, int dilation)
 {
@@ -666,7 +688,7 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
                     winograd_scratch_floats(C, N));
     // (per call: the attribute belongs to the current device; cheap and idempotent)
     MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g_wino_waves.load() == 8
-                                                                          ? reinterpret_cast<const void *>(wino_conv8_kernel)
+                                                                          ? reinterpret_cast<const void *>(wino_conv8_kernel<false>)
                                                                           : reinterpret_cast<const void *>(wino_conv_kernel)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
     // the caller's filter cache (mpsr_net_opts), if the network entry point offered a slot for this layer: the
@@ -698,9 +720,32 @@ int conv3x3_winograd(const float *x, int B, int H, int W, int C, const float *w,
     p.trace = g_wino_trace;
     const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd: grid too large");
-    if (g_wino_waves.load() == 8)
-        hipLaunchKernelGGL(wino_conv8_kernel, dim3((unsigned)blocks), dim3(512), kLdsFloats * sizeof(float), s, p);
-    else
+    // launches too small to fill the chip (the full-image trunk's atrous layers at ONE image: 96 workgroups) are cut
+    // along K like the sixteen-product kernel's (winograd3z.hip): partial outputs behind the transformed filters in `ws`
+    p.part = nullptr; p.nslices = 1; p.steps = p.cblocks;
+    p.yfloats = (size_t)B * H * W * N;
+    if (g_wino_waves.load() == 8) {
+        float *part = ws;
+        size_t part_floats = ws_floats;
+        if (u == ws) {
+            const size_t off = align_up(winograd_scratch_floats(C, N), 64);
+            part = ws + off;
+            part_floats = ws_floats > off ? ws_floats - off : 0;
+        }
+        const bool splittable = N % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)part & 15) == 0 &&
+                                (!bias || ((uintptr_t)bias & 15) == 0);
+        const int slices = winograd_slices(blocks, 256, p.cblocks, 2, splittable ? part_floats : 0, p.yfloats);
+        if (slices > 1) {
+            p.part = part; p.nslices = slices; p.steps = p.cblocks / slices;
+            MPSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv8_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
+            hipLaunchKernelGGL(wino_conv8_kernel<true>, dim3((unsigned)(blocks * slices)), dim3(512),
+                               kLdsFloats * sizeof(float), s, p);
+            MPSR_CHECK_LAUNCH("wino_conv8_kernel");
+            return winograd_finish_slices(part, bias, y, p.yfloats, slices, N, relu, s);
+        }
+        hipLaunchKernelGGL(wino_conv8_kernel<false>, dim3((unsigned)blocks), dim3(512), kLdsFloats * sizeof(float), s, p);
+    } else
         hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), kLdsFloats * sizeof(float), s, p);
     MPSR_CHECK_LAUNCH("wino_conv_kernel");
     return MPSR_OK;

@@ -434,7 +434,7 @@ int launch_winograd3w(const float *x, int B, int H, int W, int C, const float *u
 // winograd3z.hip: the same layer in SIXTEEN products per tile (a one-tile sub-grid reads nothing outside itself: rank 4 per
 // dimension instead of F(3,3)'s 5), one wave owning all 16 positions of its tile block
 int launch_winograd3z(const float *x, int B, int H, int W, int C, const float *u, const float *bias, int relu, float *y,
-                      int N, int dilation, hipStream_t s, const float *mask);
+                      int N, int dilation, hipStream_t s, const float *mask, float *part, size_t part_floats);
 int launch_winograd3z_filter(const float *w, int N, int C, float *u, hipStream_t s);
 // mpsr_debug_set_wino3_form: -1 = by size, 0 = F(3x3,3x3) with positions shared by eight waves (this file), 1 = F(3x3,3x3)
 // with one wave per tile block (winograd3w.hip), 2 = the sixteen-product form (winograd3z.hip)
@@ -442,9 +442,9 @@ std::atomic<int> g_wino3_form{-1};
 
 // which kernel serves a layer that conv3x3_winograd3 takes: 0 / 1 / 2 as above.  One tile per sub-grid: the sixteen-product
 // form at EVERY batch size -- fewer products and the error of a direct convolution; below ~190 workgroups (B < 192 at
-// dilation 4) its one-wave-per-SIMD workgroups do not fill the chip and it is 5-7 us behind this file's kernel (76 vs 71
-// us per launch at B = 64), which is the price of one algorithm, one error bound, whatever the batch.  Tiles with halos
-// (th > 1) have real neighbours: this file's kernels.
+// dilation 4) its one-wave-per-SIMD workgroups do not fill the chip, so it cuts such launches along K (SPLIT
+// instantiation: 32 us at B = 32 where the unsplit kernel and this file's both need ~70-76).  Tiles with halos (th > 1)
+// have real neighbours: this file's kernels.
 int winograd3_form(int B, int H, int W, int C, int N, int dilation)
 {
     const int th = H / (3 * dilation);
@@ -524,7 +524,18 @@ int conv3x3_winograd3(const float *x, int B, int H, int W, int C, const float *w
     }
     // one tile per sub-grid and enough of them to give every CU a workgroup of four one-per-SIMD waves: the forms without
     // the epilogue exchange (winograd3z.hip: sixteen products; winograd3w.hip: F(3x3,3x3), identical bits to this file's)
-    if (form == 2) return launch_winograd3z(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
+    if (form == 2) {
+        // scratch for the K-split form of small launches (winograd3z.hip): what `ws` holds behind the transformed filters
+        // (all of it when they live in the caller's cache)
+        float *part = ws;
+        size_t part_floats = ws_floats;
+        if (u == ws) {
+            const size_t off = align_up(winograd3_scratch_floats(C, N), 64);
+            part = ws + off;
+            part_floats = ws_floats > off ? ws_floats - off : 0;
+        }
+        return launch_winograd3z(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask, part, part_floats);
+    }
     if (form == 1) return launch_winograd3w(x, B, H, W, C, u, bias, relu, y, N, dilation, s, mask);
     Wino3Params p;
     p.x = x; p.u = u; p.bias = bias; p.y = y; p.mask = mask;

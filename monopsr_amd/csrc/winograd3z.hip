@@ -19,6 +19,13 @@
 // fragments straight from the transformed filters seven positions ahead in a ring of eight.  All 256 accumulators carry
 // literal names a[16 q : 16 q + 15] inside inline-asm statements (see winograd3w.hip for why); tests/test_build_audit.py
 // checks the generated code.
+//
+// SPLIT instantiation (small batches: the reference's 32 boxes per image).  A wave's K loop is 2048 MFMAs long whatever
+// the batch, so a launch that cannot fill the chip takes ~76 us at ANY batch up to 128 (32 workgroups at B = 32).  There
+// the channel range is cut into slices: workgroup (tile block, channel block, slice) runs K / slices channels and stores
+// its PARTIAL 3x3 outputs (the output transform is linear) into its slice of a scratch tensor; a second small launch adds
+// the slices in a fixed order, applies bias / ReLU and writes y -- deterministic, no atomics, no zero-fill.
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -50,6 +57,9 @@ struct Wino3ZParams {
     int cblocks, nblocks, mblocks, relu;
     unsigned xbytes, ubytes, ybytes;
     FastDiv div_tpi, div_d;  // tiles per image = dil^2, dil
+    // SPLIT: K slices; slice k runs channel steps [k * steps, (k + 1) * steps) and stores into part + k * ybytes / 4
+    float *part;
+    int nslices, steps;
 };
 
 #ifdef W3Z_TRACE  // (timing builds only: tools/wino3w_trace.py) cycle stamps of the first eight workgroups' waves
@@ -122,9 +132,10 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // MASK: a data-gradient launch of the training path (p.mask = a tensor shaped like y; an output is kept where the mask is
 // positive: the ReLU gradient of the layer the gradient belongs to, applied in the store path)
-template <bool MASK>
+template <bool MASK, bool SPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino3z_conv_kernel(const Wino3ZParams p)
 {
+    static_assert(!(MASK && SPLIT), "the masked (training) launches are never split");
     using namespace f3z;
     constexpr int WM = 1, MT = 32, NT = 128;
     constexpr int APOS = MT * KC;    // floats per position of an A buffer
@@ -133,14 +144,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int xcd = blockIdx.x & 7, l_ = blockIdx.x >> 3;
     const int nb = l_ % p.nblocks;
-    const int mb = (l_ / p.nblocks) * 8 + xcd;
+    int l2_ = l_ / p.nblocks, slice = 0;
+    if constexpr (SPLIT) {
+        slice = l2_ % p.nslices;
+        l2_ /= p.nslices;
+    }
+    const int mb = l2_ * 8 + xcd;
     if (mb >= p.mblocks) return;  // block-uniform
     const int n0 = nb * NT, t0 = mb * MT;
     W3Z_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wave % WM, ni = wave / WM;
-    const int nsteps = p.cblocks, d = p.dil, tpi = d * d;
+    const int s0 = SPLIT ? slice * p.steps : 0;                 // first channel step of this workgroup
+    const int send = SPLIT ? s0 + p.steps : p.cblocks, d = p.dil, tpi = d * d;
 
     // ---- A producer: thread = (tile, channel of the step) for WM patches per step; nine 4-byte requests per patch
     const int ch = lane & 7;
@@ -241,9 +258,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: requests of step 0, the first B fragments, accumulators, A of step 0, requests of step 1
     static_for<WM>([&](auto rc) __attribute__((always_inline)) {
-        static_for<9>([&](auto Lc) __attribute__((always_inline)) { load_raw(0, rc, Lc); });
+        static_for<9>([&](auto Lc) __attribute__((always_inline)) { load_raw(s0, rc, Lc); });
     });
-    static_for<BPRE>([&](auto qc) __attribute__((always_inline)) { load_b(0, qc); });
+    static_for<BPRE>([&](auto qc) __attribute__((always_inline)) { load_b(s0, qc); });
     W3Z_CLAIM_ACC();
     static_for<16>([&](auto qc) __attribute__((always_inline)) { W3Z_ZERO16(16 * decltype(qc)::value); });
     static_for<WM>([&](auto rc) __attribute__((always_inline)) {
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         static_for<4>([&](auto ic) __attribute__((always_inline)) { horizontal(ic); });
 #pragma unroll
         for (int i = 0; i < 16; ++i) store_a(rc, 0, i);
-        static_for<9>([&](auto Lc) __attribute__((always_inline)) { load_raw(1, rc, Lc); });
+        static_for<9>([&](auto Lc) __attribute__((always_inline)) { load_raw(s0 + 1, rc, Lc); });
     });
     __syncthreads();
     load_a(0, ICZ<0>{});
@@ -281,11 +298,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    for (int s = 0; s < nsteps; s += 2) {
+    for (int s = s0; s < send; s += 2) {
         kstep(s, ICZ<0>{});
-        if (s < 32) W3Z_STAMP(2 + s);
+        if (s - s0 < 32) W3Z_STAMP(2 + s - s0);
         kstep(s + 1, ICZ<1>{});
-        if (s < 32) W3Z_STAMP(3 + s);
+        if (s - s0 < 32) W3Z_STAMP(3 + s - s0);
     }
     // the last MFMAs' results: 18 wait states before anything reads them (hipcc pads nothing behind inline asm)
     W3Z_STAMP(34);
@@ -295,9 +312,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- epilogue, lane-local: register e of every position belongs to tile (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the
     // wave's 32 and to channel lane & 31: A^T M A on the lane's own 16 values, bias, ReLU / mask, nine strided pixels out
     const int n = n0 + 32 * ni + (lane2 & 31);
-    const float bias_v = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    const float floor_v = p.relu ? 0.f : -__builtin_inff();  // ReLU as one max
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.ybytes, 0x00020000);
+    // (SPLIT: the slice's partial outputs, no bias, no activation: wino3z_finish_kernel)
+    const float bias_v = (!SPLIT && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    const float floor_v = (!SPLIT && p.relu) ? 0.f : -__builtin_inff();  // ReLU as one max
+    float *ydst = SPLIT ? p.part + (size_t)slice * (p.ybytes / 4) : p.y;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ydst, 0, (int)p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask), 0, MASK ? (int)p.ybytes : 0, 0x00020000);
     unsigned so[9];  // byte offset of output pixel (i, j) of a tile from its pixel (0, 0): so[3 j + i]
@@ -352,11 +371,60 @@ __global__ __launch_bounds__(256) void wino3z_filter_kernel(const float *__restr
 }
 }  // namespace
 
+namespace {
+// y = act(bias + sum of the K slices' partial outputs), slices added in index order; 16 bytes per thread
+__global__ __launch_bounds__(256) void wino3z_finish_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                            float *__restrict__ y, long long total4, long long slice4,
+                                                            int nslices, int N4, int relu)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 a = reinterpret_cast<const float4 *>(part)[i];
+    for (int k = 1; k < nslices; ++k) {
+        const float4 b = reinterpret_cast<const float4 *>(part)[i + k * slice4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) {
+        const float4 b = reinterpret_cast<const float4 *>(bias)[i % N4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (relu) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+    reinterpret_cast<float4 *>(y)[i] = a;
+}
+}  // namespace
+
 namespace mpsr {
+
+static std::atomic<int> g_w3z_split{-1};  // mpsr_debug_set_wino3z_split: -1 by launch size, 0 never, k > 1 = k slices
+
+// K slices of a launch: enough workgroups for every CU (up to `want_blocks`), at least `min_steps` channel steps each
+// and an even number of them, a power of two that divides the steps; 1 = not split.  (Depends on the batch only through
+// the workgroup count rounded up to whole XCD rounds.)  Shared with the F(2x2,3x3) kernel (winograd.hip).
+int winograd_slices(long long blocks, int want_blocks, int cblocks, int min_steps, size_t part_floats, size_t y_floats)
+{
+    const int forced = g_w3z_split.load();
+    if (forced == 0 || (y_floats & 3)) return 1;
+    int s = 1;
+    if (forced > 1) s = forced;
+    else
+        while (blocks * s * 2 <= want_blocks && s < 16) s *= 2;
+    while (s > 1 && (cblocks % (2 * s) != 0 || cblocks / s < min_steps || (size_t)s * y_floats > part_floats)) s /= 2;
+    return s;
+}
+
+int winograd_finish_slices(const float *part, const float *bias, float *y, size_t y_floats, int nslices, int N, int relu,
+                           hipStream_t s)
+{
+    const long long total4 = (long long)(y_floats / 4);
+    hipLaunchKernelGGL(wino3z_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, part, bias, y, total4,
+                       total4, nslices, N / 4, relu);
+    MPSR_CHECK_LAUNCH("wino3z_finish_kernel");
+    return MPSR_OK;
+}
 
 // launches the kernel on filters already transformed by wino3z_filter_one (wino3_filter.h: U[cb][16 positions][n][8])
 int launch_winograd3z(const float *x, int B, int H, int W, int C, const float *u, const float *bias, int relu, float *y,
-                      int N, int dilation, hipStream_t s, const float *mask)
+                      int N, int dilation, hipStream_t s, const float *mask, float *part, size_t part_floats)
 {
     using namespace f3z;
     Wino3ZParams p;
@@ -373,14 +441,26 @@ int launch_winograd3z(const float *x, int B, int H, int W, int C, const float *u
     p.ybytes = (unsigned)((long long)B * H * W * N * 4);
     p.div_tpi = make_fastdiv(dilation * dilation);
     p.div_d = make_fastdiv(dilation);
-    const long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
+    long long blocks = 8LL * ceil_div(p.mblocks, 8) * p.nblocks;
     if (blocks > 0x7fffffffLL) return fail(MPSR_ERR_UNSUPPORTED, "conv3x3_winograd3: grid too large");
+    const size_t y_floats = (size_t)B * H * W * N;
+    const bool splittable = part && N % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)part & 15) == 0 &&
+                            (!bias || ((uintptr_t)bias & 15) == 0);
+    p.nslices = mask ? 1 : winograd_slices(blocks, 256, p.cblocks, 4, splittable ? part_floats : 0, y_floats);
+    p.steps = p.cblocks / p.nslices;
+    p.part = part;
     const size_t ldsb = (size_t)2 * NP * MT * KC * sizeof(float);
     const void *kern = mask ? reinterpret_cast<const void *>(wino3z_conv_kernel<true>)
-                            : reinterpret_cast<const void *>(wino3z_conv_kernel<false>);
+                            : p.nslices > 1 ? reinterpret_cast<const void *>(wino3z_conv_kernel<false, true>)
+                                            : reinterpret_cast<const void *>(wino3z_conv_kernel<false>);
     MPSR_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     if (mask) hipLaunchKernelGGL((wino3z_conv_kernel<true>), dim3((unsigned)blocks), dim3(256), ldsb, s, p);
-    else hipLaunchKernelGGL((wino3z_conv_kernel<false>), dim3((unsigned)blocks), dim3(256), ldsb, s, p);
+    else if (p.nslices > 1) {
+        blocks *= p.nslices;
+        hipLaunchKernelGGL((wino3z_conv_kernel<false, true>), dim3((unsigned)blocks), dim3(256), ldsb, s, p);
+        MPSR_CHECK_LAUNCH("wino3z_conv_kernel");
+        return winograd_finish_slices(part, bias, y, y_floats, p.nslices, N, relu, s);
+    } else hipLaunchKernelGGL((wino3z_conv_kernel<false>), dim3((unsigned)blocks), dim3(256), ldsb, s, p);
     MPSR_CHECK_LAUNCH("wino3z_conv_kernel");
     return MPSR_OK;
 }
@@ -394,6 +474,8 @@ int launch_winograd3z_filter(const float *w, int N, int C, float *u, hipStream_t
 }
 
 }  // namespace mpsr
+
+extern "C" void mpsr_debug_set_wino3z_split(int slices) { mpsr::g_w3z_split = slices; }
 
 #ifdef W3Z_TRACE
 extern "C" int mpsr_debug_wino3z_trace(unsigned long long *host_out, int count)

@@ -540,6 +540,77 @@ def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     assert not torch.equal(got, direct) or C * N < 1024
 
 
+@pytest.mark.parametrize("B,H,Wd,C,N,dil,has_bias,relu", [
+    (1, 40, 152, 256, 256, 4, True, True), (1, 40, 152, 128, 128, 2, False, True), (2, 16, 16, 64, 72, 1, True, False),
+    (3, 8, 12, 128, 40, 2, True, True)])
+def test_conv2d_winograd_f2x2_k_split_of_small_launches(B, H, Wd, C, N, dil, has_bias, relu):
+    """csrc/winograd.hip, SPLIT instantiation of the eight-wave F(2x2,3x3) kernel: a launch that cannot fill the chip (the
+    full-image trunk's atrous layers at ONE image: 96 workgroups) runs its channel range as 2 .. 8 slices whose partial
+    outputs a finishing launch adds in slice order (+ bias, ReLU): every slice count against float64, deterministic."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    rng = np.random.default_rng(B * 31 + C + N + dil)
+    x = np.maximum(rng.standard_normal((B, H, Wd, C)), 0).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = _conv_ref(x, w, bias, None, dil, relu)
+    w_ok, _ = W.fold_conv(w)
+    lib = _lib.lib()
+    outs = {}
+    lib.mpsr_debug_set_conv_winograd(1)
+    try:
+        for slices in (0, 2, 4, -1):
+            lib.mpsr_debug_set_wino3z_split(slices)
+            run = lambda: dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+            outs[slices] = run()
+            assert torch.equal(outs[slices], run())
+            _close(outs[slices], ref, 1e-5, "F(2x2,3x3), %d K slices %s" % (slices, (B, H, Wd, C, N, dil)))
+    finally:
+        lib.mpsr_debug_set_wino3z_split(-1)
+        lib.mpsr_debug_set_conv_winograd(-1)
+    assert not torch.equal(outs[2], outs[0])  # (C >= 64: at least four channel steps, two slices exist)
+    assert any(torch.equal(outs[-1], outs[k]) for k in (0, 2, 4))
+
+
+@pytest.mark.parametrize("B,dil,C,N,has_bias,relu", [(32, 4, 256, 256, True, True), (8, 4, 64, 64, True, False),
+                                                      (33, 4, 128, 132, False, True), (5, 2, 256, 40, True, True),
+                                                      (1, 4, 256, 256, True, True)])
+def test_conv2d_sixteen_product_k_split_of_small_launches(B, dil, C, N, has_bias, relu):
+    """csrc/winograd3z.hip, SPLIT instantiation: a launch too small to fill the chip (the reference's 32 boxes per image)
+    cuts its channel range into 2 .. 16 slices, each workgroup stores partial outputs, a finishing launch adds them in
+    slice order + bias + ReLU.  Every slice count against float64 and against the unsplit kernel; deterministic; the
+    automatic choice is one of them."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    from monopsr_amd.core import weights as W
+    H = 3 * dil
+    rng = np.random.default_rng(B * 77 + C + N)
+    x = np.maximum(rng.standard_normal((B, H, H, C)), 0).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    w_ok, _ = W.fold_conv(w)
+    ref = _conv_ref(x, w, bias, None, dil, relu)
+    lib = _lib.lib()
+    outs = {}
+    lib.mpsr_debug_set_conv_winograd(3)
+    try:
+        for slices in (0, 2, 4, 8, 16, -1):
+            lib.mpsr_debug_set_wino3z_split(slices)
+            run = lambda: dn.conv2d(_dev(x), _dev(w_ok), _dev(bias) if has_bias else None, None, 3, 3, dil, relu, split_k=0)
+            outs[slices] = run()
+            assert torch.equal(outs[slices], run()), "not deterministic at %d slices" % slices
+            _close(outs[slices], ref, 2e-6, "sixteen products, %d K slices %s" % (slices, (B, dil, C, N)))
+    finally:
+        lib.mpsr_debug_set_wino3z_split(-1)
+        lib.mpsr_debug_set_conv_winograd(-1)
+    if C >= 64:  # (eight channel steps or more: two slices exist, and they add in another order than one K loop)
+        assert not torch.equal(outs[2], outs[0])
+    assert any(torch.equal(outs[-1], outs[k]) for k in (0, 2, 4, 8, 16))
+    if (B, C) == (32, 256):
+        assert torch.equal(outs[-1], outs[8])  # 32 workgroups -> 8 slices of four channel steps
+
+
 @pytest.mark.parametrize("B,dil,C,N,has_bias,relu,masked", [
     (8, 4, 64, 64, True, True, False), (3, 4, 32, 40, False, False, False), (1, 4, 16, 4, True, False, False),
     (5, 2, 48, 200, True, True, False), (64, 4, 256, 256, True, True, False), (7, 3, 16, 65, True, True, False),
