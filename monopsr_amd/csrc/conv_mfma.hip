@@ -1131,6 +1131,9 @@ int thin_input_conv(const float *x, int B, int H, int W, const float *w, const f
                     hipStream_t s);
 
 bool fc_rows_applies(long long M, int K, int N);
+bool fc_rows_split_applies(long long M, int K, int N, const float *bias, const float *y, const float *ws, size_t ws_floats);
+int fc_rows_split(const float *x, long long M, int K, const float *w, const float *bias, int relu, float *y, int N,
+                  float *ws, hipStream_t s);
 int fc_rows(const float *x, long long M, int K, const float *w, const float *bias, const float *residual, int relu,
             float *y, int N, hipStream_t s);
 
@@ -1313,6 +1316,11 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
         return conv1x1_pointwise(x, M64, C, w, bias, residual, relu, y, N, stream);
     if (conv2d_takes_fc_rows(H, W, M64, C, N, KH, KW, split_k))
         return fc_rows(x, M64, C, w, bias, residual, relu, y, N, stream);
+    // ... and with a K too long for that kernel's single workgroup per tile (img_fc, K = 18432) at few rows: its K-split form
+    if (H == 1 && W == 1 && KH == 1 && KW == 1 && !residual && split_k == 0 && pointwise_override() != 0 &&
+        cur_math() == MATH_FP32 && g_tile_override.load() < 0 && g_sched_override.load() < 0 &&
+        fc_rows_split_applies(M64, C, N, bias, y, ws, ws_floats))
+        return fc_rows_split(x, M64, C, w, bias, relu, y, N, ws, stream);
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y = y; p.ws = ws; p.ws_floats = ws ? ws_floats : 0;
     p.M = (int)M64; p.H = H; p.W = W; p.C = C; p.N = N; p.KH = KH; p.KW = KW; p.dil = dilation; p.relu = relu;

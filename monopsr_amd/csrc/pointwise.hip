@@ -505,22 +505,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (lane = (row, k half), 16 bytes: the four 8-k chunks of a 128-byte line are requested together, eight chunks in
 // flight per wave), no LDS in the K loop; the four partial tiles are summed through LDS and wave 0 applies bias /
 // residual / ReLU.
-template <int DUMMY>
+// SPLIT = 1 (img_fc at the reference's 32 boxes per image: 32 rows x K = 18432 -> N = 2048): K is longer than four
+// waves can stream (64 workgroups would read the 151 MB of weights), so blockIdx.y selects one of several K slabs and
+// the workgroup stores its partial tile into slab blockIdx.y of a scratch tensor; winograd_finish_slices (winograd3z.hip)
+// adds the slabs in order + bias + ReLU.  Every weight byte is read once per 32-row block: memory-bound.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ bias, const float *__restrict__ residual,
                                                       float *__restrict__ y, int M, int N, int K, int relu,
-                                                      unsigned xbytes, unsigned wbytes)
+                                                      unsigned xbytes, unsigned wbytes, int kslab)
 {
     __shared__ __attribute__((aligned(16))) float part[3][16][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntn = (N + 31) >> 5;
     const int r0 = (blockIdx.x / ntn) * 32, n0 = (blockIdx.x % ntn) * 32;
-    const int kper = K >> 2;            // K a multiple of 32: every wave gets whole 8-k chunks
+    const int kper = kslab >> 2;        // the slab (= K unless SPLIT) a multiple of 32: every wave gets whole 8-k chunks
     const int nch = kper >> 3;          // chunks per wave
     const int i = lane & 31, h = lane >> 5;
     const unsigned OOB = 0x80000000u;
-    const unsigned koff = (unsigned)(wave * kper + 4 * h) * 4u;
+    const unsigned koff = (unsigned)((SPLIT ? (int)blockIdx.y * kslab : 0) + wave * kper + 4 * h) * 4u;
     const unsigned aoff = r0 + i < M ? (unsigned)(r0 + i) * (unsigned)K * 4u + koff : OOB;
     const unsigned boff = n0 + i < N ? (unsigned)(n0 + i) * (unsigned)K * 4u + koff : OOB;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)xbytes, 0x00020000);
@@ -564,15 +568,16 @@ __global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ 
     if (wave > 0) return;
     // accumulator element e of a lane: row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31
     const int col = n0 + i;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    const float bv = (!SPLIT && bias && col < N) ? bias[col] : 0.f;
+    float *yo = SPLIT ? y + (size_t)blockIdx.y * M * N : y;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         float v = ((acc[e] + part[0][e][lane]) + part[1][e][lane]) + part[2][e][lane] + bv;
         if (row < M && col < N) {
-            if (residual) v += residual[(size_t)row * N + col];
-            if (relu) v = fmaxf(v, 0.f);
-            y[(size_t)row * N + col] = v;
+            if (!SPLIT && residual) v += residual[(size_t)row * N + col];
+            if (!SPLIT && relu) v = fmaxf(v, 0.f);
+            yo[(size_t)row * N + col] = v;
         }
     }
 }
@@ -716,9 +721,49 @@ int fc_rows(const float *x, long long M, int K, const float *w, const float *bia
     MPSR_REQUIRE(fc_rows_applies(M, K, N), "fc_rows: unsupported shape (M=%lld K=%d N=%d)", M, K, N);
     const unsigned grid = (unsigned)(((M + 31) / 32) * ((N + 31) / 32));
     hipLaunchKernelGGL(fc_rows_kernel<0>, dim3(grid), dim3(256), 0, s, x, w, bias, residual, y, (int)M, N, K, relu,
-                       (unsigned)(M * K * 4), (unsigned)((long long)N * K * 4));
+                       (unsigned)(M * K * 4), (unsigned)((long long)N * K * 4), K);
     MPSR_CHECK_LAUNCH("fc_rows_kernel");
     return MPSR_OK;
 }
 
+// winograd3z.hip
+int winograd_finish_slices(const float *part, const float *bias, float *y, size_t y_floats, int nslices, int N, int relu,
+                           hipStream_t s);
+
+std::atomic<int> g_fc_split_rows{96};  // mpsr_debug_set_fc_split_rows: the K-split few-row kernel up to this many rows (0: never)
+
+// K slabs of the split form for a long-K layer with few rows: enough workgroups to stream the weights from every CU
+static int fc_rows_slabs(long long M, int K, int N)
+{
+    const long long tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    int s = 1;
+    while (tiles * s < 512 && s < 16 && K % (64 * s) == 0) s *= 2;
+    return s;
+}
+
+// img_fc at small batches: few rows, K too long for the four waves of one workgroup (fc_rows_applies stops at 4096)
+bool fc_rows_split_applies(long long M, int K, int N, const float *bias, const float *y, const float *ws, size_t ws_floats)
+{
+    const int rows = g_fc_split_rows.load();
+    if (!(M > 0 && M <= rows && K > 4096 && K % 64 == 0 && N > 0 && N % 4 == 0 && ws && M * K * 4 < 0x7f000000LL &&
+          (long long)N * K * 4 < 0x7f000000LL))
+        return false;
+    const int slabs = fc_rows_slabs(M, K, N);
+    return slabs > 1 && (size_t)slabs * M * N <= ws_floats && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+           (!bias || ((uintptr_t)bias & 15) == 0);
+}
+
+int fc_rows_split(const float *x, long long M, int K, const float *w, const float *bias, int relu, float *y, int N,
+                  float *ws, hipStream_t s)
+{
+    const int slabs = fc_rows_slabs(M, K, N);
+    const dim3 grid((unsigned)(((M + 31) / 32) * ((N + 31) / 32)), (unsigned)slabs);
+    hipLaunchKernelGGL(fc_rows_kernel<1>, grid, dim3(256), 0, s, x, w, nullptr, nullptr, ws, (int)M, N, K, 0,
+                       (unsigned)(M * K * 4), (unsigned)((long long)N * K * 4), K / slabs);
+    MPSR_CHECK_LAUNCH("fc_rows_kernel");
+    return winograd_finish_slices(ws, bias, y, (size_t)M * N, slabs, N, relu, s);
+}
+
 }  // namespace mpsr
+
+extern "C" void mpsr_debug_set_fc_split_rows(int rows) { mpsr::g_fc_split_rows = rows; }

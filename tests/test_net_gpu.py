@@ -540,6 +540,39 @@ def test_conv2d_winograd3_atrous_vs_fp64(B, dil, C, N, has_bias, relu, th):
     assert not torch.equal(got, direct) or C * N < 1024
 
 
+@pytest.mark.parametrize("M,K,N,has_bias,relu", [(32, 18432, 2048, True, True), (5, 4608, 512, True, False),
+                                                  (64, 18432, 2048, False, True), (33, 8192, 100, True, True),
+                                                  (1, 18432, 2048, True, True)])
+def test_fc_few_rows_long_k_split_vs_fp64(M, K, N, has_bias, relu):
+    """img_fc at the reference's 32 boxes per image (csrc/pointwise.hip, fc_rows_kernel<1>): few rows, K = 18432 --
+    the few-row kernel with K cut into slabs over blockIdx.y and a finishing launch that adds the partial tiles in order
+    (+ bias, ReLU).  Against float64, against the stream-K kernel it replaces there (mpsr_debug_set_fc_split_rows(0)),
+    ragged rows / columns, deterministic."""
+    from monopsr_amd import _lib
+    from monopsr_amd.core import device_net as dn
+    rng = np.random.default_rng(M + K + N)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if has_bias else None
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + (bias.astype(np.float64) if has_bias else 0.0)
+    if relu:
+        ref = np.maximum(ref, 0)
+    lib = _lib.lib()
+    run = lambda: dn.conv2d(_dev(x).reshape(M, 1, 1, K), _dev(w), _dev(bias) if has_bias else None, None, 1, 1, 1, relu,
+                            split_k=0).reshape(M, N)
+    got = run()
+    assert torch.equal(got, run())
+    lib.mpsr_debug_set_fc_split_rows(0)
+    try:
+        other = run()
+    finally:
+        lib.mpsr_debug_set_fc_split_rows(96)
+    scale = np.abs(ref).max()
+    assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * scale
+    assert np.abs(other.cpu().numpy() - ref).max() <= 2e-6 * scale
+    assert not torch.equal(got, other)  # (it really is the other kernel)
+
+
 @pytest.mark.parametrize("B,H,Wd,C,N,dil,has_bias,relu", [
     (1, 40, 152, 256, 256, 4, True, True), (1, 40, 152, 128, 128, 2, False, True), (2, 16, 16, 64, 72, 1, True, False),
     (3, 8, 12, 128, 40, 2, True, True)])

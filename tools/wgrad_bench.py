@@ -24,6 +24,9 @@ SHAPES = [  # name, launches per step, H, W, C, N, k, dilation
     ("dec conv3_1 3x3 256->128", 1, 48, 48, 256, 128, 3, 1),
     ("dec conv3_2 3x3 128->128", 1, 48, 48, 128, 128, 3, 1),
     ("fc 18432->1024", 2, 1, 1, 18432, 1024, 1, 1),
+    # the decoder's upsampled layers in tap-GEMM form: a 1x1 weight gradient on the SOURCE map with 9 N outputs
+    ("dec conv2_1 tap GEMM 512->9x256", 1, 12, 12, 512, 2304, 1, 1),
+    ("dec conv3_1 tap GEMM 256->9x128", 1, 24, 24, 256, 1152, 1, 1),
 ]
 
 
