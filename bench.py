@@ -50,6 +50,14 @@ def _launch_ranks(argv):
             port = str(s.getsockname()[1])
     import signal
     procs = []
+    got_signal = []
+
+    def on_signal(signum, frame):  # a SIGTERM / SIGINT to the launcher goes to the ranks: none is left behind
+        got_signal.append(signum)
+    # (installed BEFORE the first rank exists: a signal that arrives while the ranks are being started must not take the
+    # launcher down by the default action and orphan them)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
     # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
     # cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument` (the task environment exports
     # it already; a value the caller set is kept)
@@ -74,12 +82,6 @@ def _launch_ranks(argv):
                 p.kill()  # the exact children started above, never a pattern
                 p.wait()
 
-    got_signal = []
-
-    def on_signal(signum, frame):  # a SIGTERM / SIGINT to the launcher goes to the ranks: none is left behind
-        got_signal.append(signum)
-    for sg in (signal.SIGTERM, signal.SIGINT):
-        signal.signal(sg, on_signal)
     # poll ALL ranks: the first one that exits non-zero (or a signal to this process) ends the others, which would
     # otherwise sit in the rendezvous or in an RCCL collective until its timeout
     codes = [None] * n
