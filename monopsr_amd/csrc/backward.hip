@@ -557,7 +557,8 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     if (B == 0) return MPSR_OK;
     MPSR_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     // a head with (at most) four output channels: reduce over the pixels on the vector ALU (thin_conv.hip)
-    if (mpsr::thin_wgrad_applies(B, H, W, C, N, KH, KW, dilation))
+    // (it reads dy as 16-byte pixels)
+    if (((uintptr_t)dy & 15) == 0 && mpsr::thin_wgrad_applies(B, H, W, C, N, KH, KW, dilation))
         return mpsr::thin_wgrad(x, dy, B, H, W, C, dw, db, mpsr::as_stream(stream));
     const long long M = (long long)B * H * W;
     MPSR_REQUIRE(M * C * 4 < 0xfffff000LL && M * N * 4 < 0xfffff000LL, "conv2d_wgrad: tensor exceeds 4 GiB");
