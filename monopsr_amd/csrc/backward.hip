@@ -577,6 +577,16 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     const int msteps_total = mpsr::ceil_div(p.M, WG_K);
     int slices = g_wgrad_target / (tiles * taps > 0 ? tiles * taps : 1);  // aim at one round of resident workgroups
     if (slices < 1) slices = 1;
+    // XCD-aware order (a group = the tiles of one pixel slice, all on one XCD): whole groups must fill an XCD's share of
+    // the round.  18 tiles x 42 slices put 6 groups = 108 workgroups on two of the XCDs' 96 slots -- a second round for
+    // 12 of them: the decoder's tap-GEMM weight gradients ran at 73 / 93 TFLOP/s where the same kernel without the order
+    // reaches 118 / 119.  So: as many whole groups per XCD as fit, and with fewer than two the plain order.
+    bool group_ok = true;
+    if (taps == 1 && tiles > 1) {
+        const int per_xcd = (g_wgrad_target / 8) / tiles;
+        if (per_xcd >= 2) slices = 8 * per_xcd;
+        else group_ok = false;
+    }
     if (slices > msteps_total) slices = msteps_total;
     p.splits = slices;
     p.per_tap = taps <= MAX_TAPS;
@@ -604,7 +614,7 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
         }
         groups = blocks / tiles;
     }
-    p.grouped = g_wgrad_grouped && groups >= 8 && tiles > 1;
+    p.grouped = g_wgrad_grouped && group_ok && groups >= 8 && tiles > 1;
     p.ngroups = (int)groups;
     if (p.grouped) blocks = (groups + 7) / 8 * 8 * tiles;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, mpsr::as_stream(stream), p);
