@@ -57,6 +57,20 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef PWS_WIDE
 #define PWS_WIDE 0
 #endif
+// Cache-policy bits of the residual loads and of the result stores: 2 = non-temporal.  The residual passes through ONCE
+// (151 MB on block3's conv3) next to operands that are re-read for the whole launch -- the 1 MB of filters by every
+// tile, a row group's activations by all its column blocks: marked streaming it stops evicting those from the 4 MB L2.
+// Step, interleaved on one board, three boards: 13.50 -> 13.41 ms (-1.2 %) with the residual loads alone.  The result
+// stores are a smaller and mixed effect: streaming them helps the launches WITHOUT a residual (conv1 / shortcut / tap
+// GEMMs: 13.41 -> 13.39) and costs on conv3 (its result is the next launch's input: 13.43 with every store streaming),
+// hence the default below.  The same hint on the F(4x4,3x3) / sixteen-product kernels' stores (W4_NT, W3Z_STORE_AUX)
+// measured +0.08 / +0.05 ms, on the upsampling gather's loads and stores (UPC_NT) equal: they stay off.
+#ifndef PWS_STORE_AUX
+#define PWS_STORE_AUX (RES ? 0 : 2)
+#endif
+#ifndef PWS_RES_AUX
+#define PWS_RES_AUX 2
+#endif
 #ifndef PWS_WSTEP
 #define PWS_WSTEP 16  // wide form: MFMA slots between two stores of the previous tile (16: three per stage, four stages)
 #endif
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 : (unsigned)(RES_OFF + (tid >> 5) * 512 + (tid & 31) * 16);
     float4 rst[6];
     auto load_r = [&](RowRef rr, int jj) __attribute__((always_inline)) {
-        rst[jj % 6] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_at(rr, 8 * jj, p.N), rvoff, 0, 0));
+        rst[jj % 6] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_at(rr, 8 * jj, p.N), rvoff, 0, PWS_RES_AUX));
     };
     auto store_r = [&](int jj) __attribute__((always_inline)) {
         *reinterpret_cast<float4 *>(lds + ((WIDE && (jj & 1)) ? (rwoff ^ 128u) : rwoff) + jj * 4096) = rst[jj % 6];
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     } else if constexpr (SE0 >= 0) if (D % SSTEP == 1 && SE0 + D / SSTEP < 16 * WT) {
                         const int q = (SE0 + D / SSTEP) / 16, e = (SE0 + D / SSTEP) % 16;
                         __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET ^ 1>{}, q, e),
-                                                              rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+                                                              rsrc_at(yp, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, PWS_STORE_AUX);
                         if constexpr (EMIT) if (e == 15) emit_bits(IC<SET ^ 1>{}, q, r0p, plive);
                     }
 #endif
@@ -476,7 +490,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 16; ++e)
                 {
                     __builtin_amdgcn_raw_buffer_store_b32(out_bits(IC<SET>{}, q, e),
-                                                          rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, 0);
+                                                          rsrc_at(yl, 32 * q + (e & 3) + 8 * (e >> 2), p.N), evoff, 0, PWS_STORE_AUX);
                     if constexpr (EMIT) if (e == 15) emit_bits(IC<SET>{}, q, r0s, r0s < p.M);
                 }
         }

@@ -60,6 +60,10 @@ struct UpcParams {
     float hscale, wscale;
 };
 
+// cache policy of the gather's z loads (bit 0) and result stores (bit 1): 1 = non-temporal (A/B builds)
+#ifndef UPC_NT
+#define UPC_NT 0
+#endif
 constexpr int kPf = 8;  // float4 registers per thread that carry source pixels on their way into LDS
 std::atomic<int> g_upconv_band{0};  // mpsr_debug_set_upconv_band: output rows per band of the rolling window (0 = 8)
 
@@ -107,7 +111,11 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
             // load, or HIP's float4 struct as the element type, sends the register array to scratch memory)
             const int pix = first + lgrp + j * lgroups;
             const bool live = loader && pix < npix;
+#if UPC_NT & 1
+            pf[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(live ? zp + ((size_t)ra * p.w + pix) * PART + 4 * lpiece : zp));
+#else
             pf[j] = *reinterpret_cast<const f32x4 *>(live ? zp + ((size_t)ra * p.w + pix) * PART + 4 * lpiece : zp);
+#endif
         }
     };
     // (row, col) = position of this thread's pixel `first + lgrp` relative to row ra, kept by the caller
@@ -210,7 +218,11 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
             }
             float *o = OUT_C8 ? p.y + ((((size_t)b * (p.N / 8) + blk) * p.H + y) * p.W + x) * 8 + 4 * half
                               : p.y + (((size_t)b * p.H + y) * p.W + x) * p.N + n0 + 4 * half;
+#if UPC_NT & 2
+            __builtin_nontemporal_store(f32x4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4 *>(o));
+#else
             *reinterpret_cast<float4 *>(o) = acc;
+#endif
         }
         if (k + 1 == nbands) break;
         __syncthreads();  // every thread has finished reading this band's rows: the ring may be overwritten

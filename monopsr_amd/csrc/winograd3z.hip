@@ -93,6 +93,9 @@ __device__ __forceinline__ void static_for(F &&f)
 // which hipcc does not pad for inline asm -- the operands here are written by LDS / buffer loads only, and
 // tests/test_build_audit.py checks the compiled kernel for a vector-ALU write of an operand in the two instructions in
 // front of each MFMA; a blanket s_nop 1 measured 1 % of the K loop)
+#ifndef W3Z_STORE_AUX
+#define W3Z_STORE_AUX 0  // cache policy of the result stores: 2 = non-temporal (A/B builds)
+#endif
 #ifdef W3Z_PAD_NOP
 #define W3Z_PAD "s_nop 1\n\t"
 #else
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 3; ++i) {
                 float v = fmaxf(yv[i] + bias_v, floor_v);
                 if constexpr (MASK) v = mk[3 * j + i] > 0.f ? v : 0.f;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voff, so[3 * j + i], 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voff, so[3 * j + i], W3Z_STORE_AUX);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // (one register column at a time: hipcc otherwise hoists all 256 reads)

@@ -131,6 +131,9 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+#ifndef W4_NT
+#define W4_NT 0  // 1: the result leaves through non-temporal stores (A/B builds)
+#endif
 #ifndef W4_SPREAD
 #define W4_SPREAD 0
 #endif
@@ -481,7 +484,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int yy = 0; yy < 4; ++yy) {
                     float v = yv[yy] + bias2[h];
                     if (p.relu) v = fmaxf(v, 0.f);
+#if W4_NT
+                    if (ok) __builtin_nontemporal_store(v, &o[((size_t)yy * p.W + xx) * pstride]);
+#else
                     if (ok) o[((size_t)yy * p.W + xx) * pstride] = v;
+#endif
                 }
             }
         }

@@ -252,31 +252,36 @@ def test_captured_step_trains_like_the_eager_step():
         return out
     data = batches()
     runs = {}
-    for graphed in (False, True):
+    for kind in ("eager", "eager again", "graph"):
         net = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
         tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
-        if graphed:
+        if kind == "graph":
             tr.capture_step(warmup=2)
         losses = [float(tr.step(s)) for s in data]
         torch.cuda.synchronize()
         assert tr.global_step == steps and net.step_count == steps
-        runs[graphed] = (losses, net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), tr.optimizer.shadow.clone())
-    assert tr._graph.graph is not None  # steps 4..8 of the second run were replays
-    # (the weight gradient's atomics differ in the last bits from run to run and Adam's m / sqrt(v) amplifies that on
-    # small gradients: eager against eager shows the same spread.  A replay that ignored the new sample, the new learning
-    # rate or the moving average would be off by tens of percent in these measures.)
-    le, lg = runs[False][0], runs[True][0]
-    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(le[:1], lg[:1])), (le, lg)
-    assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+        runs[kind] = (losses, net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), tr.optimizer.shadow.clone())
+    assert tr._graph.graph is not None  # steps 4..8 of the last run were replays
+    # The weight gradient's atomics differ in the last bits from run to run and Adam's m / sqrt(v) amplifies that on small
+    # gradients, so two EAGER runs already differ after eight steps -- by how much varies from run to run (fixed bounds
+    # on graph-vs-eager failed about one run in five).  The captured run is therefore held to a few times the spread of
+    # the two eager runs measured right here.  A replay that ignored the new sample, the new learning rate or the moving
+    # average would be off by tens of percent in these measures: orders of magnitude beyond that spread.
+    le, le2, lg = runs["eager"][0], runs["eager again"][0], runs["graph"][0]
+    assert abs(le[0] - lg[0]) <= 1e-6 * abs(le[0]), (le, lg)  # (the first forward pass has no atomics in front of it)
+    spread = max(abs(a - b) / abs(a) for a, b in zip(le, le2))
+    assert all(abs(a - b) <= (4 * spread + 2e-3) * abs(a) for a, b in zip(le, lg)), (le, le2, lg)
     net0 = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
     p0 = net0.params.clone()
-    for i, name in enumerate(("params", "average"), start=1):
-        a, b = runs[False][1 if name == "params" else 4] - p0, runs[True][1 if name == "params" else 4] - p0
-        rel = float((a - b).norm() / a.norm())
-        assert rel <= 0.03, (name, rel)
-    for i, name in ((2, "adam_m"), (3, "adam_v")):
-        a, b = runs[False][i], runs[True][i]
-        assert float((a - b).norm() / a.norm()) <= 0.10, name
+
+    def rel(i, other, shift):
+        a, b = runs["eager"][i] - shift, runs[other][i] - shift
+        return float((a - b).norm() / a.norm())
+    for i, name, floor in ((1, "params", 0.01), (4, "average", 0.01), (2, "adam_m", 0.03), (3, "adam_v", 0.03)):
+        shift = p0 if i in (1, 4) else 0.0
+        ee, ge = rel(i, "eager again", shift), rel(i, "graph", shift)
+        assert ge <= 4 * ee + floor, (name, ee, ge)
+        assert ge <= 0.5, (name, ge)  # (and in absolute terms nowhere near a replay that ignored an input)
     # a sample of another shape is refused, not silently read through the captured tensors
     bad = dict(data[0], rgb_image_crops=data[0]["rgb_image_crops"][:2])
     with pytest.raises(ValueError):
