@@ -64,7 +64,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // stores are a smaller and mixed effect: streaming them helps the launches WITHOUT a residual (conv1 / shortcut / tap
 // GEMMs: 13.41 -> 13.39) and costs on conv3 (its result is the next launch's input: 13.43 with every store streaming),
 // hence the default below.  The same hint on the F(4x4,3x3) / sixteen-product kernels' stores (W4_NT, W3Z_STORE_AUX)
-// measured +0.08 / +0.05 ms, on the upsampling gather's loads and stores (UPC_NT) equal: they stay off.
+// measured +0.08 / +0.05 ms, on their transformed-filter loads +0.05 / +0.09 (W4_BAUX, W3Z_BAUX), on F(4x4,3x3)'s patch
+// loads +0.13 (W4_AAUX), on the upsampling gather's loads and stores (UPC_NT) equal: everything that is read twice or
+// read back at once wants the default policy; they stay off.
 #ifndef PWS_STORE_AUX
 #define PWS_STORE_AUX (RES ? 0 : 2)
 #endif

@@ -93,6 +93,9 @@ __device__ __forceinline__ void static_for(F &&f)
 // which hipcc does not pad for inline asm -- the operands here are written by LDS / buffer loads only, and
 // tests/test_build_audit.py checks the compiled kernel for a vector-ALU write of an operand in the two instructions in
 // front of each MFMA; a blanket s_nop 1 measured 1 % of the K loop)
+#ifndef W3Z_BAUX
+#define W3Z_BAUX 0  // cache policy of the transformed-filter loads: 2 = non-temporal (A/B builds)
+#endif
 #ifndef W3Z_STORE_AUX
 #define W3Z_STORE_AUX 0  // cache policy of the result stores: 2 = non-temporal (A/B builds)
 #endif
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (step > 0) return;
 #endif
         const unsigned so = ((unsigned)step * (unsigned)NP + (unsigned)q) * bpstride;
-        fb[cB(q)] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, bvoff, so, 0));
+        fb[cB(q)] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, bvoff, so, W3Z_BAUX));
     };
     // ---- A fragments: lane = (tile = lane & 31 of the wave's 32, k half = lane >> 5)
     const float *ard = lds + (32 * mi + (lane & 31)) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1));

@@ -131,6 +131,12 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+#ifndef W4_BAUX
+#define W4_BAUX 0  // cache policy of the transformed-filter loads / the patch loads: 2 = non-temporal (A/B builds)
+#endif
+#ifndef W4_AAUX
+#define W4_AAUX 0
+#endif
 #ifndef W4_NT
 #define W4_NT 0  // 1: the result leaves through non-temporal stores (A/B builds)
 #endif
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                   : (unsigned)((r * p.W + s) * p.C + (live ? step : 0) * KC) * 4u;
         pa[6 * r + s] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rr, voffc[r == 0 ? 0 : r == 5 ? 2 : 1][s == 0 ? 0 : s == 5 ? 2 : 1],
-                                                        so, 0));
+                                                        so, W4_AAUX));
     };
     // B^T applied to six values in place, in three parts of four operations (parts 0 and 1 read the original values,
     // part 2 finishes from part 0's temporaries)
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
         const unsigned so = ((unsigned)(live ? step : 0) * 36u + (unsigned)(gpos + 6 * u + j)) * bpstride;
-        fb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, 0));
+        fb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, W4_BAUX));
     };
 
     // ---- A fragment address: row = lane & 31 (tile), k half = lane >> 5
@@ -565,7 +571,7 @@ __device__ __forceinline__ void wino4s_body(const Wino4Params &p, const int mb, 
                                   : (unsigned)((r * p.W + s) * p.C + (live ? step : 0) * KC) * 4u;
         pa[6 * r + s] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rr, voffc[r == 0 ? 0 : r == 5 ? 2 : 1][s == 0 ? 0 : s == 5 ? 2 : 1],
-                                                        so, 0));
+                                                        so, W4_AAUX));
     };
     float ta, tb, tc, te;
     // column s of the patch -> rows 3 half .. 3 half + 2 of B^T d, left in rows 0..2; two parts of three operations
@@ -625,7 +631,7 @@ __device__ __forceinline__ void wino4s_body(const Wino4Params &p, const int mb, 
         const __amdgpu_buffer_rsrc_t rr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, live ? (int)p.ubytes : 0, 0x00020000);
         const unsigned so = ((unsigned)(live ? step : 0) * 36u + (unsigned)(gpos + 6 * u + j)) * bpstride;
-        fb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, 0));
+        fb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, bvoff, so, W4_BAUX));
     };
     const float *ard = lds + 3 * jb * APOS + (lane & 31) * 8 + 4 * ((lane >> 5) ^ (((lane & 31) >> 3) & 1));
     float4 fa[3];
