@@ -143,12 +143,14 @@ class _ConstantLr:
 
 class _StepGraph:
     """InstanceTrainer.capture_step(): eager warm-up calls, one captured call, then replays (see there)."""
+    TICKS = 96  # eager launches on the caller's stream in front of every call (step())
 
     def __init__(self, trainer, warmup):
         self.tr, self.left = trainer, max(1, int(warmup))
         dev = trainer.net.params.device
         self.side = torch.cuda.Stream(device=dev)  # capture needs a non-default stream; the scratch caches are per stream
         self.lr_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self._tick = torch.zeros((), dtype=torch.float32, device=dev)  # (see step(): eager launches in front of every call)
         self.graph = self.static = self.loss = None
 
     def _copy_in(self, sample):
@@ -166,6 +168,17 @@ class _StepGraph:
     def step(self, sample):
         tr = self.tr
         main = torch.cuda.current_stream()
+        # Workaround, measured on this stack (ROCm 7.2, torch 2.10+rocm7.0; tools/graph_replay_probe.py): a replay of this
+        # ~1100-node graph that directly follows a device-wide synchronisation (a .cpu(), a checkpoint save / restore, an
+        # evaluation pass) after earlier replays came back with its FORWARD intact and scattered weight gradients
+        # non-finite in 10-30 % of the cases -- whichever kernels the step uses (every A/B switch of the library tried),
+        # eager steps never; a synchronisation or a spin kernel in front of the replay changes nothing.  Eager launches on
+        # the caller's stream in front of EVERY call of this method -- the warm-up calls and the capturing call included:
+        # in front of the replays alone they do not help (9 bad of 40) -- make it go away: 0 bad of 280 over the
+        # scenarios that failed (8 launches: 3 of 40; 64: 0 of 40).  The cause sits below this package, in how the graph
+        # is captured / launched around a synchronisation; the launches cost ~0.2 ms per step.
+        for _ in range(self.TICKS):
+            self._tick.add_(0.0)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             if self.graph is None and self.left > 0:  # eager, on the capturing stream
@@ -297,7 +310,11 @@ class InstanceTrainer:
         create the moving average and are the captured call); every later call copies the sample into the captured
         call's tensors, writes the step's learning rate where the captured Adam launch reads it and replays.  Shapes
         and dtypes of the sample must stay those of the first call.  Single-process training only: a data-parallel
-        step exchanges gradients through torch.distributed while backward runs and stays eager."""
+        step exchanges gradients through torch.distributed while backward runs and stays eager.
+        Two things to know before choosing it (r05): it no longer beats the eager step in time (52.2 vs 51.1 ms: the
+        eager launches are back to back by now), and replays of a graph this large need the workaround in
+        _StepGraph.step() on this ROCm / torch stack -- without it a replay that follows a device-wide synchronisation
+        returned non-finite gradients in 10-30 % of the cases (tools/graph_replay_probe.py)."""
         if self.reducer._active():
             raise RuntimeError("capture_step(): data-parallel steps stay eager (the bucketed all-reduce is issued "
                                "from Python while backward runs)")

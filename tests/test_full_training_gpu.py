@@ -227,7 +227,9 @@ def test_captured_step_trains_like_the_eager_step():
     B, div, steps = 4, 4, 8
     cfg = config_utils.default_config()
     opt = cfg.train_config.optimizer.adam_optimizer
-    opt.learning_rate_type, opt.initial_learning_rate = 'exponential_decay', 2e-4
+    # (2e-5: at ten times that rate the loss of this random-target problem jumps between 1.7e3 and 4.9e4 from step to
+    # step, two eager runs drift apart by percents within eight steps and a ninth step occasionally overflows)
+    opt.learning_rate_type, opt.initial_learning_rate = 'exponential_decay', 2e-5
     opt.decay_steps, opt.decay_factor, opt.staircase = 2, 0.8, True
     opt.use_moving_average, opt.moving_average_decay = True, 0.9
 
