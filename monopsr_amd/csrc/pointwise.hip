@@ -70,6 +70,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef PWS_STORE_AUX
 #define PWS_STORE_AUX (RES ? 0 : 2)
 #endif
+#ifndef PWS_A_AUX
+#define PWS_A_AUX 0  // the activations' loads (A/B builds): streaming them costs +0.2 .. +0.36 ms -- every row group is read
+                     // by all of its column blocks and wants to stay in L2
+#endif
 #ifndef PWS_RES_AUX
 #define PWS_RES_AUX 2
 #endif
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float4 stg[WT];
     auto load_a = [&](RowRef xr, int stage, int j) __attribute__((always_inline)) {
         stg[j] = __builtin_bit_cast(
-            float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_at(xr, 32 * j, p.K), avoff, stage * (KS * 4), 0));
+            float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_at(xr, 32 * j, p.K), avoff, stage * (KS * 4), PWS_A_AUX));
     };
     auto store_a = [&](int buf, int j) __attribute__((always_inline)) {
         *reinterpret_cast<float4 *>(lds + buf * STAGE_B + j * TILE_B + awoff) = stg[j];
