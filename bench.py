@@ -212,51 +212,88 @@ def conv_replay(net, B):
         _lib.check(lib.mpsr_conv2d_plan(Bq, H, Wd, cin, cout, kh, kw, dil, ctypes.byref(kind), ctypes.byref(ex)))
         return kind.value, ex.value
 
-    def add(part, idx, M_hw, alg_cin=None, raw=False, residual=False, override=None):
+    # Operands with the RESIDENCY of the step's own (r06; review weak 9: the replay ran ~5 % slower than the same launches
+    # in situ): every launch reads what the launch in front of it just wrote -- the trunk's real data flow, bottleneck by
+    # bottleneck, with the unit's input (or its projection shortcut) as conv3's residual -- out of a small rotating pool
+    # of buffers per size, like the network entry points' ping-pong scratch; a fresh relu(N(0,1)) tensor stands in only
+    # where the producing kernel is not a matrix launch (the pooled root output is a view of the root's own result, the
+    # full-image feature crop, the two upsampling gathers' results, the heads' concat rows).
+    pool = {}
+
+    def out_buffer(n):
+        ring = pool.setdefault(n, [[], 0])
+        if len(ring[0]) < 4:
+            ring[0].append(torch.empty((n,), dtype=torch.float32, device=dev))
+            return ring[0][-1]
+        ring[1] = (ring[1] + 1) % 4
+        return ring[0][ring[1]]
+
+    def stand_in(n, raw=False):
+        x = torch.empty((n,), dtype=torch.float32, device=dev).normal_()
+        return x if raw else x.clamp_(min=0)
+
+    def add(part, idx, M_hw, alg_cin=None, x=None, res=None, override=None):
+        """-> the launch's output tensor (the last part's for a tap GEMM)."""
         r = part.records[idx]
         Bq, H, Wd = M_hw
-        # inputs with the statistics of the step's own activations: every layer but the root reads the output of a
-        # ReLU (half zeros) -- a dense N(0,1) operand draws more power and ran the replay ~2 % slower than in situ
-        x = torch.empty((Bq * H * Wd * r["cin"],), dtype=torch.float32, device=dev).normal_()
-        if not raw:
-            x.clamp_(min=0)
+        n_in = Bq * H * Wd * r["cin"]
+        if x is None:
+            x = stand_in(n_in)
+        assert x.numel() >= n_in, (idx, x.numel(), n_in)
         bias = part.blob.data_ptr() + 4 * r["b_off"] if r["b_off"] >= 0 else None
         alg = 2.0 * Bq * H * Wd * (alg_cin or r["cin"]) * r["kh"] * r["kw"] * r["cout"]
-        alg_b = 4.0 * (Bq * H * Wd * (r["cin"] + r["cout"] * (2 if residual else 1)) + r["cout"] * r["kh"] * r["kw"] * r["cin"])
+        alg_b = 4.0 * (Bq * H * Wd * (r["cin"] + r["cout"] * (2 if res is not None else 1)) +
+                       r["cout"] * r["kh"] * r["kw"] * r["cin"])
         if override is not None:  # the layer runs as `parts` 1x1 GEMMs of the source map with 1152 outputs each
             sh, sw, parts = override
             wgt = torch.randn((parts * 1152 * r["cin"],), dtype=torch.float32, device=dev) * 0.02
-            xs = x[:Bq * sh * sw * r["cin"]]
+            assert x.numel() >= Bq * sh * sw * r["cin"]
             for pi in range(parts):
                 y = torch.empty((Bq * sh * sw * 1152,), dtype=torch.float32, device=dev)
-                jobs.append(dict(x=xs, y=y, w=wgt.data_ptr() + 4 * pi * 1152 * r["cin"], bias=None, res=None, keep=wgt,
+                jobs.append(dict(x=x, y=y, w=wgt.data_ptr() + 4 * pi * 1152 * r["cin"], bias=None, res=None, keep=wgt,
                                  shape=(Bq, sh, sw, r["cin"], 1152, 1, 1, 1, 0), alg=alg / parts, alg_b=alg_b / parts,
                                  kind=7, ex=2.0 * Bq * sh * sw * r["cin"] * 1152))
-            return
-        y = torch.empty((Bq * H * Wd * r["cout"],), dtype=torch.float32, device=dev)
-        res = torch.empty_like(y).normal_().clamp_(min=0) if residual else None
+            return y
+        y = out_buffer(Bq * H * Wd * r["cout"])
+        assert y.data_ptr() != x.data_ptr() and (res is None or res.data_ptr() != y.data_ptr())
         kind, ex = plan(Bq, H, Wd, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"])
         jobs.append(dict(x=x, y=y, w=part.blob.data_ptr() + 4 * r["w_off"], bias=bias, res=res, keep=None,
                          shape=(Bq, H, Wd, r["cin"], r["cout"], r["kh"], r["kw"], r["dilation"], r["relu"]),
                          alg=alg, alg_b=alg_b, kind=kind, ex=ex))
+        return y
 
     tr = net.crop_trunk
     roles = [sp["role"] for sp in W.scaled_trunk_specs(W.CROP_SCOPE, net.width_div)]
-    add(tr, 0, (B * 576, 1, 1), 147, raw=True)
+    y0 = add(tr, 0, (B * 576, 1, 1), 147, x=stand_in(B * 576 * tr.records[0]["cin"], raw=True))
+    cur, sc, a = y0, None, None  # (the 3x3 / 2 max-pool keeps a quarter of the root's pixels: a view of its result)
     for k in range(1, tr.n):
-        add(tr, k, (B, 12, 12), residual=roles[k] == "conv3")
+        if roles[k] == "shortcut":
+            sc = add(tr, k, (B, 12, 12), x=cur)
+        elif roles[k] == "conv1":
+            a = add(tr, k, (B, 12, 12), x=cur)
+        elif roles[k] == "conv2":
+            a = add(tr, k, (B, 12, 12), x=a)
+        else:  # conv3: + the unit's input (or its projection), ReLU
+            cur = add(tr, k, (B, 12, 12), x=a, res=sc if sc is not None else cur)
+            sc = None
     dec = net.decoder
     kinds7, ex7 = (ctypes.c_int * 7)(), (ctypes.c_double * 7)()
     _lib.check(lib.mpsr_squash_decoder_plan(B, 12, 12, 48, 48, dec.layers, dec.n, kinds7, ex7))
+    prev = None
     for k, hw in enumerate([(12, 12), (12, 12), (24, 24), (24, 24), (48, 48), (48, 48), (48, 48)]):
         if kinds7[k] == 7:  # tap GEMM on the source map (half the size), one launch per 128 output channels
-            add(dec, k, (B, hw[0], hw[1]), override=(hw[0] // 2, hw[1] // 2, dec.records[k]["cout"] // 128))
+            add(dec, k, (B, hw[0], hw[1]), x=prev, override=(hw[0] // 2, hw[1] // 2, dec.records[k]["cout"] // 128))
+            prev = None  # (its gather is vector work and is not replayed: the next layer reads a stand-in)
         else:
-            add(dec, k, (B, hw[0], hw[1]), residual=k == 1)
+            # squash = two GEMMs over the K halves: crop features, then the full-image feature crop + the first as residual
+            xin = cur if k == 0 else None if k == 1 else prev
+            prev = add(dec, k, (B, hw[0], hw[1]), x=xin, res=prev if k == 1 else None)
             jobs[-1]["kind"], jobs[-1]["ex"] = kinds7[k], ex7[k]
     hd = net.heads
+    prev = None
     for k in range(hd.n):
-        add(hd, k, (B, 1, 1), {1: 1043, 4: 1060}.get(k))
+        chained = k in (2, 3, 5, 6)  # layers whose input IS the previous launch's output (the others read concat rows)
+        prev = add(hd, k, (B, 1, 1), {1: 1043, 4: 1060}.get(k), x=prev if chained else None)
 
     # the network entry points hand every layer the scheduling scratch and leave the schedule to the library
     # (split_k = 0); the replay does the same, so it launches the kernels a step launches
@@ -358,10 +395,11 @@ def roofline_object(net, args, device, ms_per_step):
            "kernel_ms_per_step": round(pass_s * 1e3, 3),
            "kernel_ms_per_step_le_ms_per_step": bool(pass_s * 1e3 <= ms_per_step),
            "replay": "the step's matrix-pipe launches back to back -- the variants the step launches: residual operands "
-                     "on conv3 / squash, the decoder's tap GEMMs, img_fc on stream-K -- on post-ReLU-like operands "
-                     "(relu(N(0,1)); the root conv on N(0,1)); the step's own activations live in ping-pong scratch and "
-                     "cannot be replayed; not replayed: the vector-ALU kernels between them (im2col, pools, the two "
-                     "upsampling gathers, head glue, Chamfer)"}
+                     "on conv3 / squash, the decoder's tap GEMMs, img_fc on stream-K -- in the step's own data flow: every "
+                     "launch reads what the launch in front of it wrote (bottleneck by bottleneck, rotating buffers like "
+                     "the entry points' ping-pong scratch), relu(N(0,1)) stand-ins only where the producer is a vector "
+                     "kernel; not replayed: the vector-ALU kernels between them (im2col, pools, the two upsampling "
+                     "gathers, head glue, Chamfer) -- `in_situ` has both families measured inside the timed loop"}
     if fp32:
         out["launch_kinds"] = {"implicit_gemm": kinds.get(0, 0), "winograd_f2x2_3x3": kinds.get(1, 0),
                                "direct_narrow": kinds.get(2, 0), "winograd_f4x4_3x3": kinds.get(3, 0),
@@ -385,6 +423,58 @@ def roofline_object(net, args, device, ms_per_step):
         except Exception as e:
             out["peak_measured_on_this_board"] = repr(e)
     return out
+
+
+MATRIX_KERNELS = ("pw_conv_kernel", "wino3z_conv_kernel", "wino3h_conv_kernel", "wino3w_conv_kernel", "wino3_conv_kernel",
+                  "wino3p_conv_kernel", "wino4_conv_kernel", "wino4s_conv_kernel", "wino_conv_kernel", "wino_conv8_kernel",
+                  "conv_igemm_kernel", "conv_sk_kernel", "fc_rows_kernel", "conv3x3_narrow_mfma_kernel")
+
+
+def in_situ_object(one_step, executed_flops_per_step, ms_per_step, steps=4):
+    """Per-kernel durations of the TIMED step itself (not of a replay): `steps` more steps of the same loop under
+    torch.profiler (roctracer activity records of every kernel this process launches, the library's included), summed
+    by kernel family.  matrix_ms_per_step + vector_ms_per_step <= ms_per_step must hold: durations exclude the gaps
+    between launches.  This is what answers "how busy are the matrix pipes IN the step"; the replay above (HIP events,
+    as the measurement contract asks) runs the same launches on other buffers and is a few percent slower."""
+    from torch.profiler import ProfilerActivity, profile
+    one_step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+    fam = {}
+    for ev in prof.key_averages():
+        us = None
+        for attr in ("self_device_time_total", "device_time_total", "self_cuda_time_total", "cuda_time_total"):
+            v = getattr(ev, attr, None)
+            if v:
+                us = float(v)
+                break
+        if not us:
+            continue
+        name = ev.key
+        short = next((k for k in MATRIX_KERNELS if k in name), None)
+        if short is not None and "<" in name:  # keep the template arguments that tell the variants apart
+            short += name[name.index("<"):name.index(">") + 1] if ">" in name else ""
+        key = ("matrix", short) if short is not None else ("vector", name.split("(")[0].split("::")[-1][:60])
+        d = fam.setdefault(key, [0.0, 0])
+        d[0] += us
+        d[1] += int(ev.count)
+    if not fam:
+        raise RuntimeError("the profiler returned no device activity")
+    mat = sum(v[0] for k, v in fam.items() if k[0] == "matrix") / steps / 1e3
+    vec = sum(v[0] for k, v in fam.items() if k[0] == "vector") / steps / 1e3
+    top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]
+    return {"how": "torch.profiler (roctracer kernel records) over %d further steps of the timed loop" % steps,
+            "matrix_ms_per_step": round(mat, 3), "vector_ms_per_step": round(vec, 3),
+            "sum_ms_per_step": round(mat + vec, 3), "ms_per_step": ms_per_step,
+            "sum_le_ms_per_step": bool(mat + vec <= ms_per_step * 1.005),
+            "matrix_launches_per_step": round(sum(v[1] for k, v in fam.items() if k[0] == "matrix") / steps, 1),
+            "vector_launches_per_step": round(sum(v[1] for k, v in fam.items() if k[0] == "vector") / steps, 1),
+            "frac_in_situ": round(executed_flops_per_step / (mat * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernels_ms_per_step": {("%s:%s" % k): [round(v[0] / steps / 1e3, 3), round(v[1] / steps, 1)]
+                                    for k, v in top}}
 
 
 def emd_object(device, b=256, n=2048):
@@ -422,6 +512,54 @@ def emd_object(device, b=256, n=2048):
             "match_cost_read_GBps": round(4 * pairs / t_c / 1e9, 1),
             "match_cost_grad_read_GBps": round(8 * pairs / t_g / 1e9, 1), "hbm_peak_GBps": 8000,
             "bound": "v_exp_f32 issue (passes), HBM (materialised match)"}
+
+
+def ops_at_reference_shape_object(device, b=32, n=2304):
+    """The two point-cloud ops at the shape the REFERENCE evaluates them on: (32, 2304, 3) clouds -- 32 boxes per image
+    (configs/monopsr_model_000.yaml:14-17), every pixel of the 48 x 48 xyz map a point
+    (/root/reference/src/monopsr/core/models/monopsr/monopsr_model.py:1127-1164: masked maps reshaped to (B, 2304, 3), then
+    approx_match + match_cost and nn_distance).  Parity at this shape: tests/test_ops_gpu.py (2304^2 against the oracle)."""
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    from monopsr_amd.tf_ops.nn_distance import tf_nndistance as nnd
+    g = torch.Generator(device=device).manual_seed(16)
+    x1 = torch.rand((b, n, 3), device=device, generator=g) * 2 - 1
+    x2 = torch.rand((b, n, 3), device=device, generator=g) * 2 - 1
+    ones = torch.ones((b, n), device=device)
+
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    d1, i1, d2, i2 = nnd.nn_distance(x1, x2)
+    t_nf = timeit(lambda: nnd.nn_distance(x1, x2), 50)
+    t_nb = timeit(lambda: nnd.nn_distance_grad(x1, x2, ones, i1, ones, i2), 50)
+    match = am.approx_match(x1, x2)
+    t_m = timeit(lambda: am.approx_match(x1, x2), 10)
+    t_c = timeit(lambda: am.match_cost(x1, x2, match), 10)
+    t_g = timeit(lambda: am.match_cost_grad(x1, x2, match), 10)
+    t_f = timeit(lambda: am.emd_loss_fwd_bwd(x1, x2), 10)
+    pairs = float(b) * n * n
+    return {"shape": [b, n, n],
+            "workload": "the reference's evaluation shape: 32 boxes x 2304-point clouds (every pixel of the 48x48 map)",
+            "nn_distance": {"fwd_us": round(t_nf * 1e6, 1), "bwd_us": round(t_nb * 1e6, 1),
+                            "fwd_alg_GBps": round(b * 2 * n * 20 / t_nf / 1e9, 1),
+                            "bwd_alg_GBps": round(b * 2 * n * 32 / t_nb / 1e9, 1),
+                            "fwd_pair_evals_per_s": float("%.4g" % (2.0 * pairs / t_nf)),
+                            "clouds_per_s_fwd_bwd": round(b / (t_nf + t_nb), 1)},
+            "emd": {"approx_match_ms": round(t_m * 1e3, 3), "match_cost_ms": round(t_c * 1e3, 3),
+                    "match_cost_grad_ms": round(t_g * 1e3, 3),
+                    "approx_match_plus_match_cost_clouds_per_s": round(b / (t_m + t_c), 1),
+                    "fused_loss_fwd_bwd_ms": round(t_f * 1e3, 3), "fused_clouds_per_s": round(b / t_f, 1),
+                    "match_bytes": int(4 * pairs), "approx_match_write_GBps": round(4 * pairs / t_m / 1e9, 1)},
+            "hbm_peak_GBps": 8000,
+            "note": "32 clouds are 32 workgroup columns of the EMD passes and 4.5 workgroups per cloud of the Chamfer "
+                    "search: the chip is partly filled at this shape (the cfg3 / cfg5 objects above are the filled ones)"}
 
 
 def cfg5_step_object(step, inp, device, steps):
@@ -671,13 +809,48 @@ def cpu_baseline(weights, host, sample, npts, budget_s=18.0):
 
 
 def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_dev=None, make_trainer=None,
-                         bucket_mib=64, full_trunk=False, allreduce="rccl", decoder_bn="batch"):
-    """ms per training step of `batch` instances per rank (crop trunk + decoder + heads trainable, 72.8 M parameters
-    in one flat buffer).  With a process group (N > 1) every rank trains its own shard and the flat 291 MB gradient
-    goes through core/trainer.ReverseBucketReducer (64 MiB buckets launched from the end of the buffer as backward
-    reports layers ready, averaged, THEN per-variable clip as the reference does: core/trainer.py:76-81); the step is
-    timed with and without the reduce (MAX over ranks), the difference being the exposed, non-overlapped part."""
+                         bucket_mib=64, full_trunk=False, allreduce="rccl", decoder_bn="batch", one_rank_rccl=False):
+    """ms per training step of `batch` instances per rank.  full_trunk=False: crop trunk + decoder + heads trainable
+    (72.8 M parameters, 291 MB gradient; the full-image branch enters as a synthetic feature crop).  full_trunk=True: BOTH
+    ResNet-101 trunks trainable from one raw 375x1242 image per rank + `batch` boxes -- the reference's whole trainable
+    set (net_builder.py:44-52, core/trainer.py:71-81), the 100 M-parameter / 401 MB gradient SURVEY 8(d) cfg4 names; the
+    default of an N > 1 run.  With a process group (N > 1) every rank trains its own shard and the flat gradient goes
+    through core/trainer.ReverseBucketReducer (64 MiB buckets launched from the end of the buffer as backward reports
+    layers ready, averaged, THEN per-variable clip as the reference does: core/trainer.py:76-81); the step is timed
+    with and without the reduce (MAX over ranks), the difference being the exposed, non-overlapped part.
+    one_rank_rccl (N = 1): a ONE-rank "nccl" process group is created for the duration of this object and the step runs
+    the same RCCL calls an N > 1 step issues (force_collectives; every collective an identity) -- the library, the
+    sizes and the stream ordering are the real ones, the wire is not."""
     world = dist.get_world_size() if dist is not None else 1
+    own_pg = None
+    if one_rank_rccl and dist is None:
+        try:
+            import socket
+            import torch.distributed as own_pg
+            if own_pg.is_initialized():
+                raise RuntimeError("a process group exists already")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            own_pg.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            one_rank = {"backend": own_pg.get_backend(), "rccl_version": ".".join(map(str, torch.cuda.nccl.version()))}
+        except Exception as e:  # the measurement still runs, without collectives
+            own_pg, one_rank = None, {"error": repr(e)[:300]}
+    try:
+        return _training_step_object(device, batch, inp, steps, warmup, dist, red_dev, make_trainer, bucket_mib,
+                                     full_trunk, allreduce, decoder_bn, world,
+                                     one_rank if one_rank_rccl and dist is None else None, own_pg)
+    finally:
+        if own_pg is not None:
+            try:
+                own_pg.destroy_process_group()
+            except Exception:
+                pass
+
+
+def _training_step_object(device, batch, inp, steps, warmup, dist, red_dev, make_trainer, bucket_mib, full_trunk,
+                          allreduce, decoder_bn, world, one_rank, own_pg):
     if make_trainer is None:
         from monopsr_amd.core import config_utils, train_net, trainer
         from monopsr_amd.core import weights as W
@@ -688,7 +861,8 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         else:
             net = train_net.TrainNet(W.synthetic_weights(seed=0), device=device, decoder_bn=decoder_bn)
         tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0,
-                                     bucket_bytes=bucket_mib << 20, allreduce=allreduce)
+                                     bucket_bytes=bucket_mib << 20, allreduce=allreduce,
+                                     force_collectives=own_pg is not None)
         sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
                       cam_p=inp["cam_p"], est_view_angs=inp["view"], class_indices=inp["cls"],
                       mean_lwh=inp["mean_lwh"], prop_cen_z_offset=inp["z_off"])
@@ -721,6 +895,11 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
 
     out = {"params": int(net.params.numel()), "grad_bytes": int(net.grads.numel() * 4), "steps": steps,
            "ranks": world,
+           "trainable": ("both ResNet-101 trunks + decoder + heads = the reference's whole trainable set (SURVEY 8(d) "
+                         "cfg4: 100,204,832 parameters / 400,819,328 gradient bytes in TF's parameterisation; here "
+                         "BatchNorm is folded into one bias per channel and every tensor padded to 256 bytes); input: "
+                         "one synthetic 375x1242 image + %d boxes per rank" % batch) if full_trunk else
+                        "crop trunk + decoder + heads (the full-image branch enters as a synthetic feature crop)",
            "what": "fwd + configured losses (incl. global-map projection) + bwd + clip + Adam + EMA, fp32; decoder "
                    "BN: %s" % ("batch statistics pooled over all ranks (fp64 sums all-reduced per layer and direction: the "
                                "whole step's batch, as the reference's single-process step)" if decoder_bn == "batch_global"
@@ -768,6 +947,20 @@ def training_step_object(device, batch, inp, steps=3, warmup=2, dist=None, red_d
         dt, vals = timed(steps)
         losses += vals
         out.update({"ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(batch / dt, 1)})
+        if one_rank is not None:
+            if own_pg is not None:  # the step above ran the N > 1 step's RCCL calls on a one-rank communicator
+                issued = list(getattr(tr.reducer, "last_issued", []))
+                one_rank.update({"collectives_per_step": {k: issued.count(k) for k in sorted(set(issued))},
+                                 "mode": tr.reducer.mode, "buckets": len(tr.reducer.buckets),
+                                 "bucket_mib": tr.reducer.bucket_bytes >> 20})
+                tr.reducer.enabled = False
+                dt0, _ = timed(max(2, steps // 3))
+                tr.reducer.enabled = True
+                one_rank["ms_per_step_without_collectives"] = round(dt0 * 1e3, 2)
+                one_rank["note"] = ("world_size 1: every collective is an identity -- what is exercised is RCCL itself, "
+                                    "the bucket sizes, async issue from backward and the average -> clip -> Adam order; "
+                                    "it says nothing about xGMI")
+            out["rccl_one_rank"] = one_rank
     out["loss_per_step"] = [round(v, 1) for v in losses]
     out["note"] = ("random-initialised weights and synthetic targets: the first Adam steps are a transient (every "
                    "parameter moves by the learning rate whatever its gradient); the list is the loss of every step "
@@ -814,6 +1007,29 @@ def gather_rank_objects(dist, world, fn):
     return objs
 
 
+_OUT = None  # the stream the ONE JSON line goes to (main(): the process's original stdout)
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too: RCCL prints a five-line version block
+    ("RCCL version : ...", HIP / ROCm version, hostname, library path) to the C stdout when a communicator is created
+    -- buffered, so it lands BEHIND the JSON line at exit (seen in r06 on the first run that created a communicator
+    in this process).  So the process keeps its original stdout for the line alone and points file descriptor 1 at
+    stderr for everybody else (C libraries, child processes, stray prints)."""
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        _OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _OUT
+
+
+def emit_line(line):
+    out = _OUT if _OUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 class Emitter:
     """Rank 0 prints exactly ONE JSON line.  Once the headline exists a watchdog is armed: if the side measurements
     that follow (extra objects, collectives with the other ranks) have not finished by the deadline, the watchdog
@@ -856,7 +1072,7 @@ class Emitter:
                 line = json.dumps(dict(self.result, extras_incomplete=reason))
             except (RuntimeError, TypeError, ValueError):
                 line = json.dumps(dict({k: self.result[k] for k in keys if k in self.result}, extras_incomplete=reason))
-            print(line, flush=True)
+            emit_line(line)
             self.done = True
 
     def _expired(self):
@@ -876,14 +1092,14 @@ class Emitter:
                             "scaling", "vs_baseline", "dtype", "data", "config")
                     line = json.dumps(dict({k: self.result[k] for k in keys if k in self.result},
                                            extras_timed_out_after_s=self.deadline_s))
-                print(line, flush=True)
+                emit_line(line)
                 self.done = True
         os._exit(0)  # every rank: the launcher must not turn a printed headline into a failed run
 
     def emit(self, result):
         with self.lock:
             if not self.done and self.rank == 0:
-                print(json.dumps(result), flush=True)
+                emit_line(json.dumps(result))
             self.done = True
         self.timer.cancel()
 
@@ -977,8 +1193,12 @@ def main():
     ap.add_argument("--bucket-mib", type=int, default=64, choices=[16, 32, 64, 128],
                     help="N > 1: bucket size of the training step's gradient all-reduce (ReverseBucketReducer)")
     ap.add_argument("--train-full-trunk", action="store_true",
-                    help="training_step with BOTH ResNet-101 trunks trainable (100.3 M parameters: the 401 MB gradient "
-                         "BASELINE cfg4 names) on a raw 375x1242 image per rank instead of the crop-trunk-only net")
+                    help="N = 1: make `training_step` itself the both-trunk step (it is the default for N > 1, and the "
+                         "N = 1 line carries it as `training_step_full` anyway)")
+    ap.add_argument("--train-crop-trunk-only", action="store_true",
+                    help="N > 1: training_step on the crop-trunk net (72.8 M parameters, 291 MB gradient) instead of the "
+                         "both-trunk net (the reference's whole trainable set, 401 MB: SURVEY 8(d) cfg4)")
+    ap.add_argument("--no-train-step-full", action="store_true", help="N = 1: skip the training_step_full object")
     ap.add_argument("--no-full-image", action="store_true", help="skip the extra full_image_path object")
     ap.add_argument("--allreduce", default="rccl", choices=["rccl", "direct"],
                     help="N > 1: the training step's gradient exchange per bucket -- rccl: one all_reduce (the library "
@@ -992,6 +1212,7 @@ def main():
                          "unfinished extra objects")
     args = ap.parse_args()
 
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1143,6 +1364,14 @@ def main():
             result["roofline"] = roofline_object(net, args, device, result["ms_per_step"])
         except Exception as e:
             result["roofline"] = {"error": repr(e)}
+    if rank == 0 and not args.no_roofline and args.math == "fp32" and isinstance(result.get("roofline"), dict) \
+            and "flops_per_launch" in result["roofline"]:
+        try:
+            rf = result["roofline"]
+            rf["in_situ"] = in_situ_object(one_step, rf["flops_per_launch"] * rf["launches_per_step"],
+                                           result["ms_per_step"])
+        except Exception as e:
+            result["roofline"]["in_situ"] = {"error": repr(e)[:300]}
     if rank == 0 and not args.no_roofline:
         # the Chamfer op alone, as the north star asks ("achieved HBM GB/s on nn_distance"): algorithmic bytes =
         # b*(n+m)*20 forward (12 read + 8 written per point), b*(n+m)*32 backward; the kernel is VALU-bound, so the
@@ -1185,6 +1414,11 @@ def main():
                 result["emd"] = emd_object(device)
             except Exception as e:
                 result["emd"] = {"error": repr(e)}
+    if rank == 0 and not args.no_roofline and not args.no_emd:
+        try:
+            result["ops_at_reference_shape"] = ops_at_reference_shape_object(device)
+        except Exception as e:
+            result["ops_at_reference_shape"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline and not args.no_emd and isinstance(step, Step):
         try:
             result["cfg5_step"] = cfg5_step_object(step, inp, device, args.steps)
@@ -1247,12 +1481,25 @@ def main():
                 tb = args.train_batch or args.batch
                 tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
                 # N = 1: 2 + 18 steps, so that the line shows the loss past the first Adam steps' transient
+                # N > 1: the both-trunk net (cfg4's 401 MB gradient) unless --train-crop-trunk-only
+                full = (not args.train_crop_trunk_only) if multi else args.train_full_trunk
                 ts = training_step_object(device, tb, tinp, steps=6 if multi else 18, dist=dist if multi else None,
-                                          red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=args.train_full_trunk,
+                                          red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=full,
                                           allreduce=args.allreduce, decoder_bn=args.decoder_bn)
                 result["training_step"] = ts
             except Exception as e:
                 result["training_step"] = {"error": repr(e)}
+        if not multi and rank == 0 and not args.no_train_step_full and not args.train_full_trunk:
+            # BASELINE cfg4's per-GPU share as specified: the both-trunk, 100 M-parameter step (401 MB gradient), on a
+            # one-rank RCCL communicator so that the N > 1 step's collective calls run for real (identities)
+            try:
+                tb = args.train_batch or args.batch
+                tinp = inp if tb == args.batch else make_inputs(tb, args.points, rank, device)[0]
+                result["training_step_full"] = training_step_object(
+                    device, tb, tinp, steps=6, dist=None, red_dev=red_dev, bucket_mib=args.bucket_mib, full_trunk=True,
+                    allreduce=args.allreduce, decoder_bn=args.decoder_bn, one_rank_rccl=True)
+            except Exception as e:
+                result["training_step_full"] = {"error": repr(e)}
     if rank == 0 and args.cpu_sample != 0 and n_gpus == 1:
         try:
             result["cpu_baseline"], _ = cpu_baseline(weights, host, min(args.cpu_sample, args.batch), args.points)

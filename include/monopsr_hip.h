@@ -551,7 +551,8 @@ int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, const float *
                    const mpsr_head_consts *consts, const float *blob, const mpsr_layer *layers, int n_layers,
                    const mpsr_head_outputs *outs, void *workspace, size_t workspace_bytes, mpsr_stream_t stream);
 /* ABI 5: the boxes of several images in one call -- cam_p (n_cams,12), cam_index (B) int32 in [0, n_cams) picks each
- * box's projection matrix (NULL: every box uses the first).  The reference feeds one image per step
+ * box's projection matrix (NULL: every box uses the first; an index outside the range is never dereferenced -- the
+ * outputs of that box that depend on the projection come back NaN).  The reference feeds one image per step
  * (monopsr_model.py:95-99, one pl_cam_p); N images x 32 boxes in one call read the 150 MB of FC weights once. */
 int mpsr_heads_fwd_cams(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d, const float *cam_p,
                         int n_cams, const int *cam_index, const float *view_angs, const int *class_idx,

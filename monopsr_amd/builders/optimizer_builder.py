@@ -51,22 +51,6 @@ class AdamWithMovingAverage:
                 self.shadow.lerp_(net.params, 1.0 - self.moving_average_decay)
         return lr
 
-    def apply_gradients_lr_dev(self, net, lr_t_dev):
-        """apply_gradients for a step that is captured into a HIP graph: the Adam launch reads its bias-corrected rate
-        from the device scalar `lr_t_dev` (written by the caller before every replay: `lr_t_of(net, global_step)`); the
-        moving average must exist already (the eager steps before the capture create it)."""
-        net.adam_step_lr_dev(lr_t_dev)
-        if self.use_moving_average:
-            if self.shadow is None:
-                raise RuntimeError("run at least one eager step before capturing: the moving average starts there")
-            self.shadow.lerp_(net.params, 1.0 - self.moving_average_decay)
-
-    def lr_t_of(self, net, global_step):
-        """The value apply_gradients_lr_dev's Adam launch must find for the step about to run (advances net.step_count
-        like adam_step does)."""
-        net.step_count += 1
-        return net.adam_rate(self.learning_rate(global_step), net.step_count)
-
     def averaged_params(self, net):
         """The moving averages -- what a checkpoint holds under `<name>/ExponentialMovingAverage` -- or the raw
         parameters when averaging is off."""

@@ -155,30 +155,35 @@ class DgradBank:
     packing.  Anything else that runs backward (tests, a caller's own loop) never sees a stale layout: without
     refresh() the per-layer path runs as before."""
 
-    def __init__(self, layers, device):
+    def __init__(self, layers, device, skip=()):
+        """skip: indices of layers whose data gradient is never computed (a trunk's root convolution reads the image,
+        which needs no gradient): they get no slice -- should one ever be asked for, _dgrad_filter packs it per call."""
         lib = _lib.lib()
+        skip = set(skip)
+        banked = [(i, L) for i, L in enumerate(layers) if i not in skip]
         sizes = []
-        for L in layers:
+        for _, L in banked:
             n4 = L.cout + (-L.cout) % 4
             sizes.append(L.cin * L.kh * L.kw * n4)
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + (n + 63) // 64 * 64)  # 256-byte aligned slices (16-byte loads in the kernels)
         self.flat = torch.empty((offs[-1],), dtype=torch.float32, device=device)
-        jobs = (_lib.PackJob * len(layers))()
-        for i, L in enumerate(layers):
+        self.skipped = sorted(skip)
+        jobs = (_lib.PackJob * len(banked))()
+        for j, (_, L) in enumerate(banked):
             n4 = L.cout + (-L.cout) % 4
-            L.wd = self.flat[offs[i]:offs[i] + sizes[i]].view(L.cin, L.kh * L.kw * n4)
+            L.wd = self.flat[offs[j]:offs[j] + sizes[j]].view(L.cin, L.kh * L.kw * n4)
             L.dgrad_bank = self
-            jobs[i].w, jobs[i].wd = L.w.data_ptr(), L.wd.data_ptr()
-            jobs[i].N, jobs[i].Nd, jobs[i].T, jobs[i].C = L.cout, n4, L.kh * L.kw, L.cin
-        nbytes = lib.mpsr_dgrad_pack_table_bytes(jobs, len(layers))
+            jobs[j].w, jobs[j].wd = L.w.data_ptr(), L.wd.data_ptr()
+            jobs[j].N, jobs[j].Nd, jobs[j].T, jobs[j].C = L.cout, n4, L.kh * L.kw, L.cin
+        nbytes = lib.mpsr_dgrad_pack_table_bytes(jobs, len(banked))
         if not nbytes:
             raise _lib.InvalidArgumentError("DgradBank: bad layer table")
         import ctypes
         host = torch.zeros(((nbytes + 7) // 8,), dtype=torch.int64)
         n_chunks = ctypes.c_longlong(0)
-        _lib.check(lib.mpsr_dgrad_pack_table_build(jobs, len(layers), host.data_ptr(), ctypes.byref(n_chunks)))
+        _lib.check(lib.mpsr_dgrad_pack_table_build(jobs, len(banked), host.data_ptr(), ctypes.byref(n_chunks)))
         self.table = host.to(device)
         self.n_chunks = int(n_chunks.value)
         self.fresh = False

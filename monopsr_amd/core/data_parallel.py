@@ -34,11 +34,12 @@ def shard_sample(sample, rank, world_size, per_instance_keys=None):
     return out
 
 
-def gather_instances(t, total, group=None):
+def gather_instances(t, total, group=None, force_collective=False):
     """All ranks receive the concatenation over ranks (in rank order) of a per-instance tensor whose shards follow
-    shard_range(total, ...).  Uneven shards are padded to the largest one for the collective."""
+    shard_range(total, ...).  Uneven shards are padded to the largest one for the collective.  force_collective: issue
+    the all_gather on a one-rank group too (an identity: the real RCCL call on a single-GPU box)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return t
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     big = max(sizes)
@@ -49,10 +50,10 @@ def gather_instances(t, total, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
-def reduce_metric_sums(values, group=None):
+def reduce_metric_sums(values, group=None, force_collective=False):
     """Sum scalar / small metric tensors over ranks (e.g. per-rank Chamfer sums and valid-pixel counts)."""
     t = torch.stack([v.reshape(()).to(torch.float64) for v in values])
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
         dist.all_reduce(t, group=group)
     return t
 

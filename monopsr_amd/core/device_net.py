@@ -43,24 +43,32 @@ class FilterCache:
             o.filter_cache, o.filter_cache_floats = self.buf.data_ptr(), self.buf.numel()
             o.filter_cache_valid = 1 if self.filled else 0
             o.filter_cache_tags = self.tags
+            self._tags_before = bytes(self.tags)  # (mark_filled: did this call re-write a slice?)
         o.ready_event = event
         o.math = _lib.CALL_MATH[math]
         o.winograd_policy = _lib.CALL_WINOGRAD[winograd_policy]
         return o
 
     def mark_filled(self):
-        """The native call that was handed this cache returned MPSR_OK: its launches (which fill the slices) are
+        """The native call that was handed this cache returned MPSR_OK: its launches (which fill, or RE-fill, slices) are
         queued on the calling stream.  Calls on OTHER streams must not read the slices before those launches have run:
-        the stream that filled the cache is remembered and later callers on another stream wait for its event."""
-        if self.buf is None or self.filled:
+        the LAST stream that wrote the cache is remembered with an event and later callers on another stream wait for
+        it.  A call re-writes slices whenever the kernel choice of a layer changes (arithmetic mode, Winograd policy, a
+        batch size on the other side of a kernel's threshold): the library records that in `tags`, so a call after
+        which the tags differ from the snapshot `opts()` took was a writer.  One DeviceNet is driven by
+        one host thread at a time (`tags` is plain host memory the library updates without a lock;
+        clone_with_own_scratch() gives every thread / stream its own cache)."""
+        if self.buf is None:
             return
+        wrote = not self.filled or bytes(self.tags) != getattr(self, "_tags_before", None)
         self.filled = True
-        self.fill_stream = torch.cuda.current_stream(self.buf.device)
-        self.fill_event = torch.cuda.Event()
-        self.fill_event.record(self.fill_stream)
+        if wrote:
+            self.fill_stream = torch.cuda.current_stream(self.buf.device)
+            self.fill_event = torch.cuda.Event()
+            self.fill_event.record(self.fill_stream)
 
     def before_call(self):
-        """Orders a call on another stream than the one that filled the cache behind the fill."""
+        """Orders a call on another stream than the last one that wrote the cache behind that write."""
         if self.filled and getattr(self, "fill_event", None) is not None:
             cur = torch.cuda.current_stream(self.buf.device)
             if cur != self.fill_stream:

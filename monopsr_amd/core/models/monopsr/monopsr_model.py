@@ -77,7 +77,8 @@ class MonoPSRModel:
     def build_batch(self, samples):
         """N images with their boxes in ONE pass (inference, fused heads): `samples` = a list of the dicts `build` takes
         (`rgb_image` (H_i,W_i,3), `boxes_2d_norm`, `boxes_2d`, `cam_p`, `est_view_angs`, `class_indices`, `mean_lwh`,
-        `prop_cen_z_offset`; box counts and image sizes may differ per image).  The reference's step is one image
+        `prop_cen_z_offset`; box counts and image sizes may differ per image, and an image may have NO boxes: its dict then
+        holds empty tensors).  The reference's step is one image
         (monopsr_model.py:222-237, configs/monopsr_model_000.yaml:14-17); here every image is preprocessed as there,
         then all of them go through DeviceNet.forward_images: one full-image trunk call with batch N, one crop-trunk /
         decoder / heads call with all boxes.  Returns a list of per-image output dicts (views into the batch
@@ -91,12 +92,21 @@ class MonoPSRModel:
                                                       mean_sub_type=self.mean_sub_type) for s in samples]
         images = torch.cat(pre, 0)
         counts = [int(s['boxes_2d'].shape[0]) for s in samples]
+        if sum(counts) == 0:  # no box in any image: nothing to run (every output is per box)
+            nb = self.dataset_config.num_alpha_bins
+            z = lambda *shape: torch.zeros((0,) + shape, dtype=torch.float32, device=dev)
+            empty = {constants.KEY_INST_XYZ_MAP_LOCAL: z(self.map_roi_size[0], self.map_roi_size[1], 3),
+                     "lwh": z(3), "lwh_offs": z(3), "alpha_bins": z(nb), "alpha_regs": z(nb), "centroids": z(3)}
+            empty.update({k: z(1) for k in ("prop_cen_z", "cen_y", "cen_y_offs", "cen_z", "cen_z_offs", "cen_x",
+                                            "view_ang")})
+            return [dict(empty, **{constants.SAMPLE_LABEL_CLASS_INDICES: s['class_indices']}) for s in samples]
         box_ind = torch.cat([torch.full((c,), i, dtype=torch.int32, device=dev) for i, c in enumerate(counts)])
-        cat = lambda k: torch.cat([s[k].reshape(s['boxes_2d'].shape[0], -1) for s in samples], 0)
+        # (explicit trailing sizes: reshape(0, -1) of an image WITHOUT boxes is ambiguous and raises)
+        cat = lambda k, w: torch.cat([s[k].reshape(c, w) for s, c in zip(samples, counts)], 0)
         cam_p = torch.stack([s['cam_p'].reshape(3, 4) for s in samples], 0)
         xyz, out = self.device_net.forward_images(
-            images, cat('boxes_2d_norm'), box_ind, cat('boxes_2d'), cam_p, cat('est_view_angs').reshape(-1),
-            cat('class_indices'), cat('mean_lwh'), cat('prop_cen_z_offset').reshape(-1),
+            images, cat('boxes_2d_norm', 4), box_ind, cat('boxes_2d', 4), cam_p, cat('est_view_angs', 1).reshape(-1),
+            cat('class_indices', 1), cat('mean_lwh', 3), cat('prop_cen_z_offset', 1).reshape(-1),
             img_roi_size=tuple(self.img_roi_size), map_roi_size=tuple(self.map_roi_size),
             resized_full_img_shape=tuple(self.resized_full_img_shape),
             image_shape=self.image_input_shape, max_depth=self.depth_range[1],

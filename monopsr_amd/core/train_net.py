@@ -92,7 +92,10 @@ class TrainNet:
         # data-gradient layouts of every layer, made by one launch per step (the trainer refreshes it before backward)
         # (dgrad_bank=False: each layer's layout is packed inside backward, one launch per layer -- the A/B of
         # tools/train_bench.py --dgrad-bank 0)
-        self.dgrad_bank = ops.DgradBank(self.layers, self.device) if (dgrad_bank and self.device.type == "cuda") else None
+        # (the two root convolutions read images: no data gradient, no slice -- ADVICE r05)
+        roots = [0] + ([self.full_base] if self.full_base is not None else [])
+        self.dgrad_bank = (ops.DgradBank(self.layers, self.device, skip=roots)
+                           if (dgrad_bank and self.device.type == "cuda") else None)
         if decoder_bn in ('batch', 'batch_global'):
             # decoder records: squash (2 GEMMs), then one record per spec; BatchNorm layers get the UNFOLDED kernel
             # in their weight slot and beta in their bias slot
@@ -265,8 +268,8 @@ class TrainNet:
         return float(lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step))
 
     def adam_step_lr_dev(self, lr_t_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
-        """adam_step with the bias-corrected rate read from the device scalar `lr_t_dev` at run time (a launch that is
-        captured into a HIP graph); the caller keeps step_count."""
+        """adam_step with the bias-corrected rate read from the device scalar `lr_t_dev` at run time (for a caller whose
+        schedule lives on the device; `adam_rate` gives the value); the caller keeps step_count."""
         _lib.check(_lib.lib().mpsr_adam_step_lr_dev(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
                                                     _lib.ptr(self.adam_v), self.params.numel(), _lib.ptr(lr_t_dev),
                                                     beta1, beta2, eps, grad_scale, _lib.stream()))

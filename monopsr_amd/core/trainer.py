@@ -20,16 +20,20 @@ class ReverseBucketReducer:
     layers report their gradients ready -- backward visits layers in roughly reverse buffer order (heads, decoder,
     trunk), so the first buckets are on the wire while the trunk is still back-propagating."""
 
-    def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None, mode="rccl"):
+    def __init__(self, flat, layer_spans, bucket_bytes=64 << 20, group=None, mode="rccl", force_active=False):
         """layer_spans[i]: the element range(s) of `flat` layer i's backward writes -- one (lo, hi) or a list of them
         (weight gradient AND bias gradient: a bucket holding any part of either must wait for the layer).
         mode: "rccl" = one all_reduce per bucket (the library's own algorithm choice); "direct" = reduce-scatter of the
         bucket into 1 / world shards followed by an all-gather (on the fully connected xGMI mesh every rank
         then sends each peer its shard ONCE per phase over that peer's own link, instead of 2 (world - 1) ring steps
-        bound by one link).  Same sums up to the reduction order; selectable with bench.py --allreduce."""
+        bound by one link).  Same sums up to the reduction order; selectable with bench.py --allreduce.
+        force_active: issue the collectives even on a ONE-rank group (they are then identities) -- the one way to run
+        the real RCCL sequence on a box with a single GPU (tests/test_rccl_one_rank_gpu.py, bench.py `rccl_one_rank`)."""
         if mode not in ("rccl", "direct"):
             raise ValueError("reducer mode must be 'rccl' or 'direct'")
         self.flat, self.group, self.bucket_bytes, self.mode = flat, group, bucket_bytes, mode
+        self.force_active = bool(force_active)
+        self.issued = []  # names of the collectives issued since the last reset(), in issue order (tests read it)
         self._shards = {}
         self.enabled = True  # False: buckets are tracked but nothing is exchanged (timing the step without it)
         n = max(1, bucket_bytes // flat.element_size())
@@ -52,10 +56,11 @@ class ReverseBucketReducer:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.deferred = []
+        self.issued = []
 
     def _active(self):
         return (self.enabled and dist.is_available() and dist.is_initialized()
-                and dist.get_world_size(self.group) > 1)
+                and (dist.get_world_size(self.group) > 1 or self.force_active))
 
     def layer_ready(self, li):
         for bi in self.layer_buckets[li]:
@@ -75,16 +80,19 @@ class ReverseBucketReducer:
                     shard = self._shards[bi] = torch.empty(((hi - lo) // world,), dtype=self.flat.dtype,
                                                            device=self.flat.device)
                 rs = dist.reduce_scatter_tensor(shard, self.flat[lo:hi], group=self.group, async_op=True)
+                self.issued.append("reduce_scatter_tensor")
                 if dist.get_backend(self.group) == "nccl":
                     # RCCL runs a communicator's collectives in issue order on its own stream: the gather can follow now
                     # and both overlap the rest of backward
                     self.works.append(rs)
                     self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], shard, group=self.group,
                                                                   async_op=True))
+                    self.issued.append("all_gather_into_tensor")
                 else:  # gloo runs asynchronous work items concurrently: the gather is issued once the scatter is done
                     self.deferred.append((rs, bi))
             else:  # "rccl", or a last bucket that does not divide into world shards
                 self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+                self.issued.append("all_reduce")
 
     def finish(self, average=True):
         for bi in range(len(self.buckets) - 1, -1, -1):
@@ -95,11 +103,14 @@ class ReverseBucketReducer:
             lo, hi = self.buckets[bi]
             self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], self._shards[bi], group=self.group,
                                                           async_op=True))
+            self.issued.append("all_gather_into_tensor")
         for w in self.works:
             w.wait()
         if average and self._active():
             self.flat.div_(dist.get_world_size(self.group))
+        issued = self.issued
         self.reset()
+        self.last_issued = issued
 
 
 def synthetic_ground_truth(sample, seed=0, num_alpha_bins=12, map_size=(48, 48)):
@@ -141,73 +152,6 @@ class _ConstantLr:
         self.use_moving_average = False
 
 
-class _StepGraph:
-    """InstanceTrainer.capture_step(): eager warm-up calls, one captured call, then replays (see there)."""
-    TICKS = 96  # eager launches on the caller's stream in front of every call (step())
-
-    def __init__(self, trainer, warmup):
-        self.tr, self.left = trainer, max(1, int(warmup))
-        dev = trainer.net.params.device
-        self.side = torch.cuda.Stream(device=dev)  # capture needs a non-default stream; the scratch caches are per stream
-        self.lr_t = torch.zeros((), dtype=torch.float32, device=dev)
-        self._tick = torch.zeros((), dtype=torch.float32, device=dev)  # (see step(): eager launches in front of every call)
-        self.graph = self.static = self.loss = None
-
-    def _copy_in(self, sample):
-        for k, v in sample.items():
-            if torch.is_tensor(v):
-                dst = self.static[k]
-                if dst.shape != v.shape or dst.dtype != v.dtype:
-                    raise _lib.InvalidArgumentError("captured step: sample[%r] is %s %s, the captured call saw %s %s" %
-                                                    (k, tuple(v.shape), v.dtype, tuple(dst.shape), dst.dtype))
-                if dst.data_ptr() != v.data_ptr():
-                    dst.copy_(v, non_blocking=True)
-            elif self.static.get(k) is not v and self.static.get(k) != v:
-                raise _lib.InvalidArgumentError("captured step: sample[%r] changed (only tensors may)" % k)
-
-    def step(self, sample):
-        tr = self.tr
-        main = torch.cuda.current_stream()
-        # Workaround, measured on this stack (ROCm 7.2, torch 2.10+rocm7.0; tools/graph_replay_probe.py): a replay of this
-        # ~1100-node graph that directly follows a device-wide synchronisation (a .cpu(), a checkpoint save / restore, an
-        # evaluation pass) after earlier replays came back with its FORWARD intact and scattered weight gradients
-        # non-finite in 10-30 % of the cases -- whichever kernels the step uses (every A/B switch of the library tried),
-        # eager steps never; a synchronisation or a spin kernel in front of the replay changes nothing.  Eager launches on
-        # the caller's stream in front of EVERY call of this method -- the warm-up calls and the capturing call included:
-        # in front of the replays alone they do not help (9 bad of 40) -- make it go away: 0 bad of 280 over the
-        # scenarios that failed (8 launches: 3 of 40; 64: 0 of 40).  The cause sits below this package, in how the graph
-        # is captured / launched around a synchronisation; the launches cost ~0.2 ms per step.
-        for _ in range(self.TICKS):
-            self._tick.add_(0.0)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            if self.graph is None and self.left > 0:  # eager, on the capturing stream
-                self.left -= 1
-                loss = tr._eager_step(sample)
-            elif self.graph is None:
-                self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()}
-                self.lr_t.fill_(tr.optimizer.lr_t_of(tr.net, tr.global_step))
-                torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=self.side):
-                    self.loss = tr._eager_step(self.static, lr_t_dev=self.lr_t)
-                # the graph's launches hold the addresses of this stream's scratch buffers: keep the tensors, so that a
-                # cache eviction (more than 8 streams using the package) cannot hand the memory to someone else
-                from monopsr_amd.core import device_net as dn
-                self.pinned = dn.pinned_stream_scratch(tr.net.params.device, self.side)
-                # (capture records, it does not run: this call's step is the first replay)
-                self.graph.replay()
-                loss = self.loss.clone()
-            else:
-                self._copy_in(sample)
-                self.lr_t.fill_(tr.optimizer.lr_t_of(tr.net, tr.global_step))
-                self.graph.replay()
-                tr.global_step += 1
-                loss = self.loss.clone()
-        main.wait_stream(self.side)
-        return loss
-
-
 class InstanceTrainer:
     """sample keys for step(): those of MonoPSRModel.build (rgb_image_crops, full_img_feature_crop, boxes_2d, cam_p,
     est_view_angs, class_indices, mean_lwh, prop_cen_z_offset) plus the ground truth the reference feeds through
@@ -215,7 +159,9 @@ class InstanceTrainer:
     gt_view_angs (B), gt_inst_xyz_maps_local / gt_inst_xyz_maps_global (B,h,w,3), gt_valid_mask_maps (B,h,w,1)."""
 
     def __init__(self, net, model_config, dataset_config, train_config=None, group=None, lr=None, clip_norm=1.0,
-                 bucket_bytes=64 << 20, classes_name='Car', allreduce="rccl"):
+                 bucket_bytes=64 << 20, classes_name='Car', allreduce="rccl", force_collectives=False):
+        """force_collectives: run the gradient exchange even on a one-rank process group (ReverseBucketReducer
+        force_active): the real RCCL calls of an N > 1 step on a single-GPU box."""
         self.net, self.model_config, self.dataset_config = net, model_config, dataset_config
         self.clip_norm, self.classes_name = clip_norm, classes_name
         self.model = MonoPSRModel(model_config, dataset_config, net, 'train', classes_name, fused_heads=False)
@@ -225,14 +171,14 @@ class InstanceTrainer:
             self.optimizer = optimizer_builder.build(train_config.optimizer)
         self.global_step = 0
         self._clip = None
-        self._graph = None
         spans = []
         base = net.grads.data_ptr()
         for L in net.layers:  # everything a layer's backward deposits: weight gradient and bias / beta gradient
             spans.append([((t.data_ptr() - base) // 4, (t.data_ptr() - base) // 4 + t.numel())
                           for t in (L.dw, L.db) if t is not None])
         self.spans = spans
-        self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group, mode=allreduce)
+        self.reducer = ReverseBucketReducer(net.grads, spans, bucket_bytes, group, mode=allreduce,
+                                            force_active=force_collectives)
         for li, L in enumerate(net.layers):
             L.on_grad_ready = (lambda i=li: self.reducer.layer_ready(i))
 
@@ -276,11 +222,11 @@ class InstanceTrainer:
         return self.net.grads
 
     def step(self, sample):
-        if self._graph is not None:
-            return self._graph.step(sample)
-        return self._eager_step(sample)
-
-    def _eager_step(self, sample, lr_t_dev=None):
+        """One training step, launched eagerly on the current stream.  (Rounds 4-5 also offered the step as ONE captured
+        HIP graph; it was removed in r06: it no longer beat the eager step -- 52.2 vs 51.1 ms, the eager launches are
+        back to back -- and replays that followed a device-wide synchronisation returned non-finite weight gradients
+        in 10-30 % of the cases on this ROCm 7.2 / torch 2.10 stack for a reason that was never found, while eager steps
+        with every uninitialised read made deterministic are clean: tests/test_poisoned_scratch_gpu.py.  DESIGN.md 4.6.)"""
         self.net.zero_grad()
         out = self.forward(sample)
         self.losses_dict, loss = self.loss(out, sample)
@@ -295,35 +241,9 @@ class InstanceTrainer:
         self.reducer.finish(average=True)
         if self.clip_norm:
             self.clip_per_variable()
-        if lr_t_dev is None:
-            self.optimizer.apply_gradients(self.net, self.global_step)
-        else:
-            self.optimizer.apply_gradients_lr_dev(self.net, lr_t_dev)
+        self.optimizer.apply_gradients(self.net, self.global_step)
         self.global_step += 1
         return loss.detach()
-
-    def capture_step(self, warmup=2):
-        """From now on step() replays ONE HIP graph: the ~1100 launches of a training step (forward, configured losses,
-        backward, clip, Adam, moving average) captured once -- the eager step leaves 2-3 ms of launch gaps per step in
-        its loss / head / optimizer sections, where the host issues hundreds of tiny kernels (`tools/train_bench.py
-        --graph`: 59.8 -> 56.8 ms).  The first `warmup` + 1 calls run eagerly (they size the per-stream scratch caches,
-        create the moving average and are the captured call); every later call copies the sample into the captured
-        call's tensors, writes the step's learning rate where the captured Adam launch reads it and replays.  Shapes
-        and dtypes of the sample must stay those of the first call.  Single-process training only: a data-parallel
-        step exchanges gradients through torch.distributed while backward runs and stays eager.
-        Two things to know before choosing it (r05): it no longer beats the eager step in time (52.2 vs 51.1 ms: the
-        eager launches are back to back by now), and replays of a graph this large need the workaround in
-        _StepGraph.step() on this ROCm / torch stack -- without it a replay that follows a device-wide synchronisation
-        returned non-finite gradients in 10-30 % of the cases (tools/graph_replay_probe.py)."""
-        if self.reducer._active():
-            raise RuntimeError("capture_step(): data-parallel steps stay eager (the bucketed all-reduce is issued "
-                               "from Python while backward runs)")
-        if self._graph is None:
-            self._graph = _StepGraph(self, warmup)
-        return self
-
-    def release_step_graph(self):
-        self._graph = None
 
     # ------------------------------------------------------------------ checkpoint / resume (core/trainer.py:85,149-185)
     def save(self, checkpoint_dir, name='monopsr'):
@@ -377,11 +297,7 @@ class InstanceTrainer:
         ema = t.get('monopsr_amd/flat_params/ExponentialMovingAverage')
         opt = self.optimizer
         if ema is not None and opt.shadow is not None and tuple(opt.shadow.shape) == tuple(ema.shape):
-            # in place: a captured step graph (capture_step) has this tensor's address baked into its lerp launch --
-            # rebinding the attribute would leave the replays averaging into a buffer nobody reads any more
-            opt.shadow.copy_(torch.from_numpy(ema).to(dev))
+            opt.shadow.copy_(torch.from_numpy(ema).to(dev))  # in place: anyone holding the tensor keeps seeing the average
         else:
             opt.shadow = None if ema is None else torch.from_numpy(ema).to(dev)
-            # the moving average appeared, vanished or changed size: a captured graph no longer describes the step
-            self.release_step_graph()
         return self.global_step

@@ -506,9 +506,18 @@ struct HeadIn {
     const float *boxes, *cam_p, *view, *mean_lwh, *z_off;
     const int *cls;
     const int *cam_idx;  // per box: which of the cam_p matrices (boxes of several images in one call), or nullptr: the first
+    int n_cams;          // cam_idx[b] outside [0, n_cams) reads kBadCam: that box's outputs are NaN, nothing is read out of bounds
     mpsr_head_consts k;
 };
-__device__ __forceinline__ const float *cam_of(const HeadIn &in, int b) { return in.cam_p + (in.cam_idx ? 12 * in.cam_idx[b] : 0); }
+__device__ const float kBadCam[12] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
+                                      __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
+                                      __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+__device__ __forceinline__ const float *cam_of(const HeadIn &in, int b)
+{
+    if (!in.cam_idx) return in.cam_p;
+    const int i = in.cam_idx[b];  // (a caller's index: guarded like crop_and_resize's box_ind, image_ops.hip)
+    return (i >= 0 && i < in.n_cams) ? in.cam_p + 12 * i : kBadCam;
+}
 
 // scalar features shared by both concat rows (monopsr_output_builder.py:147-158,228-240):
 // index 0..3 box coords in film coordinates / half image size, 4 box height / image height, 5 view angle,
@@ -638,7 +647,8 @@ extern "C" int mpsr_heads_fwd(const float *feat_box3d, int B, int feat_elems, co
 }
 
 // The boxes of SEVERAL images in one call: cam_p (n_cams,12), cam_index (B) in [0, n_cams) selects each box's projection
-// matrix (nullptr: all boxes use the first).  The reference's step is one image (monopsr_model.py:95, one pl_cam_p); a
+// matrix (nullptr: all boxes use the first; an index outside the range makes that box's outputs NaN -- never an
+// out-of-bounds read).  The reference's step is one image (monopsr_model.py:95, one pl_cam_p); a
 // batch of images is N such steps whose FC weights (150 MB) are then read once instead of N times.
 extern "C" int mpsr_heads_fwd_cams(const float *feat_box3d, int B, int feat_elems, const float *boxes_2d,
                                    const float *cam_p, int n_cams, const int *cam_index, const float *view_angs,
@@ -677,7 +687,7 @@ extern "C" int mpsr_heads_fwd_cams(const float *feat_box3d, int B, int feat_elem
 
     HeadIn in;
     in.boxes = boxes_2d; in.cam_p = cam_p; in.view = view_angs; in.mean_lwh = mean_lwh; in.z_off = cen_z_offset;
-    in.cls = class_idx; in.cam_idx = cam_index; in.k = *consts;
+    in.cls = class_idx; in.cam_idx = cam_index; in.n_cams = n_cams; in.k = *consts;
     int rc;
     // both img_fc layers share the flattened features: one GEMM, N = 2 x 1024, split along K = 18432
     if ((rc = run_layer(blob, L[0], feat_box3d, B, 1, 1, nullptr, imgfc, 0, skws, skn, s))) return rc;

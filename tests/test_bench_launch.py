@@ -170,7 +170,10 @@ def test_two_ranks_of_the_real_step_on_one_gpu():
     assert len(res["per_rank_ms_per_step"]) == 2 and max(res["per_rank_ms_per_step"]) <= res["ms_per_step"] * 1.05
     ts = res["training_step"]
     assert "error" not in ts, ts
-    assert ts["ranks"] == 2 and ts["grad_bytes"] > 250e6 and ts["ms_per_step"] > 0
+    # N > 1 default (r06): the both-trunk net -- SURVEY 8(d) cfg4's 100 M-parameter / 401 MB gradient is what the reducer
+    # carries (the reference trains both ResNet-101 trunks: net_builder.py:44-52, core/trainer.py:71-81)
+    assert ts["ranks"] == 2 and ts["params"] >= 100204832 and ts["grad_bytes"] >= 400819328 and ts["ms_per_step"] > 0
+    assert "both ResNet-101 trunks" in ts["trainable"]
     assert "exposed_allreduce_ms" in ts and "ms_per_step_without_allreduce" in ts
     emd = res["emd"]
     assert "error" not in emd and emd["all_ranks"]["ranks_ok"] == 2, emd

@@ -216,101 +216,68 @@ def test_export_weights_round_trips_into_the_inference_net(tmp_path):
     np.testing.assert_array_equal(eb[n + "/BatchNorm/moving_variance"], weights[n + "/BatchNorm/moving_variance"])
 
 
-def test_captured_step_trains_like_the_eager_step():
-    """InstanceTrainer.capture_step(): the whole step as one HIP-graph launch.  Two trainers from the same weights, the
-    same batches (a different one every step: the replay must read the NEW sample), an exponentially decaying learning
-    rate (the captured Adam launch must read the NEW rate) and the parameter moving average: the losses of every step and
-    the parameters / Adam moments / averages after eight steps agree to the run-to-run spread of the weight gradient's
-    atomics."""
+def test_save_restore_step_keeps_the_schedule_and_the_moving_average():
+    """Eight eager steps with an exponentially decaying learning rate and the parameter moving average, save, restore,
+    one more step: the restore puts the average back IN PLACE (anyone holding the tensor keeps seeing it), the next
+    step moves it by (1 - decay) x (params - average) like any other step, and a second save holds what the trainer
+    holds.  (Until r05 this scenario was driven through a captured HIP graph of the step; the captured step was removed
+    in r06 -- monopsr_amd/core/trainer.py: InstanceTrainer.step -- and its bounds, for the record, were: losses within
+    4 x the spread of two eager runs + 2e-3, state within 4 x that spread + 0.01 / 0.03, at a learning rate of 2e-5
+    because fixed bounds of 5e-3 (loss) and 0.03 / 0.10 (state) at 2e-4 failed one run in five for reasons of chaos.)"""
     from monopsr_amd.core import config_utils, train_net, trainer
     from monopsr_amd.core import weights as W
     B, div, steps = 4, 4, 8
     cfg = config_utils.default_config()
     opt = cfg.train_config.optimizer.adam_optimizer
-    # (2e-5: at ten times that rate the loss of this random-target problem jumps between 1.7e3 and 4.9e4 from step to
-    # step, two eager runs drift apart by percents within eight steps and a ninth step occasionally overflows)
     opt.learning_rate_type, opt.initial_learning_rate = 'exponential_decay', 2e-5
     opt.decay_steps, opt.decay_factor, opt.staircase = 2, 0.8, True
     opt.use_moving_average, opt.moving_average_decay = True, 0.9
-
-    def batches():
-        out = []
-        for i in range(steps):
-            rng = np.random.default_rng(500 + i)
-            y1, x1 = rng.uniform(0, 150, B), rng.uniform(0, 1000, B)
-            boxes = np.stack([y1, x1, y1 + rng.uniform(20, 200, B), x1 + rng.uniform(20, 200, B)], 1).astype(np.float32)
-            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-            s = dict(rgb_image_crops=dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
-                     full_img_feature_crop=dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0)
-                                               .astype(np.float32)),
-                     boxes_2d=dev(boxes), cam_p=dev(np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2],
-                                                              [0, 0, 1, 0.003]], np.float32)),
-                     est_view_angs=dev(rng.uniform(-0.6, 0.6, (B, 1)).astype(np.float32)),
-                     class_indices=dev(np.ones((B, 1), np.int32)),
-                     mean_lwh=dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
-                     prop_cen_z_offset=dev(np.full((B,), 2.178, np.float32)))
-            s.update(trainer.synthetic_ground_truth(s, seed=600 + i))
-            out.append(s)
-        return out
-    data = batches()
-    runs = {}
-    for kind in ("eager", "eager again", "graph"):
-        net = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
-        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
-        if kind == "graph":
-            tr.capture_step(warmup=2)
-        losses = [float(tr.step(s)) for s in data]
-        torch.cuda.synchronize()
-        assert tr.global_step == steps and net.step_count == steps
-        runs[kind] = (losses, net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), tr.optimizer.shadow.clone())
-    assert tr._graph.graph is not None  # steps 4..8 of the last run were replays
-    # The weight gradient's atomics differ in the last bits from run to run and Adam's m / sqrt(v) amplifies that on small
-    # gradients, so two EAGER runs already differ after eight steps -- by how much varies from run to run (fixed bounds
-    # on graph-vs-eager failed about one run in five).  The captured run is therefore held to a few times the spread of
-    # the two eager runs measured right here.  A replay that ignored the new sample, the new learning rate or the moving
-    # average would be off by tens of percent in these measures: orders of magnitude beyond that spread.
-    le, le2, lg = runs["eager"][0], runs["eager again"][0], runs["graph"][0]
-    assert abs(le[0] - lg[0]) <= 1e-6 * abs(le[0]), (le, lg)  # (the first forward pass has no atomics in front of it)
-    spread = max(abs(a - b) / abs(a) for a, b in zip(le, le2))
-    assert all(abs(a - b) <= (4 * spread + 2e-3) * abs(a) for a, b in zip(le, lg)), (le, le2, lg)
-    net0 = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
-    p0 = net0.params.clone()
-
-    def rel(i, other, shift):
-        a, b = runs["eager"][i] - shift, runs[other][i] - shift
-        return float((a - b).norm() / a.norm())
-    for i, name, floor in ((1, "params", 0.01), (4, "average", 0.01), (2, "adam_m", 0.03), (3, "adam_v", 0.03)):
-        shift = p0 if i in (1, 4) else 0.0
-        ee, ge = rel(i, "eager again", shift), rel(i, "graph", shift)
-        assert ge <= 4 * ee + floor, (name, ee, ge)
-        assert ge <= 0.5, (name, ge)  # (and in absolute terms nowhere near a replay that ignored an input)
-    # a sample of another shape is refused, not silently read through the captured tensors
-    bad = dict(data[0], rgb_image_crops=data[0]["rgb_image_crops"][:2])
-    with pytest.raises(ValueError):
-        tr.step(bad)
-    # ADVICE r4: capture -> restore -> step -> save.  restore() must leave the captured graph's moving-average tensor in
-    # place (its address is baked into the replayed lerp launch): the average keeps moving after a resume and save() /
-    # averaged_params() see it
+    data = []
+    for i in range(steps):
+        rng = np.random.default_rng(500 + i)
+        y1, x1 = rng.uniform(0, 150, B), rng.uniform(0, 1000, B)
+        boxes = np.stack([y1, x1, y1 + rng.uniform(20, 200, B), x1 + rng.uniform(20, 200, B)], 1).astype(np.float32)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        s = dict(rgb_image_crops=dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
+                 full_img_feature_crop=dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0)
+                                           .astype(np.float32)),
+                 boxes_2d=dev(boxes), cam_p=dev(np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2],
+                                                          [0, 0, 1, 0.003]], np.float32)),
+                 est_view_angs=dev(rng.uniform(-0.6, 0.6, (B, 1)).astype(np.float32)),
+                 class_indices=dev(np.ones((B, 1), np.int32)),
+                 mean_lwh=dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                 prop_cen_z_offset=dev(np.full((B,), 2.178, np.float32)))
+        s.update(trainer.synthetic_ground_truth(s, seed=600 + i))
+        data.append(s)
+    net = train_net.TrainNet(W.synthetic_weights(seed=77, width_div=div), width_div=div)
+    tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config)
+    losses = [float(tr.step(s)) for s in data]
+    assert np.isfinite(losses).all() and tr.global_step == steps and net.step_count == steps
+    assert abs(tr.optimizer.learning_rate(steps) - 2e-5 * 0.8 ** 4) < 1e-12  # staircase: 4 decays in 8 steps
     import tempfile
     with tempfile.TemporaryDirectory() as ckpt:
         prefix = tr.save(ckpt)
         shadow_ptr = tr.optimizer.shadow.data_ptr()
         before = tr.optimizer.shadow.clone()
+        pb = net.params.clone()
+        net.params.add_(1.0)  # (what a crash between save and resume leaves does not matter)
+        tr.optimizer.shadow.zero_()
         assert tr.restore(prefix) == steps
-        assert tr._graph is not None and tr.optimizer.shadow.data_ptr() == shadow_ptr
-        assert torch.equal(tr.optimizer.shadow, before)
+        assert tr.optimizer.shadow.data_ptr() == shadow_ptr and torch.equal(tr.optimizer.shadow, before)
+        assert torch.equal(net.params, pb) and net.step_count == steps
         float(tr.step(data[0]))
         torch.cuda.synchronize()
-        moved = float((tr.optimizer.shadow - before).abs().max())
-        assert moved > 0, "the moving average froze after restore()"
-        # it moved by (1 - decay) x (params - average), as one eager update would
+        assert bool(torch.isfinite(net.grads).all())
         want = before + (1.0 - 0.9) * (net.params - before)
+        assert float((tr.optimizer.shadow - before).abs().max()) > 0, "the moving average froze after restore()"
         assert float((tr.optimizer.shadow - want).abs().max()) <= 1e-5 * float(want.abs().max())
         from monopsr_amd.core import tf_checkpoint
         saved = tf_checkpoint.read_checkpoint(tr.save(ckpt))
         np.testing.assert_array_equal(saved['monopsr_amd/flat_params/ExponentialMovingAverage'],
                                       tr.optimizer.shadow.cpu().numpy())
-        # a checkpoint WITHOUT an average rebinds the attribute: the captured graph is dropped, not left replaying
+        # a checkpoint WITHOUT an average: the attribute is re-bound, the next step starts a new average
         tr.optimizer.shadow = None
         tr.restore(tr.save(ckpt))
-        assert tr._graph is None
+        assert tr.optimizer.shadow is None
+        float(tr.step(data[1]))
+        assert tr.optimizer.shadow is not None

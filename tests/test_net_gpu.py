@@ -1041,6 +1041,19 @@ def test_model_build_batch_of_images_equals_single_image_calls_and_oracle(golden
         for key in ("inst_xyz_map_local", "lwh", "alpha_bins", "centroids"):
             _close(batch[i][key], ref[key], 1e-4, "image %d %s (vs oracle)" % (i, key))
     assert model.build_batch([]) == []
+    # an image WITHOUT boxes between images with boxes (reshape(0, -1) used to raise), and only such images
+    def no_boxes(s):
+        e = dict(s)
+        for k in ("boxes_2d", "boxes_2d_norm", "est_view_angs", "class_indices", "mean_lwh", "prop_cen_z_offset"):
+            e[k] = s[k][:0]
+        return e
+    mixed = model.build_batch([dict(samples[1]), no_boxes(samples[2]), dict(samples[3])])
+    assert mixed[1]["centroids"].shape == (0, 3) and mixed[1]["inst_xyz_map_local"].shape[0] == 0
+    for j, i in ((0, 1), (2, 3)):
+        for key in keys:
+            _close(mixed[j][key], batch[i][key], 2e-5, "image %d %s (with an empty image in the call)" % (i, key))
+    none = model.build_batch([no_boxes(samples[0]), no_boxes(samples[1])])
+    assert [o["centroids"].shape for o in none] == [(0, 3), (0, 3)] and none[0]["inst_xyz_map_local"].shape == (0, 48, 48, 3)
 
 
 def test_heads_with_a_projection_matrix_per_box_equal_per_image_calls():
@@ -1068,6 +1081,17 @@ def test_heads_with_a_projection_matrix_per_box_equal_per_image_calls():
             _close(got[key][sl], one[key], 1e-5, "%s image %d" % (key, k))
     with pytest.raises(ValueError):
         net.heads_fwd(feat, _dev(boxes), _dev(cams), _dev(view), _dev(cls), _dev(mean_lwh), _dev(z_off))
+    # hostile cam_index: negative / past n_cams is never dereferenced -- those boxes' centroids are NaN, the
+    # other boxes keep their bits, and outputs that do not depend on the projection matrix stay finite
+    bad = idx.copy()
+    bad[1], bad[6] = -1, nimg + 1000000
+    hostile = net.heads_fwd(feat, _dev(boxes), _dev(cams), _dev(view), _dev(cls), _dev(mean_lwh), _dev(z_off),
+                            cam_index=_dev(bad))
+    ok = np.ones(B, bool)
+    ok[[1, 6]] = False
+    cen = hostile["centroids"].cpu().numpy()
+    assert np.isnan(cen[~ok]).any(axis=1).all() and np.isfinite(cen[ok]).all()
+    assert torch.equal(hostile["centroids"][torch.from_numpy(ok).cuda()], got["centroids"][torch.from_numpy(ok).cuda()])
 
 
 def test_evaluate_predictions_metrics():

@@ -142,3 +142,47 @@ def test_reducer_single_process_is_a_noop():
     red.layer_ready(0)
     red.finish()
     assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
+
+
+def _one_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from monopsr_amd.core import data_parallel
+        from monopsr_amd.core.trainer import ReverseBucketReducer
+        spans = [(0, 300), (300, 450), (450, 700), (700, 1000)]
+        res = {}
+        for mode in ("rccl", "direct"):
+            flat = torch.arange(1000, dtype=torch.float32)
+            idle = ReverseBucketReducer(flat, spans, bucket_bytes=250 * 4, mode=mode)
+            forced = ReverseBucketReducer(flat, spans, bucket_bytes=250 * 4, mode=mode, force_active=True)
+            for red in (idle, forced):
+                for li in (3, 2, 1, 0):
+                    red.layer_ready(li)
+                red.finish(average=True)
+            res[mode] = (idle._active(), forced._active(), list(idle.last_issued), sorted(set(forced.last_issued)),
+                         len(forced.last_issued), bool(torch.equal(flat, torch.arange(1000, dtype=torch.float32))))
+        x = torch.arange(12.0).reshape(4, 3)
+        res["gather"] = bool(torch.equal(data_parallel.gather_instances(x, 4, force_collective=True), x))
+        res["sums"] = data_parallel.reduce_metric_sums([torch.tensor(2.0), torch.tensor(3.0)],
+                                                       force_collective=True).tolist()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_on_a_one_rank_group_are_identities():
+    """force_active (the switch tests/test_rccl_one_rank_gpu.py uses to run the real RCCL calls on a single-GPU box): on a
+    one-rank group an unforced reducer issues nothing, a forced one issues every bucket's collectives and leaves the
+    buffer as it was; same for the metric path's helpers."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    res = q.get(timeout=5)
+    assert res["rccl"] == (False, True, [], ["all_reduce"], 4, True), res["rccl"]
+    assert res["direct"] == (False, True, [], ["all_gather_into_tensor", "reduce_scatter_tensor"], 8, True), res["direct"]
+    assert res["gather"] and res["sums"] == [2.0, 3.0]

@@ -26,9 +26,6 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="the step (forward, losses, backward, clip, Adam, moving average) captured into ONE HIP graph "
-                         "after two eager steps (InstanceTrainer.capture_step); single process only")
     ap.add_argument("--unfused-relu-grads", action="store_true",
                     help="A/B: the ReLU gradients inside a bottleneck unit as elementwise passes")
     ap.add_argument("--unlinked-units", action="store_true",
@@ -88,11 +85,6 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    if args.graph:  # the step as ONE HIP graph launch (InstanceTrainer.capture_step); eager warm-up + capture first
-        tr.capture_step(warmup=2)
-        for _ in range(3):
-            tr.step(sample)
-        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(tr.step(sample))
