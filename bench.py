@@ -236,7 +236,7 @@ def conv_replay(net, B):
         """-> the launch's output tensor (the last part's for a tap GEMM)."""
         r = part.records[idx]
         Bq, H, Wd = M_hw
-        n_in = Bq * H * Wd * r["cin"]
+        n_in = Bq * (override[0] * override[1] if override is not None else H * Wd) * r["cin"]
         if x is None:
             x = stand_in(n_in)
         assert x.numel() >= n_in, (idx, x.numel(), n_in)
@@ -286,7 +286,8 @@ def conv_replay(net, B):
             prev = None  # (its gather is vector work and is not replayed: the next layer reads a stand-in)
         else:
             # squash = two GEMMs over the K halves: crop features, then the full-image feature crop + the first as residual
-            xin = cur if k == 0 else None if k == 1 else prev
+            # (k = 2 / 4 outside the tap-GEMM form read a bilinear upsampling -- a vector kernel's result: stand-in)
+            xin = cur if k == 0 else None if k in (1, 2, 4) else prev
             prev = add(dec, k, (B, hw[0], hw[1]), x=xin, res=prev if k == 1 else None)
             jobs[-1]["kind"], jobs[-1]["ex"] = kinds7[k], ex7[k]
     hd = net.heads
@@ -457,7 +458,10 @@ def in_situ_object(one_step, executed_flops_per_step, ms_per_step, steps=4):
         short = next((k for k in MATRIX_KERNELS if k in name), None)
         if short is not None and "<" in name:  # keep the template arguments that tell the variants apart
             short += name[name.index("<"):name.index(">") + 1] if ">" in name else ""
-        key = ("matrix", short) if short is not None else ("vector", name.split("(")[0].split("::")[-1][:60])
+        if short is None:  # "void (anonymous namespace)::name<...>(args)" -> name
+            base = name.replace("(anonymous namespace)::", "").replace("void ", "")
+            base = base.split("(")[0].split("<")[0].split("::")[-1].strip() or name[:60]
+        key = ("matrix", short) if short is not None else ("vector", base[:60])
         d = fam.setdefault(key, [0.0, 0])
         d[0] += us
         d[1] += int(ev.count)

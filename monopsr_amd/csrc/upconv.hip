@@ -64,7 +64,11 @@ struct UpcParams {
 #ifndef UPC_NT
 #define UPC_NT 0
 #endif
+#ifndef UPC_DEFER
+#define UPC_DEFER 0  // 1: a band's results wait in registers and leave after the next band's rows are committed (r06 A/B: slower)
+#endif
 constexpr int kPf = 8;  // float4 registers per thread that carry source pixels on their way into LDS
+constexpr int kGrp = 4;  // output rows per thread and band whose results wait in registers until the band's stores
 std::atomic<int> g_upconv_band{0};  // mpsr_debug_set_upconv_band: output rows per band of the rolling window (0 = 8)
 
 // One workgroup per (8-channel block, image) walks the image in bands of RB output rows.  LDS is a ring of `cap` source
@@ -110,7 +114,11 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
             // (an unconditional load through a selected address -- unused slots re-read one cached line; a conditional
             // load, or HIP's float4 struct as the element type, sends the register array to scratch memory)
             const int pix = first + lgrp + j * lgroups;
+#ifdef UPC_SKIP_LOAD  // (timing experiments only -- tools/gather_bench.py: every request re-reads one cached line)
+            const bool live = false;
+#else
             const bool live = loader && pix < npix;
+#endif
 #if UPC_NT & 1
             pf[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(live ? zp + ((size_t)ra * p.w + pix) * PART + 4 * lpiece : zp));
 #else
@@ -170,6 +178,106 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
         }
     }
     __syncthreads();
+#if UPC_DEFER
+    // r06 A/B (-DUPC_DEFER=1; NOT the shipped form): a band's results wait in registers (kGrp items per thread) and leave
+    // AFTER the next band's rows have been committed.  Motive: gfx950 has one in-order counter for loads and stores, and
+    // with a store inside the item loop hipcc's wait for it also drains the prefetch loads issued at the top of the band;
+    // the knock-out builds (tools/gather_bench.py) showed the launch taking the SUM of its phases -- conv2_1 174 us = 51
+    // (stores, set-up) + 70 (the 36 LDS reads per output: 126 B/clk/CU, the LDS pipe's rate) + 43 (z loads).  Measured
+    // in one session against the r05 form: 243 vs 176 us (conv2_1), 389 vs 314 us (conv3_1) -- the stores as one burst
+    // behind the band cost more than the loads they stopped draining; the r05 form stays.
+    for (int k = 0; k < nbands; ++k) {
+        // rows the next band adds: (hi, nhi] -- at most kPf * lgroups pixels (gather_geometry)
+        int nlo = 0, nhi = hi;
+        if (k + 1 < nbands) band_rows(k + 1, nlo, nhi);
+        const int nnew = (nhi - hi) * p.w;
+        issue(hi + 1, nnew, 0);
+        const int y0 = k * p.RB, ylast = min(y0 + p.RB, p.H) - 1;
+        float4 res[kGrp];
+        auto flush = [&](int ybase) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < kGrp; ++g) {
+                const int y = ybase + g * rpp;
+                if (y > ylast) continue;
+                float *o = OUT_C8 ? p.y + ((((size_t)b * (p.N / 8) + blk) * p.H + y) * p.W + x) * 8 + 4 * half
+                                  : p.y + (((size_t)b * p.H + y) * p.W + x) * p.N + n0 + 4 * half;
+#ifdef UPC_SKIP_STORE  // (timing experiments only)
+                asm volatile("" ::"v"(res[g].x), "v"(res[g].y), "v"(res[g].z), "v"(res[g].w), "v"(o));
+#elif UPC_NT & 2
+                __builtin_nontemporal_store(f32x4{res[g].x, res[g].y, res[g].z, res[g].w}, reinterpret_cast<f32x4 *>(o));
+#else
+                *reinterpret_cast<float4 *>(o) = res[g];
+#endif
+            }
+        };
+        const int yb = y0 + rr;  // this thread's rows of the band: yb, yb + rpp, ... (at most kGrp: gather_geometry)
+        {
+#pragma unroll
+            for (int g = 0; g < kGrp; ++g) {
+                const int y = yb + g * rpp;
+                if (y > ylast) continue;
+                int ro[3][2];
+                float wy[3][2];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int qy = y + d - 1;
+                    const bool vy = qy >= 0 && qy < p.H;
+                    const float sy = (float)min(max(qy, 0), p.H - 1) * p.hscale;
+                    const int r0 = (int)floorf(sy), r1 = min(r0 + 1, p.h - 1);
+                    const float ly = sy - (float)r0;
+                    ro[d][0] = slot(r0) * rowf4;
+                    ro[d][1] = slot(r1) * rowf4;
+                    wy[d][0] = vy ? 1.f - ly : 0.f;
+                    wy[d][1] = vy ? ly : 0.f;
+                }
+                f32x2 a01 = {bias4.x, bias4.y}, a23 = {bias4.z, bias4.w};
+#ifdef UPC_SKIP_SUM  // (timing experiments only: one LDS read instead of 36, no arithmetic)
+                {
+                    const float4 v = src4[ro[1][0] + co[1][0]];
+                    a01 += f32x2{v.x, v.y} * f32x2{wy[1][0], wx[1][0]};
+                }
+#else
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int t2 = 2 * (dy * 3 + dx);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const float wgt = wy[dy][a] * wx[dx][c];
+                                const float4 v = src4[ro[dy][a] + co[dx][c] + t2];
+                                const f32x2 w2 = {wgt, wgt};
+                                a01 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, a01);
+                                a23 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, a23);
+                            }
+                    }
+#endif
+                float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+                if (p.relu) {
+                    acc.x = fmaxf(acc.x, 0.f);
+                    acc.y = fmaxf(acc.y, 0.f);
+                    acc.z = fmaxf(acc.z, 0.f);
+                    acc.w = fmaxf(acc.w, 0.f);
+                }
+                res[g] = acc;
+            }
+        }
+        if (k + 1 == nbands) {
+            flush(yb);
+            break;
+        }
+        __syncthreads();  // every thread has finished reading this band's rows: the ring may be overwritten
+        {
+            int row = lrow0, col = lcol0;
+            commit(hi + 1, nnew, 0, row, col);
+        }
+        flush(yb);  // behind the commit's wait for the rows: the stores no longer share a wait with the loads
+        __syncthreads();
+        hi = nhi;
+    }
+#else  // (the r05 form: every item stores its result at once -- kept for same-session A/B builds, -DUPC_DEFER=0)
     for (int k = 0; k < nbands; ++k) {
         // rows the next band adds: (hi, nhi] -- at most kPf * lgroups pixels (gather_geometry)
         int nlo = 0, nhi = hi;
@@ -233,6 +341,7 @@ __global__ __launch_bounds__(512) void upconv_gather_kernel(const UpcParams p)
         __syncthreads();
         hi = nhi;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -482,8 +591,14 @@ bool gather_geometry(int h, int w, int H, int W, float hscale, int *threads, int
     // a map whose source rows all fit a third of the LDS is ONE band (three workgroups per CU overlap each other's load
     // and arithmetic phases); otherwise bands of 8 rows (or one pass) with the next band's rows prefetched
     int rb = rpp > 8 ? rpp : 8;
-    if ((size_t)h * w * 288 <= kGatherLdsBytes * 3 / 5) rb = (H + rpp - 1) / rpp * rpp;
-    else if (g_upconv_band.load() > 0) rb = (g_upconv_band.load() + rpp - 1) / rpp * rpp;  // (tuning knob)
+    const int max_rb = UPC_DEFER ? kGrp * rpp : 1 << 30;  // (the deferred-store A/B form keeps kGrp rows per thread in registers)
+    if (rb > max_rb) rb = max_rb;
+    if (g_upconv_band.load() > 0) {  // (tuning knob: bands of this many rows, also where one band would do)
+        rb = (g_upconv_band.load() + rpp - 1) / rpp * rpp;
+        if (rb > max_rb) rb = max_rb;
+    } else if ((size_t)h * w * 288 <= kGatherLdsBytes * 3 / 5 && (H + rpp - 1) / rpp * rpp <= max_rb) {
+        rb = (H + rpp - 1) / rpp * rpp;
+    }
     // the kernel's own band arithmetic: the most rows a band reaches, the most a further band adds
     int rows = 0, add = 0, prev_hi = -1;
     for (int k = 0; k * rb < H; ++k) {

@@ -29,10 +29,15 @@ def main():
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--graph", action="store_true",
                     help="also time one image's launches captured into a HIP graph (torch.cuda.CUDAGraph) and replayed")
+    ap.add_argument("--knob", action="append", default=[],
+                    help="library debug knob for this run, e.g. --knob mpsr_debug_set_conv_sched=1 (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
+    for kv in args.knob:
+        name, val = kv.split("=")
+        getattr(_lib.lib(), name)(*[int(v) for v in val.split(",")])
     cfg = config_utils.default_config()
     weights = W.synthetic_weights(seed=0, scopes=(W.CROP_SCOPE, W.FULL_SCOPE))
     net = dn.DeviceNet(weights, device=dev, full_trunk=True)
@@ -80,7 +85,7 @@ def main():
         torch.cuda.synchronize()
         batched[str(n)] = round(e0.elapsed_time(e1) / (args.reps * n), 3)
     gflop = 2 * 167.1 + B * 12.393  # full-image trunk + per-crop path
-    out = {"workload": "full path: 375x1242 image + %d boxes" % B, "ms_per_image": round(ms, 3),
+    out = {"workload": "full path: 375x1242 image + %d boxes" % B, "knobs": args.knob, "ms_per_image": round(ms, 3),
            "images_per_s": round(1e3 / ms, 1), "crops_per_s": round(B * 1e3 / ms, 1),
            "algorithmic_GFLOP_per_image": round(gflop, 1), "TFLOP_per_s": round(gflop / ms, 1),
            "build_batch_ms_per_image_by_images_per_call": batched}
