@@ -106,7 +106,15 @@ int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, const float *xy
  * held constant) in one call that never materialises match: cost (b), grad1 = d cost / d xyz1 (b,n,3),
  * grad2 (b,m,3).  Every match entry is recomputed from the per-level ratios where it is consumed; results equal
  * mpsr_approx_match + mpsr_match_cost + mpsr_match_cost_grad to fp32 summation order.  grad1 / grad2 may be NULL
- * (cost only: the metric of monopsr_model.py:1143-1149).  temp: mpsr_emd_temp_floats(b,n,m,semantics) floats. */
+ * (cost only: the metric of monopsr_model.py:1143-1149).  temp: mpsr_emd_temp_floats(b,n,m,semantics) floats, or --
+ * ABI 6 -- mpsr_emd_loss_temp_floats(b,n,m,semantics): with that much scratch (the state + both clouds re-ordered +
+ * their permutations: b*(n+m)*4 floats more; device semantics, clouds of up to 4096 points) the call CULLS LEVELS: it
+ * sorts both clouds into Morton order and leaves out, chunk of 32 points by chunk, the pairs whose exponential
+ * exp(level * d^2) is exactly zero in fp32 at the four steepest levels (-16384 .. -256: d beyond 0.08 .. 0.64) -- the
+ * reference's kernels evaluate every pair at every level (tf_approxmatch_g.cu:21-160).  Same terms otherwise, summed in
+ * the order of the sorted clouds: equal to the plain evaluation up to fp32 summation order (held to 2e-5 by the tests).
+ * Gradients come back in the caller's point order. */
+size_t mpsr_emd_loss_temp_floats(int b, int n, int m, int semantics);
 int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
                   float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream);
 

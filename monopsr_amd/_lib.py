@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPSR_LIB_PATH: development knob for A/B-ing two builds of the library inside one GPU session
 LIB_PATH = os.environ.get("MPSR_LIB_PATH") or os.path.join(_HERE, "libmonopsr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     "mpsr_nn_distance_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_approx_match_temp_floats": (c_sz, [c_i, c_i, c_i]),
     "mpsr_emd_temp_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "mpsr_emd_loss_temp_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "mpsr_approx_match": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "mpsr_approx_match_ex": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_sz, c_i, c_f]),
     "mpsr_emd_loss": (c_i, [c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_f]),

@@ -12,7 +12,7 @@ thread_local int t_call_wino_policy = -1;
 }  // namespace mpsr
 
 extern "C" const char *mpsr_last_error(void) { return mpsr::error_buffer(); }
-extern "C" int mpsr_abi_version(void) { return 5; }
+extern "C" int mpsr_abi_version(void) { return 6; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host.  Used by the TensorFlow
 // checkpoint reader/writer (core/tf_checkpoint.py) to verify block trailers and tensor payloads.

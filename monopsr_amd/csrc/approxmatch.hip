@@ -117,6 +117,165 @@ __device__ __forceinline__ double sqdist_d(float ax, float ay, float az, float b
     return dx * dx + dy * dy + dz * dz;
 }
 
+// ---------------------------------------------------------------------------------------------------- spatial order
+// r06: level culling for the fused loss (mpsr_emd_loss; the reference evaluates every pair at every level:
+// tf_approxmatch_g.cu:21-160).  e = exp(level * d^2) is EXACTLY zero in fp32 once level * d^2 * log2(e) < -150 (below
+// half the smallest denormal), and a zero term changes no sum.  At the steepest levels (-16384, -4096, -1024, -256) that
+// is d > 0.08 / 0.16 / 0.32 / 0.64 -- most pairs of a unit-scale cloud -- but a wave can only leave pairs out together, so
+// both clouds are first brought into Morton order (emd_sort_kernel: one workgroup per cloud, bitonic sort in LDS, the
+// permutation kept for the gradients' way back); a wave's own points (128 consecutive points of that order) and every
+// 32-point chunk of the staged opposite tile then have small bounding boxes, and a chunk whose box is farther from the
+// wave's box than the level's cut-off is skipped by a wave-uniform branch.  What is evaluated is evaluated as before, in
+// the order of the SORTED clouds: results differ from the unsorted evaluation by fp32 summation order only (the op's
+// budget is 1e-3; tests hold the culled loss to 2e-5 of the plain one).
+constexpr int kSortMax = 4096;    // points per cloud the in-LDS sort takes; larger clouds run without culling
+constexpr int kChunk = 32;        // staged opposite points per bounding box
+constexpr float kCullExp = -150.f;  // exp2 of anything below is +0 in fp32 (denormals kept or flushed)
+constexpr int kNeverCull = 0x100;  // flag bit (`skip` / `flags` kernel arguments): chunk tests always fail (mpsr_debug_set_emd_cull(2))
+
+__device__ __forceinline__ unsigned spread3(unsigned v)  // 5 bits -> every third bit
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// grid (b, 2): blockIdx.y = 0 sorts cloud 1 (n points), 1 cloud 2 (m points).  sorted = the points in Morton order of a
+// 32^3 grid over the cloud's own bounding box (ties and equal cells by original index: the order is a function of the
+// coordinates alone, run to run), perm[i] = original index of sorted point i.
+__global__ __launch_bounds__(256) void emd_sort_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                      const float *__restrict__ xyz2, float *__restrict__ s1,
+                                                      float *__restrict__ s2, int *__restrict__ perm1,
+                                                      int *__restrict__ perm2)
+{
+    __shared__ unsigned keys[kSortMax];
+    __shared__ float red[6][4];
+    const int cloud = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+    const int cnt = which ? m : n;
+    const float *p = (which ? xyz2 : xyz1) + (size_t)cloud * cnt * 3;
+    float *ps = (which ? s2 : s1) + (size_t)cloud * cnt * 3;
+    int *pp = (which ? perm2 : perm1) + (size_t)cloud * cnt;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < cnt; i += 256)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = p[3 * i + d];
+            lo[d] = fminf(lo[d], v);  // (fminf / fmaxf drop NaN coordinates)
+            hi[d] = fmaxf(hi[d], v);
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = wave_min_f(lo[d]);
+        hi[d] = wave_max_f(hi[d]);
+        if ((tid & 63) == 0) {
+            red[d][tid >> 6] = lo[d];
+            red[3 + d][tid >> 6] = hi[d];
+        }
+    }
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(fminf(red[d][0], red[d][1]), fminf(red[d][2], red[d][3]));
+        hi[d] = fmaxf(fmaxf(red[3 + d][0], red[3 + d][1]), fmaxf(red[3 + d][2], red[3 + d][3]));
+        const float ext = hi[d] - lo[d];
+        scale[d] = (ext > 0.f && ext < __builtin_inff()) ? 32.f / ext : 0.f;
+    }
+    int P = 1;
+    while (P < cnt) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        unsigned key = 0xffffffffu;
+        if (i < cnt) {
+            unsigned q[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)  // (a NaN / infinite coordinate lands in cell 0 / 31: any cell is correct, only slower)
+                q[d] = (unsigned)fminf(fmaxf((p[3 * i + d] - lo[d]) * scale[d], 0.f), 31.f);
+            key = ((spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2)) << 16) | (unsigned)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 256) {
+                const int ix = ((t & ~(j - 1)) << 1) | (t & (j - 1)), px = ix | j;
+                const unsigned a = keys[ix], c = keys[px];
+                const bool up = (ix & k) == 0;
+                if ((a > c) == up) {
+                    keys[ix] = c;
+                    keys[px] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < cnt; i += 256) {
+        const int src = (int)(keys[i] & 0xffffu);
+        pp[i] = src;
+        ps[3 * i] = p[3 * src];
+        ps[3 * i + 1] = p[3 * src + 1];
+        ps[3 * i + 2] = p[3 * src + 2];
+    }
+}
+
+// Bounding boxes of the kChunk-entry chunks of a staged tile (entries [0, cnt) of `tile`, up to `cap` entries; the caller
+// has synchronised after staging and synchronises again before reading `box`).  Thread t looks at entries 4 t .. 4 t + 3.
+__device__ __forceinline__ void chunk_boxes(const float4 *tile, int cnt, int cap, int tid, float (*box)[6])
+{
+    if (4 * tid >= cap) return;  // (whole waves: cap is a multiple of 256)
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = 4 * tid + e;
+        if (q < cnt) {
+            const float4 t = tile[q];
+            lo[0] = fminf(lo[0], t.x); hi[0] = fmaxf(hi[0], t.x);
+            lo[1] = fminf(lo[1], t.y); hi[1] = fmaxf(hi[1], t.y);
+            lo[2] = fminf(lo[2], t.z); hi[2] = fmaxf(hi[2], t.z);
+            if (!(t.x == t.x && t.y == t.y && t.z == t.z)) {  // a NaN point poisons every sum it enters: never skipped
+                lo[0] = lo[1] = lo[2] = -__builtin_inff();
+                hi[0] = hi[1] = hi[2] = __builtin_inff();
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 1; o < kChunk / 4; o <<= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+        }
+    if ((tid & (kChunk / 4 - 1)) == 0) {
+        float *b = box[(4 * tid) / kChunk];
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
+        b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+    }
+}
+
+// squared distance between a chunk's box and the wave's box (0 when they touch; +inf for an empty box)
+__device__ __forceinline__ float box_gap2(const float *cb, const float wlo[3], const float whi[3])
+{
+    float g2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float g = fmaxf(fmaxf(cb[d] - whi[d], wlo[d] - cb[3 + d]), 0.f);
+        g2 += g * g;
+    }
+    return g2;
+}
+
 // ---------------------------------------------------------------------------------------------------- state
 // Per cloud, in words of S: remL[n] remR[m] ratL[slots][n] ratR[slots][m]; slots = levels (ratios of every level
 // kept for the emit / loss kernels) or 1 (compact path).
@@ -140,14 +299,20 @@ struct State {
 // ---------------------------------------------------------------------------------------------------- giver pass
 // Own points = givers k.  MODE 0: sweep 1 of level `lev` only (the first launch); 1: sweep 3 of level lev-1 and sweep
 // 1 of level lev; 2: sweep 3 of level lev-1 only (the last launch).  grid (ceil(n / 512), b).
-template <bool HOST, int MODE>
+// CULL (DEVICE only; the clouds are in Morton order: "spatial order" above): a wave's own points are 128 CONSECUTIVE
+// points, chunks of the staged tile farther from their box than the level's cut-off are skipped.
+template <bool HOST, int MODE, bool CULL = false>
 __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2, void *temp, int lev,
                                                             int slots, size_t cstride, int skip)
 {
     using S = typename Sem<HOST>::S;
+    static_assert(!(HOST && CULL), "culling is a DEVICE-semantics path");
+    const float cull_exp = (skip & kNeverCull) ? -__builtin_inff() : kCullExp;  // (test mode: sorted clouds, nothing skipped)
+    skip &= 0xff;
     constexpr bool kDo3 = MODE != 0, kDo1 = MODE != 2;
     __shared__ float4 tile[kTile];  // x, y, z, (DEVICE) weight of sweep 3
+    __shared__ float cbox[CULL ? kTile / kChunk : 1][6];
     __shared__ S w1s[kTile];        // weight of sweep 1 (remR)
     __shared__ S w3s[HOST ? kTile : 1];
     const int cloud = blockIdx.y, tid = threadIdx.x;
@@ -163,14 +328,33 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
     const float lv_cur = kDo1 ? level_value<HOST>(lev) : 0.f, lv_prev = kDo3 ? level_value<HOST>(lev - 1) : 0.f;
 
     const int base = blockIdx.x * (kThreads * kPT);
+    // own point u of this thread (CULL: the wave's points are consecutive: wave w owns base + 128 w .. + 127)
+    auto own_index = [&](int u) __attribute__((always_inline)) {
+        return CULL ? base + (tid >> 6) * (64 * kPT) + u * 64 + (tid & 63) : base + u * kThreads + tid;
+    };
     float ox[kPT], oy[kPT], oz[kPT];
+    float wlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float whi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kThreads + tid;
+        const int i = own_index(u);
         const bool live = i < n;
         ox[u] = live ? p1[3 * i] : 0.f;
         oy[u] = live ? p1[3 * i + 1] : 0.f;
         oz[u] = live ? p1[3 * i + 2] : 0.f;
+        if (CULL && live) {
+            const bool ok = ox[u] == ox[u] && oy[u] == oy[u] && oz[u] == oz[u];  // (a NaN point: box = everything)
+            wlo[0] = ok ? fminf(wlo[0], ox[u]) : -__builtin_inff(); whi[0] = ok ? fmaxf(whi[0], ox[u]) : __builtin_inff();
+            wlo[1] = ok ? fminf(wlo[1], oy[u]) : -__builtin_inff(); whi[1] = ok ? fmaxf(whi[1], oy[u]) : __builtin_inff();
+            wlo[2] = ok ? fminf(wlo[2], oz[u]) : -__builtin_inff(); whi[2] = ok ? fmaxf(whi[2], oz[u]) : __builtin_inff();
+        }
+    }
+    if constexpr (CULL) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wlo[d] = wave_min_f(wlo[d]);
+            whi[d] = wave_max_f(whi[d]);
+        }
     }
     S s1[kPT], s3[kPT];
 #pragma unroll
@@ -253,6 +437,10 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
             cnt = total;  // block-uniform
         }
         __syncthreads();
+        if constexpr (CULL) {
+            chunk_boxes(tile, cnt, kTile, tid, cbox);
+            __syncthreads();
+        }
         if constexpr (HOST) {
             for (int o = 0; o < cnt; ++o) {
                 const float4 t = tile[o];
@@ -269,8 +457,16 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
             // select per pair (hipcc does not unswitch it: 5 of 17 instructions per pair pair were selects and moves)
             auto sweep = [&](auto zero_c) {
                 constexpr bool kZero = decltype(zero_c)::value;
+                for (int c0 = 0; c0 < cnt; c0 += CULL ? kChunk : kTile) {
+                int c1 = cnt;
+                if constexpr (CULL) {
+                    // the SMALLER level of the pass decides (the steeper one's term vanishes with it): c_small < 0.
+                    // (never at the zero level, whose sweep-1 term does not depend on the distance)
+                    if (!kZero && c_small * box_gap2(cbox[c0 / kChunk], wlo, whi) < cull_exp) continue;  // wave-uniform
+                    c1 = min(c0 + kChunk, cnt);
+                }
 #pragma unroll 4
-                for (int o = 0; o < cnt; ++o) {
+                for (int o = c0; o < c1; ++o) {
                     const float4 t = tile[o];
                     const float w1 = kDo1 ? w1s[o] : 0.f;
 #pragma unroll
@@ -296,6 +492,7 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
                         }
                     }
                 }
+                }
             };
             if (MODE == 1 && cur_zero) sweep(std::true_type{});
             else sweep(std::false_type{});
@@ -310,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
     }
 #pragma unroll
     for (int u = 0; u < kPT; ++u) {
-        const int i = base + u * kThreads + tid;
+        const int i = own_index(u);
         if (i >= n) continue;
         S rem = first ? multiL : (first3 ? multiL : st.remL[i]);
         if (kDo3) {
@@ -326,13 +523,17 @@ __global__ __launch_bounds__(kThreads) void emd_giver_kernel(int n, int m, const
 
 // ---------------------------------------------------------------------------------------------------- receiver pass
 // Own points = receivers l: sweep 2 of level `lev`.  grid (ceil(m / 512), b).
-template <bool HOST>
+template <bool HOST, bool CULL = false>
 __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, const float *__restrict__ xyz1,
                                                                const float *__restrict__ xyz2, void *temp, int lev,
                                                                int slots, size_t cstride, int skip)
 {
     using S = typename Sem<HOST>::S;
+    static_assert(!(HOST && CULL), "culling is a DEVICE-semantics path");
+    const float cull_exp = (skip & kNeverCull) ? -__builtin_inff() : kCullExp;  // (test mode: sorted clouds, nothing skipped)
+    skip &= 0xff;
     __shared__ float4 tile[kTile];
+    __shared__ float cbox[CULL ? kTile / kChunk : 1][6];
     __shared__ S ws[HOST ? kTile : 1];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float *p1 = xyz1 + (size_t)cloud * n * 3;
@@ -373,7 +574,8 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
     if (HOST || first || slots <= 1 || !skip) {
 #pragma unroll
         for (int u = 0; u < kPT; ++u) {
-            const int i = base + u * kThreads + tid;
+            // (CULL: a wave's own receivers are consecutive, as in the compacted form below)
+            const int i = CULL ? base + (tid >> 6) * (64 * kPT) + u * 64 + (tid & 63) : base + u * kThreads + tid;
             oi[u] = i < m ? i : -1;
         }
     } else {
@@ -433,6 +635,23 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
         oy[u] = live ? p2[3 * i + 1] : 0.f;
         oz[u] = live ? p2[3 * i + 2] : 0.f;
     }
+    float wlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float whi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    if constexpr (CULL) {
+#pragma unroll
+        for (int u = 0; u < kPT; ++u)
+            if (oi[u] >= 0) {
+                const bool ok = ox[u] == ox[u] && oy[u] == oy[u] && oz[u] == oz[u];  // (a NaN point: box = everything)
+                wlo[0] = ok ? fminf(wlo[0], ox[u]) : -__builtin_inff(); whi[0] = ok ? fmaxf(whi[0], ox[u]) : __builtin_inff();
+                wlo[1] = ok ? fminf(wlo[1], oy[u]) : -__builtin_inff(); whi[1] = ok ? fmaxf(whi[1], oy[u]) : __builtin_inff();
+                wlo[2] = ok ? fminf(wlo[2], oz[u]) : -__builtin_inff(); whi[2] = ok ? fmaxf(whi[2], oz[u]) : __builtin_inff();
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wlo[d] = wave_min_f(wlo[d]);
+            whi[d] = wave_max_f(whi[d]);
+        }
+    }
     S t_[kPT];
     f32x2 vx[kPV], vy[kPV], vz[kPV], acc[kPV];
 #pragma unroll
@@ -454,6 +673,10 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
             if (HOST) ws[q] = w;
         }
         __syncthreads();
+        if constexpr (CULL) {
+            chunk_boxes(tile, cnt, kTile, tid, cbox);
+            __syncthreads();
+        }
         if constexpr (HOST) {
             for (int o = 0; o < cnt; ++o) {
                 const float4 t = tile[o];
@@ -464,18 +687,29 @@ __global__ __launch_bounds__(kThreads) void emd_receiver_kernel(int n, int m, co
             }
         } else {
             const int o_begin = wave_active ? cnt * seg / nsplit : 0, o_end = wave_active ? cnt * (seg + 1) / nsplit : 0;
-#pragma unroll 4
-            for (int o = o_begin; o < o_end; ++o) {
-                const float4 t = tile[o];
-#pragma unroll
-                for (int v = 0; v < kPV; ++v) {
-                    const f32x2 dx = vx[v] - t.x, dy = vy[v] - t.y, dz = vz[v] - t.z;
-                    const f32x2 a = c * (dx * dx + dy * dy + dz * dz);
-                    f32x2 e;
-                    e[0] = __builtin_amdgcn_exp2f(a[0]);
-                    e[1] = __builtin_amdgcn_exp2f(a[1]);
-                    acc[v] += e * t.w;
+            for (int c0 = o_begin; c0 < o_end;) {
+                int c1 = o_end;
+                if constexpr (CULL) {
+                    c1 = min((c0 / kChunk + 1) * kChunk, o_end);  // up to the end of c0's chunk
+                    if (c * box_gap2(cbox[c0 / kChunk], wlo, whi) < cull_exp) {  // wave-uniform; c < 0 (never the zero level)
+                        c0 = c1;
+                        continue;
+                    }
                 }
+#pragma unroll 4
+                for (int o = c0; o < c1; ++o) {
+                    const float4 t = tile[o];
+#pragma unroll
+                    for (int v = 0; v < kPV; ++v) {
+                        const f32x2 dx = vx[v] - t.x, dy = vy[v] - t.y, dz = vz[v] - t.z;
+                        const f32x2 a = c * (dx * dx + dy * dy + dz * dz);
+                        f32x2 e;
+                        e[0] = __builtin_amdgcn_exp2f(a[0]);
+                        e[1] = __builtin_amdgcn_exp2f(a[1]);
+                        acc[v] += e * t.w;
+                    }
+                }
+                c0 = c1;
             }
         }
     }
@@ -742,14 +976,21 @@ __global__ __launch_bounds__(256) void emd_loss_kernel(int n, int m, const float
 // costs (distance, fourth powers, the ten level terms, gradient) issue as packed fp32, which leaves the five
 // transcendentals per pair (3 exp2, rsqrt; sqrt(d2) is taken as d2 * rsqrt) as the larger share.  Same terms in the
 // same order as pair_match<false> / emd_loss_kernel<false, ROLE>.  grid (ceil(own / 512), b).
-template <int ROLE>
+// CULL: the clouds are in Morton order ("spatial order" above), a wave's own points are 128 consecutive ones, and for a
+// chunk of the tile farther than 0.32 from the wave's box the three steepest levels (e[0..2] = exp(-16384 / -4096 /
+// -1024 d^2), one of the three exponentials and four of the twelve squarings) are exactly zero and are left out; perm =
+// original index of sorted own point i (the gradient goes back to the caller's order).
+template <int ROLE, bool CULL = false>
 __global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2, void *temp,
-                                                         float *__restrict__ cost, float *__restrict__ grad)
+                                                         float *__restrict__ cost, float *__restrict__ grad,
+                                                         const int *__restrict__ perm, int flags)
 {
     constexpr int L = Sem<false>::levels;
+    const float cull_exp = (flags & kNeverCull) ? -__builtin_inff() : kCullExp;  // (test mode: sorted clouds, nothing skipped)
     __shared__ float4 tp[kLossTile];
     __shared__ float tr[kLossTile][L + 2];
+    __shared__ float cbox[CULL ? kLossTile / kChunk : 1][6];
     __shared__ double part[4];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const int nown = ROLE == 0 ? n : m, nother = ROLE == 0 ? m : n;
@@ -757,11 +998,30 @@ __global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const fl
     const float *other = (ROLE == 0 ? xyz2 : xyz1) + (size_t)cloud * nother * 3;
     const State<false> st(temp, cloud, n, m, L);
     const float *ratOwn = ROLE == 0 ? st.ratL : st.ratR, *ratOther = ROLE == 0 ? st.ratR : st.ratL;
-    const int i0 = blockIdx.x * 512 + tid, i1 = i0 + 256;
+    const int i0 = CULL ? blockIdx.x * 512 + (tid >> 6) * 128 + (tid & 63) : blockIdx.x * 512 + tid;
+    const int i1 = CULL ? i0 + 64 : i0 + 256;
     const bool live0 = i0 < nown, live1 = i1 < nown;
     const f32x2 vx = {live0 ? own[3 * i0] : 0.f, live1 ? own[3 * i1] : 0.f};
     const f32x2 vy = {live0 ? own[3 * i0 + 1] : 0.f, live1 ? own[3 * i1 + 1] : 0.f};
     const f32x2 vz = {live0 ? own[3 * i0 + 2] : 0.f, live1 ? own[3 * i1 + 2] : 0.f};
+    float wlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float whi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    if constexpr (CULL) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h == 0 ? live0 : live1) {
+                const float px = vx[h], py = vy[h], pz = vz[h];
+                const bool ok = px == px && py == py && pz == pz;  // (a NaN point: box = everything)
+                wlo[0] = ok ? fminf(wlo[0], px) : -__builtin_inff(); whi[0] = ok ? fmaxf(whi[0], px) : __builtin_inff();
+                wlo[1] = ok ? fminf(wlo[1], py) : -__builtin_inff(); whi[1] = ok ? fmaxf(whi[1], py) : __builtin_inff();
+                wlo[2] = ok ? fminf(wlo[2], pz) : -__builtin_inff(); whi[2] = ok ? fmaxf(whi[2], pz) : __builtin_inff();
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wlo[d] = wave_min_f(wlo[d]);
+            whi[d] = wave_max_f(whi[d]);
+        }
+    }
     f32x2 ro[L];
 #pragma unroll
     for (int q = 0; q < L; ++q)
@@ -776,16 +1036,23 @@ __global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const fl
         }
         for (int q = tid; q < cnt * L; q += 256) tr[q % cnt][q / cnt] = ratOther[(size_t)(q / cnt) * nother + o0 + q % cnt];
         __syncthreads();
-        if (!live0) continue;  // a whole wave at a time (own points are taken in blocks of 256)
-        for (int o = 0; o < cnt; ++o) {
+        if constexpr (CULL) {
+            chunk_boxes(tp, cnt, kLossTile, tid, cbox);
+            __syncthreads();
+        }
+        // (CULL: a wave whose own points are all past the cloud's end has an empty box and skips every chunk)
+        if (!CULL && !live0) continue;  // a whole wave at a time (own points are taken in blocks of 256)
+        // one pair pair; kSteep = false: the three steepest levels are known to be zero for it
+        auto pair = [&](int o, auto steep_c) __attribute__((always_inline)) {
+            constexpr bool kSteep = decltype(steep_c)::value;
+            constexpr int q0 = kSteep ? 0 : 3;
             const float4 t = tp[o];
             const f32x2 dx = vx - t.x, dy = vy - t.y, dz = vz - t.z;  // own - other
             const f32x2 d2 = dx * dx + dy * dy + dz * dz;
             f32x2 e[9];
-            const f32x2 a8 = (-0.25f * kLog2e) * d2, a5 = (-16.f * kLog2e) * d2, a2 = (-1024.f * kLog2e) * d2;
+            const f32x2 a8 = (-0.25f * kLog2e) * d2, a5 = (-16.f * kLog2e) * d2;
             e[8] = f32x2{__builtin_amdgcn_exp2f(a8[0]), __builtin_amdgcn_exp2f(a8[1])};
             e[5] = f32x2{__builtin_amdgcn_exp2f(a5[0]), __builtin_amdgcn_exp2f(a5[1])};
-            e[2] = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
             auto p4 = [](f32x2 v) {
                 v = v * v;
                 return v * v;
@@ -794,11 +1061,15 @@ __global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const fl
             e[6] = p4(e[7]);
             e[4] = p4(e[5]);
             e[3] = p4(e[4]);
-            e[1] = p4(e[2]);
-            e[0] = p4(e[1]);
+            if constexpr (kSteep) {
+                const f32x2 a2 = (-1024.f * kLog2e) * d2;
+                e[2] = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+                e[1] = p4(e[2]);
+                e[0] = p4(e[1]);
+            }
             f32x2 acc = {0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = q0; q < 9; ++q) {
                 // e * (giver ratio) * (receiver ratio), as pair_match
                 if (ROLE == 0) acc += e[q] * ro[q] * tr[o][q];
                 else acc += e[q] * tr[o][q] * ro[q];
@@ -812,17 +1083,31 @@ __global__ __launch_bounds__(256) void emd_loss_pk_kernel(int n, int m, const fl
             gy += dy * sc;
             gz += dz * sc;
             if (ROLE == 0) csum += d2 * sc;  // |d| * match with |d| = d2 * rsqrt(d2)
+        };
+        if constexpr (CULL) {
+            for (int c0 = 0; c0 < cnt; c0 += kChunk) {
+                const int c1 = min(c0 + kChunk, cnt);
+                const float g2 = box_gap2(cbox[c0 / kChunk], wlo, whi);
+                if (!(g2 < __builtin_inff())) continue;  // an empty box on either side: nothing to pair
+                if ((-1024.f * kLog2e) * g2 < cull_exp) {  // wave-uniform
+                    for (int o = c0; o < c1; ++o) pair(o, std::false_type{});
+                } else {
+                    for (int o = c0; o < c1; ++o) pair(o, std::true_type{});
+                }
+            }
+        } else {
+            for (int o = 0; o < cnt; ++o) pair(o, std::true_type{});
         }
     }
     if (grad) {
         if (live0) {
-            float *g = grad + ((size_t)cloud * nown + i0) * 3;
+            float *g = grad + ((size_t)cloud * nown + (CULL ? perm[(size_t)cloud * nown + i0] : i0)) * 3;
             g[0] = gx[0];
             g[1] = gy[0];
             g[2] = gz[0];
         }
         if (live1) {
-            float *g = grad + ((size_t)cloud * nown + i1) * 3;
+            float *g = grad + ((size_t)cloud * nown + (CULL ? perm[(size_t)cloud * nown + i1] : i1)) * 3;
             g[0] = gx[1];
             g[1] = gy[1];
             g[2] = gz[1];
@@ -970,6 +1255,8 @@ __global__ __launch_bounds__(256) void match_cost_grad2_kernel(int n, int m, con
 // (bit-identical results); 2 (default): and the receiver pass splits its giver loop over the waves when few receivers
 // are live (same terms, another summation order).  Tests compare the three.
 std::atomic<int> g_emd_skip{2};
+std::atomic<int> g_emd_cull{1};  // mpsr_debug_set_emd_cull: level culling in mpsr_emd_loss (0 = never; 2 = sorted clouds, every chunk test fails: tests)
+constexpr int kCullLevels = 4;   // levels -16384 .. -256: cut-offs 0.08 .. 0.64 (beyond, nothing of a unit-scale cloud culls)
 
 int check_emd_args(const char *op, int b, int n, int m)
 {
@@ -987,22 +1274,52 @@ size_t state_floats(int b, int n, int m, int levels, bool host)
 
 // the 2L + 1 passes; `slots` = levels (ratios of every level kept) or 1; `between` runs after the receiver pass of
 // each level (the compact path accumulates match there)
+// cull_levels > 0 (DEVICE semantics, clouds in Morton order): the passes of the first `cull_levels` levels run in their
+// chunk-culling form -- a pass culls by the SMALLER of its levels, so giver pass `lev` (sweep 3 of lev - 1, sweep 1 of lev)
+// qualifies with lev < cull_levels like receiver pass `lev`.
 template <bool HOST, typename F>
 int run_passes(int b, int n, int m, const float *xyz1, const float *xyz2, void *temp, int slots, hipStream_t s,
-               F between, size_t cstride = 0)
+               F between, size_t cstride = 0, int cull_levels = 0)
 {
     constexpr int L = Sem<HOST>::levels;
     const dim3 gl(mpsr::ceil_div(n, kThreads * kPT), b), gr(mpsr::ceil_div(m, kThreads * kPT), b);
-    const int skip = g_emd_skip.load();  // 1: leave exhausted receivers out (exact), 2: and split short receiver passes
-    hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots, cstride,
-                       skip);
-    for (int lev = 0; lev < L; ++lev) {
-        hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots,
+    int skip = g_emd_skip.load();  // 1: leave exhausted receivers out (exact), 2: and split short receiver passes
+    if (g_emd_cull.load() == 2) skip |= kNeverCull;
+    if constexpr (HOST) cull_levels = 0;
+    if constexpr (!HOST) {
+        if (cull_levels > 0)
+            hipLaunchKernelGGL((emd_giver_kernel<false, 0, true>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots,
+                               cstride, skip);
+    }
+    if (cull_levels <= 0)
+        hipLaunchKernelGGL((emd_giver_kernel<HOST, 0>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, 0, slots,
                            cstride, skip);
+    for (int lev = 0; lev < L; ++lev) {
+        bool done = false;
+        if constexpr (!HOST) {
+            if (lev < cull_levels) {
+                hipLaunchKernelGGL((emd_receiver_kernel<false, true>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev,
+                                   slots, cstride, skip);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((emd_receiver_kernel<HOST>), gr, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev, slots,
+                               cstride, skip);
         if (int rc = between(lev)) return rc;
-        if (lev + 1 < L)
-            hipLaunchKernelGGL((emd_giver_kernel<HOST, 1>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev + 1,
-                               slots, cstride, skip);
+        if (lev + 1 < L) {
+            done = false;
+            if constexpr (!HOST) {
+                if (lev + 1 < cull_levels) {
+                    hipLaunchKernelGGL((emd_giver_kernel<false, 1, true>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp,
+                                       lev + 1, slots, cstride, skip);
+                    done = true;
+                }
+            }
+            if (!done)
+                hipLaunchKernelGGL((emd_giver_kernel<HOST, 1>), gl, dim3(kThreads), 0, s, n, m, xyz1, xyz2, temp, lev + 1,
+                                   slots, cstride, skip);
+        }
         // the giver capacity after the last level is never read: no trailing sweep 3
     }
     MPSR_CHECK_LAUNCH("emd passes");
@@ -1019,6 +1336,17 @@ extern "C" size_t mpsr_emd_temp_floats(int b, int n, int m, int semantics)
 }
 
 extern "C" size_t mpsr_approx_match_temp_floats(int b, int n, int m) { return mpsr_emd_temp_floats(b, n, m, MPSR_EMD_DEVICE); }
+
+// Scratch with which mpsr_emd_loss runs its level-culling form (DEVICE semantics, clouds of up to kSortMax points): the
+// state of mpsr_emd_temp_floats plus both clouds in Morton order and their permutations.  With less (but at least
+// mpsr_emd_temp_floats) the loss is evaluated without culling -- same result up to fp32 summation order.
+static size_t emd_cull_extra_floats(int b, int n, int m) { return (size_t)b * (size_t)(n + m) * 4; }
+extern "C" size_t mpsr_emd_loss_temp_floats(int b, int n, int m, int semantics)
+{
+    const size_t full = mpsr_emd_temp_floats(b, n, m, semantics);
+    if (full == 0 || semantics != MPSR_EMD_DEVICE || n > kSortMax || m > kSortMax) return full;
+    return full + emd_cull_extra_floats(b, n, m);
+}
 
 extern "C" int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                                     float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream)
@@ -1122,12 +1450,31 @@ extern "C" int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float
             hipLaunchKernelGGL((emd_loss_kernel<true, 1>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost,
                                grad2);
     } else {
-        if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
-            return rc;
         const dim3 p1(mpsr::ceil_div(n, 512), b), p2(mpsr::ceil_div(m, 512), b);
-        hipLaunchKernelGGL(emd_loss_pk_kernel<0>, p1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1);
-        if (grad2)
-            hipLaunchKernelGGL(emd_loss_pk_kernel<1>, p2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad2);
+        if (g_emd_cull.load() && n <= kSortMax && m <= kSortMax && temp_floats >= full + emd_cull_extra_floats(b, n, m)) {
+            // level culling (r06): both clouds into Morton order behind the state, every pass and both loss kernels on
+            // the sorted clouds, the four steepest levels' passes and the loss kernels in their chunk-culling form
+            float *s1 = temp + full, *s2 = s1 + (size_t)b * n * 3;
+            int *perm1 = reinterpret_cast<int *>(s2 + (size_t)b * m * 3), *perm2 = perm1 + (size_t)b * n;
+            hipLaunchKernelGGL(emd_sort_kernel, dim3(b, 2), dim3(256), 0, s, n, m, xyz1, xyz2, s1, s2, perm1, perm2);
+            MPSR_CHECK_LAUNCH("emd_sort_kernel");
+            if (int rc = run_passes<false>(b, n, m, s1, s2, temp, Sem<false>::levels, s, [](int) { return 0; }, 0, kCullLevels))
+                return rc;
+            const int flags = g_emd_cull.load() == 2 ? kNeverCull : 0;
+            hipLaunchKernelGGL((emd_loss_pk_kernel<0, true>), p1, dim3(256), 0, s, n, m, s1, s2, (void *)temp, cost, grad1,
+                               (const int *)perm1, flags);
+            if (grad2)
+                hipLaunchKernelGGL((emd_loss_pk_kernel<1, true>), p2, dim3(256), 0, s, n, m, s1, s2, (void *)temp, cost,
+                                   grad2, (const int *)perm2, flags);
+        } else {
+            if (int rc = run_passes<false>(b, n, m, xyz1, xyz2, temp, Sem<false>::levels, s, [](int) { return 0; }))
+                return rc;
+            hipLaunchKernelGGL(emd_loss_pk_kernel<0>, p1, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad1,
+                               (const int *)nullptr, 0);
+            if (grad2)
+                hipLaunchKernelGGL(emd_loss_pk_kernel<1>, p2, dim3(256), 0, s, n, m, xyz1, xyz2, (void *)temp, cost, grad2,
+                                   (const int *)nullptr, 0);
+        }
     }
     MPSR_CHECK_LAUNCH("emd_loss_kernel");
     return MPSR_OK;
@@ -1170,3 +1517,4 @@ extern "C" int mpsr_match_cost_grad(int b, int n, int m, const float *xyz1, cons
 }
 
 extern "C" void mpsr_debug_set_emd_skip(int on) { g_emd_skip = on; }
+extern "C" void mpsr_debug_set_emd_cull(int on) { g_emd_cull = on; }

@@ -405,6 +405,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- K loop, two steps per trip.  Waves 0-3: even step = request the patch of step s + 2, odd step = transform
     // it into buffer 0.  Waves 4-7: even step = transform the patch of step s + 1 into buffer 1, odd step = request
     // the patch of step s + 3.
+#ifdef W4_PRIO  // A/B builds (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = waves 4-7, 2 = waves 0-3
+    if (dgrp == (W4_PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
+#endif
     if (dgrp == 0) {
         for (int s = 0; s < nsteps; s += 2) {
             kstep(s, IC<0>{}, request(s + 2));
@@ -428,6 +431,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // vector registers: with an "a" constraint hipcc splits the 256-register budget 128 + 128 and spills)
 #ifdef W4_TRACE
     W4_STAMP(true);  // 12: K loop done
+#endif
+#ifdef W4_PRIO
+    __builtin_amdgcn_s_setprio(0);
 #endif
     int tid2 = tid;
     asm volatile("s_nop 15\n\ts_nop 7"

@@ -20,9 +20,11 @@ def _sem(semantics):
     return SEMANTICS[semantics]
 
 
-def _temp(b, n, m, sem, device):
+def _temp(b, n, m, sem, device, loss=False):
     # float64 storage: 8-byte aligned for the host semantics' double state
-    nfl = _lib.lib().mpsr_emd_temp_floats(b, n, m, sem)
+    # (loss: the fused loss' scratch -- with the sorted clouds behind the state it culls the steep levels' far pairs)
+    lib = _lib.lib()
+    nfl = lib.mpsr_emd_loss_temp_floats(b, n, m, sem) if loss else lib.mpsr_emd_temp_floats(b, n, m, sem)
     return torch.empty(((nfl + 1) // 2,), dtype=torch.float64, device=device), nfl
 
 
@@ -137,7 +139,7 @@ def emd_loss_fwd_bwd(xyz1, xyz2, semantics="device", want_grads=True):
         m = xyz2.shape[1]
         cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
         g1, g2 = (torch.empty_like(xyz1), torch.empty_like(xyz2)) if want_grads else (None, None)
-        temp, nfl = _temp(b, n, m, sem, xyz1.device)
+        temp, nfl = _temp(b, n, m, sem, xyz1.device, loss=True)
         _lib.check(_lib.lib().mpsr_emd_loss(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(cost), _lib.ptr(g1),
                                             _lib.ptr(g2), _lib.ptr(temp), nfl, sem, _lib.stream()))
     return cost, g1, g2

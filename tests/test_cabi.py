@@ -43,6 +43,12 @@ def test_ctypes_binding_matches_header_and_loads():
     assert isinstance(lib.mpsr_last_error(), bytes)  # (the message of this thread's most recent failing call, if any)
     # size helpers are pure host functions
     assert lib.mpsr_approx_match_temp_floats(2, 5, 7) == 2 * (5 + 7) * 11
+    # ABI 6: the fused loss' scratch for its level-culling form = the state + both clouds re-ordered + their permutations;
+    # host semantics and clouds beyond the in-LDS sort's 4096 points have no such form (plain size)
+    assert lib.mpsr_emd_loss_temp_floats(2, 5, 7, 0) == 2 * (5 + 7) * 11 + 2 * (5 + 7) * 4
+    assert lib.mpsr_emd_loss_temp_floats(2, 5, 7, 1) == lib.mpsr_emd_temp_floats(2, 5, 7, 1)
+    assert lib.mpsr_emd_loss_temp_floats(1, 5000, 7, 0) == lib.mpsr_emd_temp_floats(1, 5000, 7, 0)
+    assert lib.mpsr_emd_loss_temp_floats(0, 5, 7, 0) == 0
     assert lib.mpsr_trunk_workspace_bytes(0, 48, 48) == 0
     assert lib.mpsr_trunk_workspace_bytes(2, 48, 48) > 0
 

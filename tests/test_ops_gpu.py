@@ -337,6 +337,94 @@ def test_emd_exhausted_receivers_are_skipped_exactly(b, n, m, spread):
     assert float(out[1][1].abs().min()) > 0
 
 
+def _clouds(kind, b, n, m, rng):
+    """uniform: U(-1,1)^3 (bench.py's cfg5 clouds); surface: points on a car-sized box's faces + noise (what an xyz map
+    looks like); clusters: a few tight blobs far apart; tiny: everything within 0.01 (no cut-off ever applies); wide:
+    coordinates of +-40 (every cut-off applies to almost every pair)."""
+    def one(k):
+        if kind == "uniform":
+            return rng.uniform(-1, 1, (b, k, 3))
+        if kind == "surface":
+            p = rng.uniform(-1, 1, (b, k, 3)) * np.array([2.0, 0.8, 0.9])
+            ax = rng.integers(0, 3, (b, k))
+            side = rng.choice([-1.0, 1.0], (b, k))
+            for d, half in enumerate((2.0, 0.8, 0.9)):
+                p[..., d] = np.where(ax == d, side * half, p[..., d])
+            return p + rng.normal(0, 0.01, p.shape)
+        if kind == "clusters":
+            cen = rng.uniform(-3, 3, (b, 6, 3))
+            return cen[np.arange(b)[:, None], rng.integers(0, 6, (b, k))] + rng.normal(0, 0.05, (b, k, 3))
+        if kind == "tiny":
+            return rng.uniform(-0.005, 0.005, (b, k, 3)) + 0.3
+        return rng.uniform(-40, 40, (b, k, 3))
+    return one(n).astype(np.float32), one(m).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,b,n,m", [("uniform", 3, 2048, 2048), ("uniform", 2, 2304, 2304), ("uniform", 2, 1500, 700),
+                                        ("uniform", 2, 700, 1500), ("surface", 3, 2304, 2304), ("clusters", 2, 1024, 2048),
+                                        ("tiny", 2, 512, 512), ("wide", 2, 1024, 1024), ("uniform", 2, 33, 31),
+                                        ("uniform", 1, 4096, 4096), ("surface", 2, 1, 300)])
+def test_emd_level_culling_skips_only_exact_zeros(kind, b, n, m):
+    """mpsr_emd_loss with mpsr_emd_loss_temp_floats of scratch (r06): both clouds in Morton order, chunks of the opposite
+    cloud whose exponential is exactly zero at the four steepest levels left out (reference: every pair at every level,
+    tf_approxmatch_g.cu:21-160).  (1) Culling against the SAME sorted evaluation with every chunk test failing
+    (mpsr_debug_set_emd_cull(2)): gradients BIT FOR BIT -- a skipped term is e * w with e == +0 -- and the cost to its
+    last bit (an fp32 atomic of per-workgroup sums).  (2) Against the plain evaluation in the caller's point order
+    (mpsr_debug_set_emd_cull(0)): fp32 summation order only, 2e-5 of the largest gradient / of the cost.  (3) Twice the
+    same bits.  On uniform, surface-like, clustered, tiny (no cut-off applies) and wide clouds, ragged sizes both ways,
+    one-point clouds and the sort's 4096-point capacity."""
+    from monopsr_amd import _lib
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    rng = np.random.default_rng(n * 7 + m + len(kind))
+    x1, x2 = _clouds(kind, b, n, m, rng)
+    a, c = _dev(x1), _dev(x2)
+    lib = _lib.lib()
+    out = {}
+    try:
+        for mode in (1, 2, 0):
+            lib.mpsr_debug_set_emd_cull(mode)
+            out[mode] = am.emd_loss_fwd_bwd(a, c)
+        lib.mpsr_debug_set_emd_cull(1)
+        again = am.emd_loss_fwd_bwd(a, c)
+    finally:
+        lib.mpsr_debug_set_emd_cull(1)
+    for k in (1, 2):
+        assert bool(torch.isfinite(out[1][k]).all())
+        assert torch.equal(out[1][k], out[2][k]), "culled != sorted-unculled (grad%d): a non-zero term was skipped" % k
+        assert torch.equal(out[1][k], again[k]), "not deterministic"
+        scale = float(out[0][k].abs().max())
+        assert float((out[1][k] - out[0][k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, scale)
+    torch.testing.assert_close(out[1][0], out[2][0], rtol=1e-6, atol=0)
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=2e-5, atol=0)
+
+
+def test_emd_loss_without_the_extra_scratch_or_beyond_the_sort_runs_plain():
+    """The culling form needs mpsr_emd_loss_temp_floats of scratch and clouds of at most 4096 points; with
+    mpsr_emd_temp_floats (what r05 callers allocate) or larger clouds the call runs the plain evaluation -- same result up
+    to summation order -- and less scratch than that is still refused."""
+    import ctypes
+    from monopsr_amd import _lib
+    from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
+    lib = _lib.lib()
+    rng = np.random.default_rng(9)
+    for b, n, m in ((2, 600, 500), (1, 4500, 300)):
+        a = _dev(rng.uniform(-1, 1, (b, n, 3)).astype(np.float32))
+        c = _dev(rng.uniform(-1, 1, (b, m, 3)).astype(np.float32))
+        want = am.emd_loss_fwd_bwd(a, c)
+        small = lib.mpsr_emd_temp_floats(b, n, m, 0)
+        assert (lib.mpsr_emd_loss_temp_floats(b, n, m, 0) > small) == (n <= 4096)
+        temp = torch.empty((small,), dtype=torch.float32, device="cuda")
+        cost = torch.empty((b,), device="cuda")
+        g1, g2 = torch.empty_like(a), torch.empty_like(c)
+        _lib.check(lib.mpsr_emd_loss(b, n, m, _lib.ptr(a), _lib.ptr(c), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(g2),
+                                     _lib.ptr(temp), small, 0, _lib.stream()))
+        torch.testing.assert_close(cost, want[0], rtol=2e-5, atol=0)
+        assert float((g1 - want[1]).abs().max()) <= 2e-5 * float(want[1].abs().max())
+        assert float((g2 - want[2]).abs().max()) <= 2e-5 * float(want[2].abs().max())
+        assert lib.mpsr_emd_loss(b, n, m, _lib.ptr(a), _lib.ptr(c), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(g2),
+                                 _lib.ptr(temp), small - 1, 0, _lib.stream()) != 0
+
+
 def test_emd_cfg5_per_gpu_share_full_size():
     """BASELINE config 5's per-GPU share, 256 clouds x 2048^2, through the fused loss: a 3-cloud slice against the
     oracle (device semantics), every cloud independent of its batch neighbours, gradients finite and consistent with
