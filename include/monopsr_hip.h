@@ -108,12 +108,15 @@ int mpsr_approx_match_ex(int b, int n, int m, const float *xyz1, const float *xy
  * mpsr_approx_match + mpsr_match_cost + mpsr_match_cost_grad to fp32 summation order.  grad1 / grad2 may be NULL
  * (cost only: the metric of monopsr_model.py:1143-1149).  temp: mpsr_emd_temp_floats(b,n,m,semantics) floats, or --
  * ABI 6 -- mpsr_emd_loss_temp_floats(b,n,m,semantics): with that much scratch (the state + both clouds re-ordered +
- * their permutations: b*(n+m)*4 floats more; device semantics, clouds of up to 4096 points) the call CULLS LEVELS: it
- * sorts both clouds into Morton order and leaves out, chunk of 32 points by chunk, the pairs whose exponential
+ * their permutations: b*(n+m)*4 floats more; device semantics, clouds of up to 4096 points) the call CAN cull levels:
+ * sort both clouds into Morton order and leave out, chunk of 32 points by chunk, the pairs whose exponential
  * exp(level * d^2) is exactly zero in fp32 at the four steepest levels (-16384 .. -256: d beyond 0.08 .. 0.64) -- the
- * reference's kernels evaluate every pair at every level (tf_approxmatch_g.cu:21-160).  Same terms otherwise, summed in
- * the order of the sorted clouds: equal to the plain evaluation up to fp32 summation order (held to 2e-5 by the tests).
- * Gradients come back in the caller's point order. */
+ * reference's kernels evaluate every pair at every level (tf_approxmatch_g.cu:21-160).  What is skipped is exactly zero
+ * (bit-identical to the unculled evaluation of the sorted clouds), but the sums run in the order of the SORTED clouds,
+ * and the annealing's clamps amplify that rounding difference: isolated gradient elements move by up to ~1e-3 of the
+ * largest against the evaluation in the caller's order.  The form is therefore OFF unless switched on
+ * (mpsr_debug_set_emd_cull(1): -4 .. -8 % of the call at 256 x 2048^2, slower below ~64 clouds); by default the call
+ * ignores the extra scratch.  Gradients come back in the caller's point order either way. */
 size_t mpsr_emd_loss_temp_floats(int b, int n, int m, int semantics);
 int mpsr_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
                   float *temp, size_t temp_floats, int semantics, mpsr_stream_t stream);
@@ -388,6 +391,18 @@ int mpsr_batch_norm_grad(const float *dy, const float *y, const float *z, long l
 int mpsr_clip_by_norm_segments(float *grads, const int *chunk_seg, const long long *chunk_begin,
                                const int *chunk_len, int n_chunks, float *sumsq, int n_segments, float clip_norm,
                                mpsr_stream_t stream);
+
+/* ABI 6: the tail of a training step in two launches -- per-variable tf.clip_by_norm (core/trainer.py:78-81), the Adam
+ * update (builders/optimizer_builder.py:61-80) and the parameter moving average (tf.contrib.opt.MovingAverageOptimizer,
+ * optimizer_builder.py:75-80) over the same chunk table: squared norms, then ONE pass that scales the gradient on its way
+ * into the update (grads are left as they came), updates m / v / param and, when `shadow` is not NULL,
+ * shadow += (1 - ema_decay) * (param - shadow).  Operation by operation the arithmetic of mpsr_clip_by_norm_segments ->
+ * mpsr_adam_step -> that moving average; elements outside every chunk (alignment padding) are not touched.
+ * clip_norm <= 0: no clipping (sumsq may be NULL).  step = 1-based Adam step (bias correction). */
+int mpsr_clip_adam_ema_step(float *param, const float *grad, float *m, float *v, float *shadow, const int *chunk_seg,
+                            const long long *chunk_begin, const int *chunk_len, int n_chunks, float *sumsq,
+                            int n_segments, float clip_norm, float lr, float beta1, float beta2, float eps, int step,
+                            float ema_decay, mpsr_stream_t stream);
 
 /* ------------------------------------------------------------------------- per-box geometry and map losses
  * SURVEY.md 8(f) rows 3-4.  Maps are (b, h, w, c) row-major; p = h*w points per instance. */

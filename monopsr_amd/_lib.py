@@ -130,6 +130,9 @@ SIGNATURES = {
     "mpsr_batch_norm_grad_sums": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_batch_norm_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_clip_by_norm_segments": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_i, ctypes.c_float, c_f]),
+    "mpsr_clip_adam_ema_step": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, ctypes.c_float,
+                                      c_f]),
     "mpsr_xyz_map_local_to_global": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "mpsr_xyz_map_local_to_global_grad": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "mpsr_proj_err_norm": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),

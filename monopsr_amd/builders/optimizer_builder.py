@@ -51,6 +51,19 @@ class AdamWithMovingAverage:
                 self.shadow.lerp_(net.params, 1.0 - self.moving_average_decay)
         return lr
 
+    def apply_clipped_gradients(self, net, global_step, clip_table, clip_norm):
+        """apply_gradients with slim's per-variable clip_by_norm (core/trainer.py:78-81) in front, fused: squared norms,
+        then ONE pass over the flat buffers for clip -> Adam -> moving average (TrainNet.clip_adam_ema_step).  The step
+        that creates the moving average takes it from the post-step parameters, as apply_gradients does."""
+        lr = self.learning_rate(global_step)
+        if self.use_moving_average and self.shadow is not None:
+            net.clip_adam_ema_step(clip_table, clip_norm, lr=lr, shadow=self.shadow, ema_decay=self.moving_average_decay)
+        else:
+            net.clip_adam_ema_step(clip_table, clip_norm, lr=lr)
+            if self.use_moving_average:
+                self.shadow = net.params.clone()
+        return lr
+
     def averaged_params(self, net):
         """The moving averages -- what a checkpoint holds under `<name>/ExponentialMovingAverage` -- or the raw
         parameters when averaging is off."""

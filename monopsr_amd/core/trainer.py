@@ -171,6 +171,7 @@ class InstanceTrainer:
             self.optimizer = optimizer_builder.build(train_config.optimizer)
         self.global_step = 0
         self._clip = None
+        self.fused_update = True  # clip + Adam + moving average as one pass (False: the three separate passes, A/B / tests)
         spans = []
         base = net.grads.data_ptr()
         for L in net.layers:  # everything a layer's backward deposits: weight gradient and bias / beta gradient
@@ -239,9 +240,16 @@ class InstanceTrainer:
             if bank is not None:
                 bank.invalidate()
         self.reducer.finish(average=True)
-        if self.clip_norm:
-            self.clip_per_variable()
-        self.optimizer.apply_gradients(self.net, self.global_step)
+        if self.fused_update:
+            # clip (after the reduce: the reference's order, core/trainer.py:76-81) -> Adam -> moving average in two
+            # launches; net.grads keeps the reduced, UNclipped gradient (clip_per_variable() clips it in place)
+            if self._clip is None:
+                self._clip = self._clip_table()
+            self.optimizer.apply_clipped_gradients(self.net, self.global_step, self._clip, self.clip_norm)
+        else:
+            if self.clip_norm:
+                self.clip_per_variable()
+            self.optimizer.apply_gradients(self.net, self.global_step)
         self.global_step += 1
         return loss.detach()
 

@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void match_cost_grad2_kernel(int n, int m, con
 // (bit-identical results); 2 (default): and the receiver pass splits its giver loop over the waves when few receivers
 // are live (same terms, another summation order).  Tests compare the three.
 std::atomic<int> g_emd_skip{2};
-std::atomic<int> g_emd_cull{1};  // mpsr_debug_set_emd_cull: level culling in mpsr_emd_loss (0 = never; 2 = sorted clouds, every chunk test fails: tests)
+std::atomic<int> g_emd_cull{0};  // mpsr_debug_set_emd_cull: level culling in mpsr_emd_loss -- 0 (default) never, 1 when the scratch allows, 2 sorted clouds with every chunk test failing (tests).  OFF by default: the sorted summation order moves isolated gradient elements by up to ~1e-3 of the largest (the annealing's clamps amplify rounding), for -4 % (uniform) .. -8 % (surface-like clouds) of the fused loss at 256 x 2048^2 and +8 % at 32 x 2304^2 (tools/emd_time.py)
 constexpr int kCullLevels = 4;   // levels -16384 .. -256: cut-offs 0.08 .. 0.64 (beyond, nothing of a unit-scale cloud culls)
 
 int check_emd_args(const char *op, int b, int n, int m)
@@ -1518,3 +1518,4 @@ extern "C" int mpsr_match_cost_grad(int b, int n, int m, const float *xyz1, cons
 
 extern "C" void mpsr_debug_set_emd_skip(int on) { g_emd_skip = on; }
 extern "C" void mpsr_debug_set_emd_cull(int on) { g_emd_cull = on; }
+extern "C" int mpsr_debug_get_emd_cull(void) { return g_emd_cull.load(); }

@@ -4,6 +4,8 @@
 // (one workgroup per <= 16 Ki-float chunk of one variable): squared sums -> per-variable scale.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cmath>
+
 #include "common.h"
 
 namespace {
@@ -44,7 +46,73 @@ __global__ __launch_bounds__(kThreads) void seg_scale_kernel(float *__restrict__
     for (int i = threadIdx.x; i < n; i += kThreads) p[i] *= scale;
 }
 
+// clip -> Adam -> moving average of ONE chunk of one variable, in one pass over the flat buffers (r06): the per-variable
+// scale is applied to the gradient on its way into the update instead of being written back (seg_scale_kernel), and the
+// moving average is updated from the parameter just computed instead of re-reading it (a torch lerp_): 9 streams of the
+// flat buffer where the three launches moved 13.  Same arithmetic, operation by operation, as seg_scale_kernel ->
+// adam_kernel (backward.hip) -> shadow += (1 - decay) * (p - shadow).
+__global__ __launch_bounds__(kThreads) void clip_adam_ema_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                                 float *__restrict__ m, float *__restrict__ v,
+                                                                 float *__restrict__ shadow,
+                                                                 const int *__restrict__ chunk_seg,
+                                                                 const long long *__restrict__ chunk_begin,
+                                                                 const int *__restrict__ chunk_len,
+                                                                 const float *__restrict__ sumsq, float clip, float lr_t,
+                                                                 float b1, float b2, float eps, float ema_w)
+{
+    const int c = blockIdx.x;
+    float scale = 1.f;
+    bool scaled = false;
+    if (sumsq) {
+        const float norm = sqrtf(sumsq[chunk_seg[c]]);
+        scaled = norm > clip;  // (a NaN norm leaves the gradient as it is, like seg_scale_kernel)
+        if (scaled) scale = clip / norm;
+    }
+    const long long o = chunk_begin[c];
+    const int n = chunk_len[c];
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const float gr = g[o + i];
+        const float gi = scaled ? gr * scale : gr;
+        const float mi = b1 * m[o + i] + (1.f - b1) * gi;
+        const float vi = b2 * v[o + i] + (1.f - b2) * gi * gi;
+        m[o + i] = mi;
+        v[o + i] = vi;
+        const float pi = p[o + i] - lr_t * mi / (sqrtf(vi) + eps);
+        p[o + i] = pi;
+        if (shadow) {
+            const float sh = shadow[o + i];
+            shadow[o + i] = sh + ema_w * (pi - sh);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mpsr_clip_adam_ema_step(float *param, const float *grad, float *m, float *v, float *shadow,
+                                       const int *chunk_seg, const long long *chunk_begin, const int *chunk_len,
+                                       int n_chunks, float *sumsq, int n_segments, float clip_norm, float lr, float beta1,
+                                       float beta2, float eps, int step, float ema_decay, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(n_chunks >= 0 && n_segments >= 0 && step >= 1, "clip_adam_ema_step: bad arguments");
+    if (n_chunks == 0) return MPSR_OK;
+    MPSR_REQUIRE(param && grad && m && v && chunk_seg && chunk_begin && chunk_len, "clip_adam_ema_step: null pointer");
+    MPSR_REQUIRE(!(clip_norm > 0.f) || (sumsq && n_segments > 0), "clip_adam_ema_step: clipping needs the sumsq scratch");
+    hipStream_t s = mpsr::as_stream(stream);
+    const bool clip = clip_norm > 0.f;
+    if (clip) {
+        MPSR_CHECK_HIP(hipMemsetAsync(sumsq, 0, sizeof(float) * (size_t)n_segments, s));
+        hipLaunchKernelGGL(seg_sumsq_kernel, dim3(n_chunks), dim3(kThreads), 0, s, grad, chunk_seg, chunk_begin, chunk_len,
+                           sumsq);
+        MPSR_CHECK_LAUNCH("seg_sumsq_kernel");
+    }
+    const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
+    const float lr_t = (float)(lr * sqrt(c2) / c1);  // (as mpsr_adam_step)
+    hipLaunchKernelGGL(clip_adam_ema_kernel, dim3(n_chunks), dim3(kThreads), 0, s, param, grad, m, v, shadow, chunk_seg,
+                       chunk_begin, chunk_len, clip ? (const float *)sumsq : (const float *)nullptr, clip_norm, lr_t, beta1,
+                       beta2, eps, 1.f - ema_decay);
+    MPSR_CHECK_LAUNCH("clip_adam_ema_kernel");
+    return MPSR_OK;
+}
 
 extern "C" int mpsr_clip_by_norm_segments(float *grads, const int *chunk_seg, const long long *chunk_begin,
                                           const int *chunk_len, int n_chunks, float *sumsq, int n_segments,

@@ -655,6 +655,66 @@ def test_clip_by_norm_segments_matches_per_tensor_clip():
     assert torch.equal(net.grads[lo:lo + net.layers[3].dw.numel()], before[lo:lo + net.layers[3].dw.numel()])
 
 
+def test_fused_clip_adam_ema_equals_the_three_passes():
+    """mpsr_clip_adam_ema_step (r06: squared norms, then ONE pass for clip -> Adam -> moving average; the gradient is not
+    written back) against mpsr_clip_by_norm_segments -> mpsr_adam_step -> shadow.lerp_ on the same gradients, over four
+    steps with a decaying learning rate: parameters, both Adam moments and the moving average agree to 1e-6 of their
+    scale (the same arithmetic up to fused multiply-add contraction), variables under the clip threshold included, and
+    the gradient buffer of the fused path is left as it came."""
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    cfg = config_utils.default_config()
+    opt = cfg.train_config.optimizer.adam_optimizer
+    opt.learning_rate_type, opt.initial_learning_rate = 'exponential_decay', 1e-3
+    opt.decay_steps, opt.decay_factor, opt.staircase = 2, 0.5, True
+    opt.use_moving_average, opt.moving_average_decay = True, 0.9
+    weights = W.synthetic_weights(seed=92, width_div=4)
+    trs = []
+    for fused in (False, True):
+        net = train_net.TrainNet(weights, width_div=4)
+        tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config, clip_norm=1.0)
+        tr.fused_update = fused
+        trs.append(tr)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    # the variables' elements (the flat buffer also holds alignment padding, whose gradient is always zero in a real
+    # step: the whole-buffer Adam pass leaves it alone for that reason, the chunk pass because no chunk covers it)
+    seg, begin, length, _ = trs[1]._clip_table()
+    covered = torch.zeros(trs[0].net.grads.shape, dtype=torch.bool, device="cuda")
+    for lo, n in zip(begin.tolist(), length.tolist()):
+        covered[lo:lo + n] = True
+    assert 0.9 < float(covered.float().mean()) < 1.0
+    for step in range(4):
+        grads = torch.randn(trs[0].net.grads.shape, device="cuda", generator=g) * 0.02 * covered
+        for tr in trs:
+            tr.net.grads.copy_(grads)
+            tr.net.layers[3].dw.mul_(1e-3)  # a variable below the threshold: not scaled
+            before = tr.net.grads.clone()
+            if tr.fused_update:
+                if tr._clip is None:
+                    tr._clip = tr._clip_table()
+                tr.optimizer.apply_clipped_gradients(tr.net, tr.global_step, tr._clip, tr.clip_norm)
+                assert torch.equal(tr.net.grads, before)
+            else:
+                tr.clip_per_variable()
+                tr.optimizer.apply_gradients(tr.net, tr.global_step)
+                assert not torch.equal(tr.net.grads, before)
+            tr.global_step += 1
+        a, b = trs
+        assert a.net.step_count == b.net.step_count == step + 1
+        for name, x, y in (("params", a.net.params, b.net.params), ("adam_m", a.net.adam_m, b.net.adam_m),
+                           ("adam_v", a.net.adam_v, b.net.adam_v), ("average", a.optimizer.shadow, b.optimizer.shadow)):
+            assert float((x - y).abs().max()) <= 1e-6 * float(x.abs().max()), (step, name)
+    assert float((trs[0].net.params - trs[0].optimizer.shadow).abs().max()) > 0  # (the average really lags)
+    # no clipping, no average: plain Adam over the chunks == mpsr_adam_step over the whole buffer
+    nets = [train_net.TrainNet(weights, width_div=4) for _ in range(2)]
+    tab = trs[1]._clip
+    for net in nets:
+        net.grads.copy_(grads)
+    nets[0].adam_step(lr=1e-3)
+    nets[1].clip_adam_ema_step(tab, 0.0, lr=1e-3)
+    assert float((nets[0].params - nets[1].params).abs().max()) <= 1e-6 * float(nets[0].params.abs().max())
+
+
 def test_wgrad_winograd_domain_vs_direct_and_fp64():
     """The Winograd F(4x4,3x3)-domain weight gradient of the decoder's dense 3x3 layers (csrc/winograd4_wgrad.hip:
     dU = sum over tiles of (A dY A^T) (.) (B^T d B), dg = G^T dU G) against the direct kernel on a layer-sized problem

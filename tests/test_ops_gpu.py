@@ -365,14 +365,17 @@ def _clouds(kind, b, n, m, rng):
                                         ("tiny", 2, 512, 512), ("wide", 2, 1024, 1024), ("uniform", 2, 33, 31),
                                         ("uniform", 1, 4096, 4096), ("surface", 2, 1, 300)])
 def test_emd_level_culling_skips_only_exact_zeros(kind, b, n, m):
-    """mpsr_emd_loss with mpsr_emd_loss_temp_floats of scratch (r06): both clouds in Morton order, chunks of the opposite
-    cloud whose exponential is exactly zero at the four steepest levels left out (reference: every pair at every level,
-    tf_approxmatch_g.cu:21-160).  (1) Culling against the SAME sorted evaluation with every chunk test failing
-    (mpsr_debug_set_emd_cull(2)): gradients BIT FOR BIT -- a skipped term is e * w with e == +0 -- and the cost to its
-    last bit (an fp32 atomic of per-workgroup sums).  (2) Against the plain evaluation in the caller's point order
-    (mpsr_debug_set_emd_cull(0)): fp32 summation order only, 2e-5 of the largest gradient / of the cost.  (3) Twice the
-    same bits.  On uniform, surface-like, clustered, tiny (no cut-off applies) and wide clouds, ragged sizes both ways,
-    one-point clouds and the sort's 4096-point capacity."""
+    """The OPT-IN level-culling form of mpsr_emd_loss (r06; mpsr_debug_set_emd_cull(1) + mpsr_emd_loss_temp_floats of
+    scratch): both clouds in Morton order, chunks of the opposite cloud whose exponential is exactly zero at the four
+    steepest levels left out (reference: every pair at every level, tf_approxmatch_g.cu:21-160).  (1) Culling against the
+    SAME sorted evaluation with every chunk test failing (mpsr_debug_set_emd_cull(2)): gradients BIT FOR BIT -- a skipped
+    term is e * w with e == +0 -- and the cost to its last bit (an fp32 atomic of per-workgroup sums).  (2) Twice the
+    same bits.  (3) Against the plain evaluation in the caller's point order (the default): the SORTED summation order
+    moves isolated gradient elements by up to ~1e-3 of the largest (measured 4.5e-5 .. 1.2e-3 on these clouds: the
+    annealing's clamps -- min(rem / offered, 1), max(0, rem - offered) -- amplify rounding differences of the sums), the
+    cost by < 2e-5: that is WHY the form is off by default (the path's parity budget against the reference is 1e-3 and
+    the plain evaluation spends ~1e-6 of it); bounds here 3e-3 / 1e-4.  On uniform, surface-like, clustered, tiny (no
+    cut-off applies) and wide clouds, ragged sizes both ways, one-point clouds and the sort's 4096-point capacity."""
     from monopsr_amd import _lib
     from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
     rng = np.random.default_rng(n * 7 + m + len(kind))
@@ -387,15 +390,15 @@ def test_emd_level_culling_skips_only_exact_zeros(kind, b, n, m):
         lib.mpsr_debug_set_emd_cull(1)
         again = am.emd_loss_fwd_bwd(a, c)
     finally:
-        lib.mpsr_debug_set_emd_cull(1)
+        lib.mpsr_debug_set_emd_cull(0)
     for k in (1, 2):
         assert bool(torch.isfinite(out[1][k]).all())
         assert torch.equal(out[1][k], out[2][k]), "culled != sorted-unculled (grad%d): a non-zero term was skipped" % k
         assert torch.equal(out[1][k], again[k]), "not deterministic"
         scale = float(out[0][k].abs().max())
-        assert float((out[1][k] - out[0][k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, scale)
+        assert float((out[1][k] - out[0][k]).abs().max()) <= 3e-3 * scale + 1e-12, (k, scale)
     torch.testing.assert_close(out[1][0], out[2][0], rtol=1e-6, atol=0)
-    torch.testing.assert_close(out[1][0], out[0][0], rtol=2e-5, atol=0)
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=1e-4, atol=0)
 
 
 def test_emd_loss_without_the_extra_scratch_or_beyond_the_sort_runs_plain():
@@ -407,20 +410,24 @@ def test_emd_loss_without_the_extra_scratch_or_beyond_the_sort_runs_plain():
     from monopsr_amd.tf_ops.approxmatch import tf_approxmatch as am
     lib = _lib.lib()
     rng = np.random.default_rng(9)
+    assert lib.mpsr_debug_get_emd_cull() == 0  # the default: plain evaluation whatever the scratch
     for b, n, m in ((2, 600, 500), (1, 4500, 300)):
         a = _dev(rng.uniform(-1, 1, (b, n, 3)).astype(np.float32))
         c = _dev(rng.uniform(-1, 1, (b, m, 3)).astype(np.float32))
-        want = am.emd_loss_fwd_bwd(a, c)
+        want = am.emd_loss_fwd_bwd(a, c)  # (default: plain)
         small = lib.mpsr_emd_temp_floats(b, n, m, 0)
         assert (lib.mpsr_emd_loss_temp_floats(b, n, m, 0) > small) == (n <= 4096)
         temp = torch.empty((small,), dtype=torch.float32, device="cuda")
         cost = torch.empty((b,), device="cuda")
         g1, g2 = torch.empty_like(a), torch.empty_like(c)
-        _lib.check(lib.mpsr_emd_loss(b, n, m, _lib.ptr(a), _lib.ptr(c), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(g2),
-                                     _lib.ptr(temp), small, 0, _lib.stream()))
-        torch.testing.assert_close(cost, want[0], rtol=2e-5, atol=0)
-        assert float((g1 - want[1]).abs().max()) <= 2e-5 * float(want[1].abs().max())
-        assert float((g2 - want[2]).abs().max()) <= 2e-5 * float(want[2].abs().max())
+        lib.mpsr_debug_set_emd_cull(1)  # culling asked for, but the scratch / the cloud size rules it out: plain bits
+        try:
+            _lib.check(lib.mpsr_emd_loss(b, n, m, _lib.ptr(a), _lib.ptr(c), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(g2),
+                                         _lib.ptr(temp), small, 0, _lib.stream()))
+        finally:
+            lib.mpsr_debug_set_emd_cull(0)
+        torch.testing.assert_close(cost, want[0], rtol=1e-6, atol=0)
+        assert torch.equal(g1, want[1]) and torch.equal(g2, want[2])
         assert lib.mpsr_emd_loss(b, n, m, _lib.ptr(a), _lib.ptr(c), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(g2),
                                  _lib.ptr(temp), small - 1, 0, _lib.stream()) != 0
 

@@ -60,4 +60,4 @@ for name, b, n in (("uniform", 256, 2048), ("surface", 256, 2048), ("uniform", 3
             print("%s %d x %d^2 cull=%d (round %d): fused loss %.3f ms  cost only %.3f" % (
                 name, b, n, cull, rnd, timeit(lambda: am.emd_loss_fwd_bwd(y1, y2), 5),
                 timeit(lambda: am.emd_loss_fwd_bwd(y1, y2, want_grads=False), 5)))
-lib.mpsr_debug_set_emd_cull(1)
+lib.mpsr_debug_set_emd_cull(0)  # (the default)
