@@ -143,6 +143,9 @@ using IC = std::integral_constant<int, V>;
 #ifndef W4_SPREAD
 #define W4_SPREAD 0
 #endif
+#ifndef W4_PRIO
+#define W4_PRIO 1  // static issue priority inside the K loop: 0 none, 1 waves 4-7 (shipped), 2 waves 0-3
+#endif
 #ifndef W4_BPRE
 #define W4_BPRE 1  // B fragments requested this many units (of 12 MFMAs) ahead: 1 (two register sets) or 2 (three)
 #endif
@@ -405,7 +408,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- K loop, two steps per trip.  Waves 0-3: even step = request the patch of step s + 2, odd step = transform
     // it into buffer 0.  Waves 4-7: even step = transform the patch of step s + 1 into buffer 1, odd step = request
     // the patch of step s + 3.
-#ifdef W4_PRIO  // A/B builds (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = waves 4-7, 2 = waves 0-3
+    // Static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "two waves per SIMD", item 4:
+    // the younger wave of a SIMD loses the issue arbitration at every segment start; one s_setprio for the whole K loop,
+    // no per-segment flips).  r06, same-session step A/B over three rounds each (tools/step_libs.sh): 13.339 ms without,
+    // 13.323 with waves 0-3 raised, 13.313 with waves 4-7 raised (-2.5 % of this kernel's two launches); 0 = off.
+#if W4_PRIO
     if (dgrp == (W4_PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
 #endif
     if (dgrp == 0) {
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef W4_TRACE
     W4_STAMP(true);  // 12: K loop done
 #endif
-#ifdef W4_PRIO
+#if W4_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
     int tid2 = tid;

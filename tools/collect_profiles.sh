@@ -26,3 +26,19 @@ cp $OUT/ops/*kernel_stats.csv $OUT/${TAG}_ops_kernel_stats.csv 2>/dev/null
 timeout 300 python3 tools/gemm_reference.py > $OUT/${TAG}_vendor_gemm_reference.txt 2> $OUT/gemm.err || echo "gemm reference failed"
 timeout 300 python3 tools/conv_layer_bench.py --tiles=-1 --split 0 --rounds 3 > $OUT/${TAG}_layers.txt 2> $OUT/layers.err || echo "layer table failed"
 cat $OUT/${TAG}_pmc_traffic.json
+# r06: the TRAINING step under the same counters (no backward kernel had an MFMA-busy figure before): three passes over
+# tools/train_bench.py, reduced with the backward kernels' names included -> <tag>_train_pmc.json
+j=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
+  j=$((j+1))
+  timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/t$j -o pmc -- python3 tools/train_bench.py --steps 2 --warmup 1 > $OUT/t$j.log 2>&1 || echo "train pmc pass $j failed/timeout"
+done
+PMC_EXTRA_PREFIXES="wino3_wgrad,wino4_wgrad,thin_,bn_,upconv_gather,act_bias_grad,adam_,clip_adam,seg_,dgrad_pack,relu_bitmask,max_pool" \
+PMC_COMMAND="rocprofv3 --pmc <set> --kernel-trace -- python3 tools/train_bench.py --steps 2 --warmup 1 (one counter set per pass)" \
+  python3 tools/pmc_reduce.py $TAG $COMMIT $OUT/t*/pmc_counter_collection.csv > $OUT/${TAG}_train_pmc.json
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trainstats -o train -- python3 tools/train_bench.py --steps 4 > $OUT/${TAG}_train_under_rocprof.json 2> $OUT/trainstats.err || echo "train stats failed"
+cp $OUT/trainstats/*kernel_stats.csv $OUT/${TAG}_train_kernel_stats.csv 2>/dev/null
+timeout 300 python3 tools/full_path_bench.py --images 8 > $OUT/${TAG}_full_path_bench.json 2> $OUT/fullpath.err || echo "full path failed"
+timeout 200 python3 tools/rccl_selftest.py > $OUT/${TAG}_rccl_one_rank.json 2> $OUT/rccl.err || echo "rccl selftest failed"
+timeout 200 python3 tools/emd_time.py > $OUT/${TAG}_emd_level_culling.txt 2> $OUT/emd.err || echo "emd timing failed"
+timeout 300 python3 -m pytest tests/test_hostile_inputs_gpu.py -s -q > $OUT/${TAG}_hostile_inputs.txt 2>&1 || echo "hostile inputs run failed"

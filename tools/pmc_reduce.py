@@ -9,6 +9,7 @@ MFMA busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)
 """
 import csv
 import json
+import os
 import re
 import sys
 import time
@@ -33,7 +34,9 @@ def main(tag, commit, paths):
     kernels = {}
     tot = defaultdict(float)
     for k, cs in agg.items():
-        if not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3w_conv") or k.startswith("wino3z_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
+        if os.environ.get("PMC_EXTRA_PREFIXES") and k.startswith(tuple(os.environ["PMC_EXTRA_PREFIXES"].split(","))):
+            pass  # (r06: the training step's own kernels -- weight gradients, BatchNorm, gathers -- for r06_train_pmc.json)
+        elif not (k.startswith("conv_") or k.startswith("wino_conv") or k.startswith("wino4_conv") or k.startswith("wino4s_conv") or k.startswith("wino3_conv") or k.startswith("wino3w_conv") or k.startswith("wino3z_conv") or k.startswith("wino3h_conv") or k.startswith("pw_conv") or k.startswith("fc_rows") or k.startswith("conv3x3_narrow_mfma")):  # the matrix-pipe kernels of a step (bench.py's conv_replay launches the same set)
             continue
         g = lambda c: (cs[c][1] / cs[c][0]) if c in cs and cs[c][0] else None
         n = max(v[0] for v in cs.values())
@@ -57,8 +60,9 @@ def main(tag, commit, paths):
             rec["l2_hit_rate"] = round(g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
         kernels[k] = rec
     out = {"round": tag, "commit": commit, "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
-           "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 "
-                      "--no-roofline --no-fast-mode (one counter set per pass)",
+           "command": os.environ.get("PMC_COMMAND", "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 "
+                                                     "--warmup 1 --cpu-sample 0 --no-roofline --no-fast-mode (one counter "
+                                                     "set per pass)"),
            "formula": "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction); mfma_busy = "
                       "(SQ_VALU_MFMA_BUSY_CYCLES/1024)/(GRBM_GUI_ACTIVE/8)",
            "kernels": kernels}

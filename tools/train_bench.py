@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--unfused-update", action="store_true",
+                    help="A/B: clip, Adam and the moving average as three separate passes (InstanceTrainer.fused_update)")
     ap.add_argument("--unfused-relu-grads", action="store_true",
                     help="A/B: the ReLU gradients inside a bottleneck unit as elementwise passes")
     ap.add_argument("--unlinked-units", action="store_true",
@@ -68,6 +70,7 @@ def main():
         autograd_ops.FUSED_RELU_GRADS = False
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
                                 clip_norm=0.0 if args.no_clip else 1.0)
+    tr.fused_update = not args.unfused_update
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
     B = args.batch
     sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
