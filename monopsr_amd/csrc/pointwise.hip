@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nst = p.K / KS;  // even, >= 4
+#ifdef PWS_PRIO  // A/B builds (r06): issue priority between the two co-resident workgroups' waves of a SIMD, by the
+    // hardware wave slot (HW_ID.wave_id, bits 3:0): 1 = the odd slot runs at priority 1 for the whole launch; 2 = the
+    // two alternate tile by tile.  Measured over three interleaved rounds of the step (tools/step_libs.sh): 13.266 ms
+    // without, 13.285 with 1, 13.297 with 2 -- two independent persistent workgroups are not the compute / load pair of
+    // one workgroup that a static priority helps (it did help winograd4.hip: W4_PRIO); not compiled in.
+    const int slot_bit = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;
+    if (PWS_PRIO == 1 && slot_bit) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // this workgroup's tiles: i -> row group; the column block is fixed
     const int G = gridDim.x;
@@ -381,6 +389,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int SET = decltype(set_c)::value;
         const int r0c = r0_of(i), r0n = r0_of(i + 1);
         const bool nlive = i + 1 < n_my;
+#ifdef PWS_PRIO
+        if (PWS_PRIO == 2) {
+            if ((SET ^ slot_bit) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         PWS_STAMP(i == 2);  // 0: tile start
         const RowRef xc = row_ref(p.x, p.K, r0c, true), xn = row_ref(p.x, p.K, r0n, nlive);
         const RowRef rn = row_ref(p.residual, p.N, r0n, nlive);
