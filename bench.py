@@ -431,7 +431,7 @@ MATRIX_KERNELS = ("pw_conv_kernel", "wino3z_conv_kernel", "wino3h_conv_kernel", 
                   "conv_igemm_kernel", "conv_sk_kernel", "fc_rows_kernel", "conv3x3_narrow_mfma_kernel")
 
 
-def in_situ_object(one_step, executed_flops_per_step, ms_per_step, steps=4):
+def in_situ_object(one_step, executed_flops_per_step, ms_per_step, steps=4, expect_matrix_launches=None):
     """Per-kernel durations of the TIMED step itself (not of a replay): `steps` more steps of the same loop under
     torch.profiler (roctracer activity records of every kernel this process launches, the library's included), summed
     by kernel family.  matrix_ms_per_step + vector_ms_per_step <= ms_per_step must hold: durations exclude the gaps
@@ -474,6 +474,12 @@ def in_situ_object(one_step, executed_flops_per_step, ms_per_step, steps=4):
         raise RuntimeError("the profiler returned no device activity")
     mat = sum(v[0] for k, v in fam.items() if k[0] == "matrix") / steps / 1e3
     vec = sum(v[0] for k, v in fam.items() if k[0] == "vector") / steps / 1e3
+    nmat = sum(v[1] for k, v in fam.items() if k[0] == "matrix") / steps
+    # (under another tracer -- rocprofv3 around this process -- the records are incomplete: say so instead of dividing)
+    if (expect_matrix_launches is not None and abs(nmat - expect_matrix_launches) > 0.5) or \
+            not (0.2 * ms_per_step < mat + vec < 2.0 * ms_per_step):
+        raise RuntimeError("incomplete kernel records (%.1f matrix launches per step, %.3f ms of records for a %.3f ms "
+                           "step): another tracer owns the device activity" % (nmat, mat + vec, ms_per_step))
     top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]
     return {"how": "torch.profiler (roctracer kernel records) over %d further steps of the timed loop.  A record spans "
                    "dispatch to completion and consecutive records overlap by the next launch's ramp-up, so their sum "
@@ -1404,7 +1410,7 @@ def main():
         try:
             rf = result["roofline"]
             rf["in_situ"] = in_situ_object(one_step, rf["flops_per_launch"] * rf["launches_per_step"],
-                                           result["ms_per_step"])
+                                           result["ms_per_step"], expect_matrix_launches=rf["launches_per_step"])
         except Exception as e:
             result["roofline"]["in_situ"] = {"error": repr(e)[:300]}
     if rank == 0 and not args.no_roofline:

@@ -51,10 +51,22 @@ struct WgradParams {
 };
 constexpr int MAX_TAPS = 9;
 
+#ifndef WG_WAVES
+#define WG_WAVES 0  // A/B builds: waves per SIMD the register allocation is held to (0 = hipcc's choice: 136 registers, 3)
+#endif
+#if WG_WAVES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_WAVES, WG_WAVES))) void conv_wgrad_kernel(const WgradParams p)
+#else
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
+#endif
 {
-    __shared__ __attribute__((aligned(16))) float At[WG_K * WG_T];  // [pixel][n]
-    __shared__ __attribute__((aligned(16))) float Bt[WG_K * WG_T];  // [pixel][c]
+#ifndef WG_DB
+#define WG_DB 0  // 1: two LDS tile pairs, one barrier per step.  A/B build (r06), measured SLOWER: 64 KB of LDS leave two
+                 // workgroups per CU instead of three -- b3 conv1 232 vs 181 us, the training step 51.2 vs 47.8 ms:
+                 // residency, not the second barrier, is what this kernel lives on
+#endif
+    __shared__ __attribute__((aligned(16))) float At[(WG_DB ? 2 : 1) * WG_K * WG_T];  // [pixel][n]
+    __shared__ __attribute__((aligned(16))) float Bt[(WG_DB ? 2 : 1) * WG_K * WG_T];  // [pixel][c]
     int t = blockIdx.x;
     int tap, si, nsplit;
     if (p.grouped) {
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb, 0, 0));
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf = 0) {
 #ifdef WG_NO_LDS_STORE  // (timing experiment only)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ra[j].x), "v"(ra[j].y), "v"(ra[j].z), "v"(ra[j].w), "v"(rb[j].x), "v"(rb[j].y), "v"(rb[j].z), "v"(rb[j].w));
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 #endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<float4 *>(&At[(lrow + 8 * j) * WG_T + lcol]) = ra[j];
-            *reinterpret_cast<float4 *>(&Bt[(lrow + 8 * j) * WG_T + lcol]) = rb[j];
+            *reinterpret_cast<float4 *>(&At[buf * WG_K * WG_T + (lrow + 8 * j) * WG_T + lcol]) = ra[j];
+            *reinterpret_cast<float4 *>(&Bt[buf * WG_K * WG_T + (lrow + 8 * j) * WG_T + lcol]) = rb[j];
         }
     };
     const float *Aw = At + (lane >> 5) * 4 * WG_T + wm * 64 + (lane & 31);
@@ -184,16 +196,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     // every pixel exactly once): thread t < 128 owns column n0 + t
     const bool do_db = p.db != nullptr && tap == (p.KH * p.KW) / 2 && tc == 0 && tid < WG_T;
     float colsum = 0.f;
-    auto compute_tile = [&]() {
+    auto compute_tile = [&](int buf = 0) {
         if (do_db) {
 #pragma unroll
-            for (int k = 0; k < WG_K; ++k) colsum += At[k * WG_T + tid];
+            for (int k = 0; k < WG_K; ++k) colsum += At[buf * WG_K * WG_T + k * WG_T + tid];
         }
 #pragma unroll
         for (int kb = 0; kb < WG_K / 8; ++kb)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int row = (kb * 8 + s) * WG_T;
+                const int row = buf * WG_K * WG_T + (kb * 8 + s) * WG_T;
                 const float a0 = Aw[row], a1 = Aw[row + 32], b0 = Bw[row], b1 = Bw[row + 32];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -209,6 +221,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     load_tile(ms_begin);
     store_tile();
     __syncthreads();
+#if WG_DB
+    int cur = 0;
+    for (int ms = ms_begin; ms < ms_end - 1; ++ms) {
+        load_tile(ms + 1);
+        decode_rows(ms + 2);  // (entry ms & 1: last read by load_tile(ms), before the previous trip's barrier)
+        compute_tile(cur);
+        store_tile(cur ^ 1);  // the other pair: nobody reads it before the barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute_tile(cur);
+#else
     for (int ms = ms_begin; ms < ms_end - 1; ++ms) {
         load_tile(ms + 1);
         decode_rows(ms + 2);  // into the table entry load_tile(ms) read before the barriers of the previous trip
@@ -218,6 +242,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         __syncthreads();
     }
     compute_tile();
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -28,7 +28,16 @@ def test_roofline_frac_agrees_with_the_pmc_busy_fraction():
     roof = r["roofline"]
     assert roof["bound"] == "mfma" and 0.0 < roof["frac"] <= 1.0
     # (both are fractions of TIME at the nominal clock: GRBM_GUI_ACTIVE advances at a fixed ~2.45 GHz -- tools/pmc_reduce.py)
-    assert abs(roof["frac"] - pmc["mfma_busy"]) <= 0.02, (roof["frac"], pmc["mfma_busy"])
+    ins = roof.get("in_situ")
+    if isinstance(ins, dict) and "frac_in_situ" in ins:
+        # r06: the line carries the step's own kernel records (torch.profiler).  Traced records and the counter collection
+        # are the same kind of measurement (every launch under a tracer) and must agree; the event-timed replay runs the
+        # same launches warm and back to back and sits between the traced figure and the one scaled to the untraced step
+        assert abs(ins["frac_in_situ"] - pmc["mfma_busy"]) <= 0.02, (ins["frac_in_situ"], pmc["mfma_busy"])
+        assert ins["frac_in_situ"] - 0.01 <= roof["frac"] <= ins["frac_in_situ_scaled_to_untraced"] + 0.01, (roof["frac"], ins)
+        assert 0.9 < ins["matrix_share_of_kernel_time"] < 1.0 and ins["matrix_launches_per_step"] == roof["launches_per_step"]
+    else:
+        assert abs(roof["frac"] - pmc["mfma_busy"]) <= 0.02, (roof["frac"], pmc["mfma_busy"])
     assert roof["kernel_ms_per_step"] <= r["ms_per_step"]
     assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
     # the kernels the line names are the kernels the PMC collection saw

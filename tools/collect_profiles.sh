@@ -42,3 +42,5 @@ timeout 300 python3 tools/full_path_bench.py --images 8 > $OUT/${TAG}_full_path_
 timeout 200 python3 tools/rccl_selftest.py > $OUT/${TAG}_rccl_one_rank.json 2> $OUT/rccl.err || echo "rccl selftest failed"
 timeout 200 python3 tools/emd_time.py > $OUT/${TAG}_emd_level_culling.txt 2> $OUT/emd.err || echo "emd timing failed"
 timeout 300 python3 -m pytest tests/test_hostile_inputs_gpu.py -s -q > $OUT/${TAG}_hostile_inputs.txt 2>&1 || echo "hostile inputs run failed"
+# the default bench command, untraced, on the same box as everything above (profiles/<tag>_bench_default_run.json)
+timeout 600 python3 bench.py > $OUT/${TAG}_bench_default_run.json 2> $OUT/default.err || echo "default bench failed"
