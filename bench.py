@@ -692,13 +692,17 @@ def full_image_path_object(device, boxes=32, images=8, reps=3):
                                                      "reference's 32 boxes per image"}}
 
 
-def winograd_off_object(one_step, args, device):
-    """The step under mpsr_set_winograd_policy(MPSR_WINOGRAD_OFF) + the element-wise error that policy is for."""
+def winograd_off_object(one_step, args, device, policy="off"):
+    """The step under mpsr_set_winograd_policy(MPSR_WINOGRAD_OFF / _ACCURATE) + the element-wise error those policies
+    are for."""
     from monopsr_amd import _lib
     from monopsr_amd.core import device_net as dn
     out = {"policy": "MPSR_WINOGRAD_OFF: no F(3x3,3x3) / F(4x4,3x3) kernel (border-class implicit GEMM and the exact tap "
-                     "GEMMs instead)"}
-    _lib.set_winograd_policy("off")
+                     "GEMMs instead)" if policy == "off" else
+                     "MPSR_WINOGRAD_ACCURATE: only the transform-domain forms that keep an element-wise 1e-3 on heavy-tailed "
+                     "maps -- sixteen-product tiles (block3), F(2x2,3x3) (decoder conv2_2 / conv3_2); no F(4x4,3x3), no "
+                     "F(3x3,3x3) halo tiles (blocks 1-2 on the direct kernels); the exact tap GEMMs as always"}
+    _lib.set_winograd_policy(policy)
     for _ in range(2):
         one_step()
     torch.cuda.synchronize()
@@ -719,7 +723,7 @@ def winograd_off_object(one_step, args, device):
         x *= np.where(rng.random(shape) < 0.01, 1e3, 1.0).astype(np.float32)
         return x.astype(np.float32)
     errs = {}
-    for name, (B, H, C, N, dil) in (("decoder conv3_2 (48x48, 128 -> 128)", (24, 48, 128, 128, 1)),
+    for name, (B, H, C, N, dil) in (("decoder conv3_2 (48x48, 128 -> 128)", (32, 48, 128, 128, 1)),
                                     ("block3 conv2 (12x12, 256 -> 256, dilation 4)", (64, 12, 256, 256, 4))):
         x = hostile((B, H, H, C))
         w = rng.standard_normal((N, 3, 3, C)) * np.sqrt(2.0 / (9 * C)) * \
@@ -734,10 +738,10 @@ def winograd_off_object(one_step, args, device):
         xd, wd, bd = torch.from_numpy(x).to(device), torch.from_numpy(w.reshape(N, -1)).to(device), \
             torch.from_numpy(bias).to(device)
         row = {}
-        for policy in ("auto", "off"):
-            got = dn.conv2d(xd, wd, bd, None, 3, 3, dil, True, split_k=0, winograd_policy=policy).cpu().double().numpy()
-            row[policy] = {"tensor_scale": float("%.3g" % (np.abs(got - ref).max() / scale)),
-                           "element_wise": float("%.3g" % (np.abs(got - ref)[big] / np.abs(ref)[big]).max())}
+        for pol in ("auto", policy):
+            got = dn.conv2d(xd, wd, bd, None, 3, 3, dil, True, split_k=0, winograd_policy=pol).cpu().double().numpy()
+            row[pol] = {"tensor_scale": float("%.3g" % (np.abs(got - ref).max() / scale)),
+                        "element_wise": float("%.3g" % (np.abs(got - ref)[big] / np.abs(ref)[big]).max())}
         errs[name] = row
     out["error_vs_float64_on_heavy_tailed_map"] = dict(
         errs, what="max|err| / max|ref| and the largest relative error of an element with |ref| > 1e-3 max|ref|; map: "
@@ -1510,6 +1514,12 @@ def main():
             result["winograd_off_mode"] = winograd_off_object(one_step, args, device)
         except Exception as e:
             result["winograd_off_mode"] = {"error": repr(e)}
+        finally:
+            _lib.set_winograd_policy("auto")
+        try:  # r06: the policy between the two -- element-wise-safe transform-domain forms only
+            result["winograd_accurate_mode"] = winograd_off_object(one_step, args, device, policy="accurate")
+        except Exception as e:
+            result["winograd_accurate_mode"] = {"error": repr(e)}
         finally:
             _lib.set_winograd_policy("auto")
     if args.math == "fp32" and not args.no_train_step and not args.no_roofline:

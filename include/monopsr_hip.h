@@ -188,7 +188,8 @@ int mpsr_conv2d_nhwc_f32(const float *x, int B, int H, int W, int C, const float
  * host threads with different options do not see each other (tests/test_threads_gpu.py).  A zero-initialised struct
  * inherits the defaults. */
 enum { MPSR_CALL_MATH_INHERIT = 0, MPSR_CALL_MATH_FP32 = 1, MPSR_CALL_MATH_BF16X3 = 2 };
-enum { MPSR_CALL_WINOGRAD_INHERIT = 0, MPSR_CALL_WINOGRAD_AUTO = 1, MPSR_CALL_WINOGRAD_OFF = 2 };
+enum { MPSR_CALL_WINOGRAD_INHERIT = 0, MPSR_CALL_WINOGRAD_AUTO = 1, MPSR_CALL_WINOGRAD_OFF = 2,
+       MPSR_CALL_WINOGRAD_ACCURATE = 3 /* ABI 6 */ };
 typedef struct mpsr_conv_opts {
     int32_t math;            /* MPSR_CALL_MATH_* */
     int32_t winograd_policy; /* MPSR_CALL_WINOGRAD_* */
@@ -225,8 +226,13 @@ int mpsr_get_conv_math(void);
  *   MPSR_WINOGRAD_OFF  direct / implicit-GEMM kernels everywhere (the upsampled convolutions keep their exact tap
  *                      GEMM): element-wise 5e-5 .. 1e-4 on the same inputs, at 1.33x the step time (17.8 vs 13.4 ms:
  *                      bench.py's `winograd_off_mode` object times it and measures both policies' errors).  For callers whose
- *                      activations are heavy-tailed AND who read small outputs individually. */
-enum { MPSR_WINOGRAD_AUTO = 0, MPSR_WINOGRAD_OFF = 1 };
+ *                      activations are heavy-tailed AND who read small outputs individually.
+ *   MPSR_WINOGRAD_ACCURATE (r06) only the transform-domain forms whose ELEMENT-WISE error on such maps stays inside
+ *                      1e-3: the sixteen-product form for block3's atrous layers (2e-4) and F(2x2,3x3) for the dense
+ *                      decoder layers (transform constants 1 and 1/2); F(4x4,3x3) and the F(3x3,3x3) halo tiles are not
+ *                      used (their layers take F(2x2,3x3) / the direct kernels).  Between the two above in speed
+ *                      (bench.py's `winograd_accurate_mode`). */
+enum { MPSR_WINOGRAD_AUTO = 0, MPSR_WINOGRAD_OFF = 1, MPSR_WINOGRAD_ACCURATE = 2 };
 int mpsr_set_winograd_policy(int policy);
 int mpsr_get_winograd_policy(void);
 

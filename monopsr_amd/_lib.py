@@ -69,7 +69,7 @@ class PackJob(ctypes.Structure):
 
 # per-call option values (MPSR_CALL_MATH_*, MPSR_CALL_WINOGRAD_*): None / "inherit" = the process-wide default
 CALL_MATH = {None: 0, "inherit": 0, "fp32": 1, "bf16x3": 2}
-CALL_WINOGRAD = {None: 0, "inherit": 0, "auto": 1, "off": 2}
+CALL_WINOGRAD = {None: 0, "inherit": 0, "auto": 1, "off": 2, "accurate": 3}
 
 
 # name -> (restype, argtypes); must list every symbol include/monopsr_hip.h declares (tests/test_cabi.py checks).
@@ -213,12 +213,13 @@ def set_conv_math(mode):
     return prev
 
 
-WINOGRAD_POLICIES = {"auto": 0, "off": 1}
+WINOGRAD_POLICIES = {"auto": 0, "off": 1, "accurate": 2}
 
 
 def set_winograd_policy(policy):
-    """Process-wide: "auto" (default: Winograd kernels wherever they are faster) or "off" (direct / implicit-GEMM
-    kernels everywhere: tighter element-wise error on heavy-tailed activations, include/monopsr_hip.h).  Returns the
+    """Process-wide: "auto" (default: Winograd kernels wherever they are faster), "off" (direct / implicit-GEMM kernels
+    everywhere: tightest element-wise error on heavy-tailed activations) or "accurate" (only the transform-domain forms
+    that keep an element-wise 1e-3 on such maps: sixteen-product tiles, F(2x2,3x3); include/monopsr_hip.h).  Returns the
     previous policy."""
     names = {v: k for k, v in WINOGRAD_POLICIES.items()}
     prev = names[lib().mpsr_get_winograd_policy()]

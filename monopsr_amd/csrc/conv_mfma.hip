@@ -1200,6 +1200,10 @@ static int winograd_mode()
     const int wino = g_wino_override.load();
     return (wino < 0 && cur_wino_policy() == MPSR_WINOGRAD_OFF) ? 0 : wino;
 }
+// MPSR_WINOGRAD_ACCURATE (r06): of the transform-domain forms only those that keep an element-wise 1e-3 on heavy-tailed
+// maps -- the sixteen-product tiles and F(2x2,3x3); no F(4x4,3x3), no F(3x3,3x3) tiles with halos.  (A debug override of
+// the Winograd selector wins, as everywhere.)
+static bool accurate_only() { return g_wino_override.load() < 0 && cur_wino_policy() == MPSR_WINOGRAD_ACCURATE; }
 
 // True when conv2d() with split_k = 0 would send this 3x3 layer to the F(4x4,3x3) kernel (network.hip asks before it
 // lays the decoder's internal tensors out channel-blocked, which only that kernel reads).
@@ -1207,6 +1211,7 @@ bool conv2d_takes_winograd4(int B, int H, int W, int C, int N, const float *ws, 
 {
     const long long M64 = (long long)B * H * W;
     const int wino = winograd_mode();
+    if (accurate_only()) return false;
     return ws && (wino < 0 || wino == 2) && g_tile_override.load() < 0 && M64 >= 65536 && C >= 64 && N >= 64 &&
            winograd4_applies(H, W, C, N) && ws_floats >= winograd4_scratch_floats(C, N) && M64 * C * 4 < 0x7f000000LL;
 }
@@ -1236,6 +1241,7 @@ bool conv2d_takes_winograd3(int B, int H, int W, int C, int N, int KH, int KW, i
     const bool want3 = wino == 3 || (wino < 0 && g_tile_override.load() < 0 && g_class_override.load() < 0 &&
                                      th <= th_max && (dilation > 1 || th > 1) &&
                                      (long long)B * dilation * dilation * th * th >= min_tiles && C >= 64 && N >= 64);
+    if (accurate_only() && !(th == 1 && winograd3_form(B, H, W, C, N, dilation) == 2)) return false;
     return can3 && want3;
 }
 
@@ -1427,7 +1433,8 @@ extern "C" void mpsr_debug_set_conv_plain(int mode) { g_plain_override = mode; }
 extern "C" void mpsr_debug_set_conv_winograd(int mode) { g_wino_override = mode; }
 extern "C" int mpsr_set_winograd_policy(int policy)
 {
-    MPSR_REQUIRE(policy == MPSR_WINOGRAD_AUTO || policy == MPSR_WINOGRAD_OFF, "set_winograd_policy: unknown policy %d", policy);
+    MPSR_REQUIRE(policy == MPSR_WINOGRAD_AUTO || policy == MPSR_WINOGRAD_OFF || policy == MPSR_WINOGRAD_ACCURATE,
+                 "set_winograd_policy: unknown policy %d", policy);
     g_wino_policy = policy;
     return MPSR_OK;
 }
@@ -1540,7 +1547,7 @@ extern "C" int mpsr_conv2d_nhwc_f32_ex(const float *x, int B, int H, int W, int 
 {
     if (opts) {
         MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "conv2d: unknown opts.math %d", opts->math);
-        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_ACCURATE,
                      "conv2d: unknown opts.winograd_policy %d", opts->winograd_policy);
     }
     mpsr::CallOptsGuard guard(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);

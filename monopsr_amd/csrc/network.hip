@@ -175,7 +175,7 @@ extern "C" int mpsr_trunk_fwd_ex(const float *img, int B, int H, int W, const fl
     MPSR_REQUIRE(B >= 0 && H >= 7 && W >= 7, "trunk_fwd: bad input shape (B=%d H=%d W=%d)", B, H, W);
     if (opts) {
         MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "%s: unknown opts.math %d", "trunk_fwd", opts->math);
-        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_ACCURATE,
                      "%s: unknown opts.winograd_policy %d", "trunk_fwd", opts->winograd_policy);
     }
     mpsr::CallOptsGuard call_opts(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);
@@ -369,7 +369,7 @@ extern "C" int mpsr_squash_decoder_fwd_ex(const float *crop_feat, const float *f
                  "squash_decoder_fwd: bad shape");
     if (opts) {
         MPSR_REQUIRE(opts->math >= 0 && opts->math <= MPSR_CALL_MATH_BF16X3, "%s: unknown opts.math %d", "squash_decoder_fwd", opts->math);
-        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_OFF,
+        MPSR_REQUIRE(opts->winograd_policy >= 0 && opts->winograd_policy <= MPSR_CALL_WINOGRAD_ACCURATE,
                      "%s: unknown opts.winograd_policy %d", "squash_decoder_fwd", opts->winograd_policy);
     }
     mpsr::CallOptsGuard call_opts(opts ? opts->math : 0, opts ? opts->winograd_policy : 0);
