@@ -170,9 +170,13 @@ SIGNATURES = {
 
 
 def lib():
-    """Load libmonopsr_hip.so once.  Import torch first in GPU processes so both share one HIP runtime."""
+    """Load libmonopsr_hip.so once -- AFTER torch, so that both resolve to ONE HIP runtime (torch ships its own
+    libamdhip64; loaded second it would be a second runtime in the process, and a kernel launched through the first one
+    on torch's memory fails with "no ROCm-capable device is detected": seen in r06 when build() loaded the library before
+    smoke() imported torch)."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  (the order matters, see above)
         if not os.path.exists(LIB_PATH):
             raise MpsrError(
                 "libmonopsr_hip.so is not built (%s). Build it with `python -c 'import __graft_entry__ as g; "
