@@ -393,22 +393,28 @@ int mpsr_batch_norm_grad(const float *dy, const float *y, const float *z, long l
  * slim.learning.create_train_op(clip_gradient_norm=1.0) does (core/trainer.py:78-81): g *= clip / max(||g||, clip).
  * The caller describes the variables once as a chunk table (device arrays): chunk i covers
  * grads[chunk_begin[i] .. +chunk_len[i]) and belongs to variable chunk_seg[i] in [0, n_segments).
- * sumsq: n_segments floats of scratch (holds each variable's squared norm on return). */
+ * chunk_seg ascends (a variable's chunks are consecutive).
+ * sumsq: scratch of sumsq_floats >= n_segments + n_chunks floats (MPSR_ERR_WORKSPACE otherwise): the first n_segments
+ * hold each variable's squared norm on return, the rest the chunks' partial sums.  ABI 6 (signature changed: sumsq_floats):
+ * the norms are summed in a FIXED order -- per chunk, then over a variable's chunks -- with no atomics, so every replica of
+ * a data-parallel run scales the same reduced gradient by the same bits and the replicas' parameters stay bit-identical
+ * (tests/test_sharded_training_step_gpu.py; an atomic accumulation left two ranks one ulp apart after one step). */
 int mpsr_clip_by_norm_segments(float *grads, const int *chunk_seg, const long long *chunk_begin,
-                               const int *chunk_len, int n_chunks, float *sumsq, int n_segments, float clip_norm,
-                               mpsr_stream_t stream);
+                               const int *chunk_len, int n_chunks, float *sumsq, size_t sumsq_floats, int n_segments,
+                               float clip_norm, mpsr_stream_t stream);
 
-/* ABI 6: the tail of a training step in two launches -- per-variable tf.clip_by_norm (core/trainer.py:78-81), the Adam
+/* ABI 6: the tail of a training step in three launches -- per-variable tf.clip_by_norm (core/trainer.py:78-81), the Adam
  * update (builders/optimizer_builder.py:61-80) and the parameter moving average (tf.contrib.opt.MovingAverageOptimizer,
  * optimizer_builder.py:75-80) over the same chunk table: squared norms, then ONE pass that scales the gradient on its way
  * into the update (grads are left as they came), updates m / v / param and, when `shadow` is not NULL,
  * shadow += (1 - ema_decay) * (param - shadow).  Operation by operation the arithmetic of mpsr_clip_by_norm_segments ->
  * mpsr_adam_step -> that moving average; elements outside every chunk (alignment padding) are not touched.
- * clip_norm <= 0: no clipping (sumsq may be NULL).  step = 1-based Adam step (bias correction). */
+ * clip_norm <= 0: no clipping (sumsq may be NULL).  sumsq / sumsq_floats as mpsr_clip_by_norm_segments (deterministic
+ * norms).  step = 1-based Adam step (bias correction). */
 int mpsr_clip_adam_ema_step(float *param, const float *grad, float *m, float *v, float *shadow, const int *chunk_seg,
                             const long long *chunk_begin, const int *chunk_len, int n_chunks, float *sumsq,
-                            int n_segments, float clip_norm, float lr, float beta1, float beta2, float eps, int step,
-                            float ema_decay, mpsr_stream_t stream);
+                            size_t sumsq_floats, int n_segments, float clip_norm, float lr, float beta1, float beta2,
+                            float eps, int step, float ema_decay, mpsr_stream_t stream);
 
 /* ------------------------------------------------------------------------- per-box geometry and map losses
  * SURVEY.md 8(f) rows 3-4.  Maps are (b, h, w, c) row-major; p = h*w points per instance. */

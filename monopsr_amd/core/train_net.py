@@ -276,15 +276,15 @@ class TrainNet:
 
     def clip_adam_ema_step(self, clip_table, clip_norm, lr=8e-5, shadow=None, ema_decay=0.0, beta1=0.9, beta2=0.999,
                            eps=1e-8):
-        """Per-variable clip_by_norm + Adam + the parameter moving average as two launches over the chunk table
-        `clip_table` = (chunk_seg, chunk_begin, chunk_len, sumsq) of InstanceTrainer._clip_table (mpsr_clip_adam_ema_step:
+        """Per-variable clip_by_norm + Adam + the parameter moving average as three launches over the chunk table
+        `clip_table` = (chunk_seg, chunk_begin, chunk_len, sumsq, n_variables) of InstanceTrainer._clip_table (mpsr_clip_adam_ema_step:
         the gradient is scaled on its way into the update and NOT written back).  clip_norm 0 / None: no clipping."""
-        seg, begin, length, sumsq = clip_table
+        seg, begin, length, sumsq, nseg = clip_table
         self.step_count += 1
         _lib.check(_lib.lib().mpsr_clip_adam_ema_step(
             _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.ptr(shadow),
             _lib.ptr(seg), _lib.ptr(begin), _lib.ptr(length), seg.numel(), _lib.ptr(sumsq), sumsq.numel(),
-            float(clip_norm or 0.0), lr, beta1, beta2, eps, self.step_count, float(ema_decay), _lib.stream()))
+            nseg, float(clip_norm or 0.0), lr, beta1, beta2, eps, self.step_count, float(ema_decay), _lib.stream()))
 
     def adam_step(self, lr=8e-5, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
         """tf.train.AdamOptimizer update (optimizer_builder.py:61-80; lr 8e-5 from monopsr_model_000.yaml:141-147)."""

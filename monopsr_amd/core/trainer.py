@@ -192,7 +192,9 @@ class InstanceTrainer:
         return self.model.loss(out, self.model.gt_dict, sample.get('gt_alpha_valid_bins'))
 
     def _clip_table(self, chunk=16384):
-        """Chunk table of mpsr_clip_by_norm_segments: every weight / bias gradient is one variable."""
+        """Chunk table of mpsr_clip_by_norm_segments: every weight / bias gradient is one variable (chunks of a variable
+        consecutive, variables ascending).  -> (chunk_seg, chunk_begin, chunk_len, sumsq scratch of n_variables + n_chunks
+        floats, n_variables)."""
         base = self.net.grads.data_ptr()
         seg, begin, length = [], [], []
         nseg = 0
@@ -209,17 +211,17 @@ class InstanceTrainer:
         dev = self.net.grads.device
         return (torch.tensor(seg, dtype=torch.int32, device=dev), torch.tensor(begin, dtype=torch.int64, device=dev),
                 torch.tensor(length, dtype=torch.int32, device=dev),
-                torch.empty((nseg,), dtype=torch.float32, device=dev))
+                torch.empty((nseg + len(seg),), dtype=torch.float32, device=dev), nseg)
 
     def clip_per_variable(self):
         """tf.clip_by_norm(g, clip_norm) per variable (weights and biases separately), on the reduced gradients:
-        two launches over the flat buffer."""
+        three launches over the flat buffer (deterministic norms)."""
         if self._clip is None:
             self._clip = self._clip_table()
-        seg, begin, length, sumsq = self._clip
+        seg, begin, length, sumsq, nseg = self._clip
         _lib.check(_lib.lib().mpsr_clip_by_norm_segments(
             _lib.ptr(self.net.grads), _lib.ptr(seg), _lib.ptr(begin), _lib.ptr(length), seg.numel(), _lib.ptr(sumsq),
-            sumsq.numel(), float(self.clip_norm), _lib.stream()))
+            sumsq.numel(), nseg, float(self.clip_norm), _lib.stream()))
         return self.net.grads
 
     def step(self, sample):

@@ -653,6 +653,25 @@ def test_clip_by_norm_segments_matches_per_tensor_clip():
     assert float((net.grads - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
     lo = (net.layers[3].dw.data_ptr() - base) // 4
     assert torch.equal(net.grads[lo:lo + net.layers[3].dw.numel()], before[lo:lo + net.layers[3].dw.numel()])
+    # the norms are summed in a fixed order (r06: replicas of a data-parallel run must clip the same reduced gradient by
+    # the same bits): the same gradients give the same bits run after run, variables spread over many chunks included
+    seg, begin, length, sumsq, nseg = tr._clip
+    assert int(torch.bincount(seg.long()).max()) > 8 and sumsq.numel() == nseg + seg.numel()
+    runs = []
+    for _ in range(6):
+        net.grads.copy_(before)
+        sumsq.fill_(float("nan"))
+        tr.clip_per_variable()
+        runs.append((sumsq[:nseg].clone(), net.grads.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    want_sq = torch.stack([before[b:b + n].double().square().sum() for b, n in zip(begin.tolist(), length.tolist())])
+    want_sq = torch.zeros(nseg, dtype=torch.float64, device="cuda").index_add_(0, seg.long(), want_sq)
+    assert float(((runs[0][0].double() - want_sq).abs() / want_sq).max()) < 1e-5
+    # a scratch without room for the chunks' partial sums is refused
+    from monopsr_amd import _lib
+    rc = _lib.lib().mpsr_clip_by_norm_segments(_lib.ptr(net.grads), _lib.ptr(seg), _lib.ptr(begin), _lib.ptr(length),
+                                               seg.numel(), _lib.ptr(sumsq), nseg, nseg, 1.0, _lib.stream())
+    assert rc != 0 and b"n_segments + n_chunks" in _lib.lib().mpsr_last_error()
 
 
 def test_fused_clip_adam_ema_equals_the_three_passes():
@@ -678,7 +697,7 @@ def test_fused_clip_adam_ema_equals_the_three_passes():
     g = torch.Generator(device="cuda").manual_seed(6)
     # the variables' elements (the flat buffer also holds alignment padding, whose gradient is always zero in a real
     # step: the whole-buffer Adam pass leaves it alone for that reason, the chunk pass because no chunk covers it)
-    seg, begin, length, _ = trs[1]._clip_table()
+    seg, begin, length, _, _ = trs[1]._clip_table()
     covered = torch.zeros(trs[0].net.grads.shape, dtype=torch.bool, device="cuda")
     for lo, n in zip(begin.tolist(), length.tolist()):
         covered[lo:lo + n] = True

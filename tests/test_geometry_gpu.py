@@ -306,7 +306,7 @@ def test_geometry_entry_points_reject_bad_arguments():
                                     x.data_ptr(), s) == 1                                   # delta must be > 0
     assert lib.mpsr_format_boxes(*([x.data_ptr()] * 9), 2, 0, 375, 1242, 1, 1, 45.0, x.data_ptr(), x.data_ptr(), s) == 1
     assert lib.mpsr_set_conv_math(7) == 1 and lib.mpsr_get_conv_math() == 0
-    assert lib.mpsr_clip_by_norm_segments(x.data_ptr(), None, None, None, 3, x.data_ptr(), 2, 1.0, s) == 1
+    assert lib.mpsr_clip_by_norm_segments(x.data_ptr(), None, None, None, 3, x.data_ptr(), 5, 2, 1.0, s) == 1
     with pytest.raises(_lib.InvalidArgumentError):
         iu.tf_inst_xyz_map_local_to_global(x[..., :2], (4, 4), torch.zeros((2, 1), device="cuda"),
                                            torch.zeros((2, 3), device="cuda"))
