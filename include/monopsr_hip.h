@@ -377,6 +377,18 @@ int mpsr_crop_and_resize_grad(const float *grad_out, int nimg, int H, int W, int
  * so mean = z[0] + sum/M and the (biased) variance = sumsq_shifted/M - (sum/M)^2. */
 int mpsr_batch_norm_stats(const float *z, long long M, int C, double *sum, double *sumsq_shifted,
                           mpsr_stream_t stream);
+/* ABI 6: the per-channel arithmetic between the passes as one launch each (they were ~16 and ~4 tiny tensor operations
+ * per layer and step on the host framework's side).  Forward: d = sum / M, mean = z_row0 + d (z_row0 = the first row of
+ * z, the shift of the sums), var = max(sumsq_shifted / M - d^2, 0) in fp64; mean and inv_std = 1 / sqrt(var + eps) as
+ * floats; moving_mean = moving_mean * decay + (1 - decay) * mean and moving_variance likewise with the UNBIASED
+ * variance var * M / max(M - 1, 1), as TensorFlow's fused kernel feeds its moving average (either may be NULL: not
+ * updated).  Backward: dbeta += sum_g (NULL: not deposited), mean_g = sum_g / count, mean_gz = sum_gz / count (count =
+ * the rows the statistics were taken over).  A caller that pools the sums over ranks does this arithmetic itself. */
+int mpsr_batch_norm_finalize(const double *sum, const double *sumsq_shifted, const float *z_row0, long long M, int C,
+                             float eps, float decay, float *moving_mean, float *moving_variance, float *mean,
+                             float *inv_std, mpsr_stream_t stream);
+int mpsr_batch_norm_grad_finalize(const double *sum_g, const double *sum_gz, double count, int C, float *dbeta,
+                                  float *mean_g, float *mean_gz, mpsr_stream_t stream);
 /* y = act((z - mean) * inv_std + beta); relu 0/1; mean, inv_std, beta (C). */
 int mpsr_batch_norm_apply(const float *z, long long M, int C, const float *mean, const float *inv_std,
                           const float *beta, int relu, float *y, mpsr_stream_t stream);

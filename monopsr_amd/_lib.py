@@ -126,6 +126,9 @@ SIGNATURES = {
                                     ctypes.c_float, ctypes.c_float, c_f]),
     "mpsr_crop_and_resize_grad": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "mpsr_batch_norm_stats": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f]),
+    "mpsr_batch_norm_finalize": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f,
+                                       c_f, c_f, c_f]),
+    "mpsr_batch_norm_grad_finalize": (c_i, [c_f, c_f, ctypes.c_double, c_i, c_f, c_f, c_f, c_f]),
     "mpsr_batch_norm_apply": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_i, c_f, c_f]),
     "mpsr_batch_norm_grad_sums": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_batch_norm_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),

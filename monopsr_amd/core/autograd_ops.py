@@ -114,9 +114,63 @@ def _pad4(L, g):
     return (F.pad(g, (0, pad)) if pad else g), pad
 
 
+# Weight gradients are LEAVES of the backward pass: nothing later in the pass reads dW, while the data gradients form the
+# chain every other launch waits for.  r06: they are launched on a second HIP stream, so that the ramp-up and the drain of
+# each launch -- ~30 us of a 1x1 weight gradient's 180 are fixed cost, not loop time -- overlap with the
+# other stream's work instead of idling the chip.  The side stream waits for the event that marks x and g ready; x and g
+# are pinned to it (record_stream); the main stream joins it at the end of the backward pass (an autograd engine
+# callback queued by the first deposit of the pass) and before the data-parallel reducer issues a bucket.
+# A/B switch (tools/train_bench.py --wgrad-main-stream).
+WGRAD_SIDE_STREAM = True
+WGRAD_SIDE_STREAMS = 1  # how many side streams the launches rotate over
+_WGRAD_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
+_WGRAD_NEXT = {}      # device index -> launches so far (the rotation)
+_JOIN_QUEUED = set()  # device indices whose end-of-backward join is queued in the running pass
+
+
+def _wgrad_stream(device):
+    pool = _WGRAD_STREAMS.setdefault(device.index, [])
+    k = _WGRAD_NEXT.get(device.index, 0)
+    _WGRAD_NEXT[device.index] = k + 1
+    k %= max(1, WGRAD_SIDE_STREAMS)
+    while len(pool) <= k:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[k]
+
+
+def join_wgrad_stream(device=None):
+    """Make the current stream wait for every weight gradient launched on the side stream so far (no-op when the side
+    stream was never used).  Called by the backward pass's own end-of-pass callback, by the reducer before it issues a
+    bucket, and by anyone who reads the flat gradient buffer from inside a backward pass."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    _JOIN_QUEUED.discard(idx)
+    for s in _WGRAD_STREAMS.get(idx, ()):
+        torch.cuda.current_stream(idx).wait_stream(s)
+
+
 def _deposit_weight_grad(L, x, g):
     """dW (and db) of one layer from its input x and the gradient g at its pre-activation output, accumulated into the
     layer's slices of the flat gradient buffer; then the layer's `on_grad_ready` hook (the data-parallel reducer)."""
+    if WGRAD_SIDE_STREAM and x.is_cuda:
+        dev = x.device
+        main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
+        if dev.index not in _JOIN_QUEUED:
+            _JOIN_QUEUED.add(dev.index)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(dev))
+        side.wait_stream(main)  # x, g (and the step's zeroed gradient buffer) are ready on the main stream here
+        with torch.cuda.stream(side):
+            _launch_weight_grad(L, x, g)
+        x.record_stream(side)
+        g.record_stream(side)
+    else:
+        _launch_weight_grad(L, x, g)
+    ready = getattr(L, "on_grad_ready", None)
+    if ready is not None:
+        ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete (or on its way on
+        #          the side stream: the reducer joins it before a bucket leaves)
+
+
+def _launch_weight_grad(L, x, g):
     lib = _lib.lib()
     s = _lib.stream()
     B, H, W, C = x.shape
@@ -142,9 +196,6 @@ def _deposit_weight_grad(L, x, g):
         L.db.add_(db4[:N])
     if pad:
         L.dw.add_(dw4[:N])
-    ready = getattr(L, "on_grad_ready", None)
-    if ready is not None:
-        ready()  # e.g. the data-parallel reducer: this layer's slice of the flat gradient is complete
 
 
 class DgradBank:
@@ -457,9 +508,14 @@ class BatchNormReluFn(torch.autograd.Function):
         _lib.check(lib.mpsr_batch_norm_stats(_lib.ptr(z), M, C, sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
         Mtot = M
         if st._group() is None:
-            d = sums[0] / M
-            mean = z.reshape(M, C)[0].double() + d
-            var = torch.clamp(sums[1] / M - d * d, min=0.0)
+            # mean / variance, the moving statistics and the two float vectors of the apply pass in ONE launch
+            # (r06: the torch expressions below were ~16 launches of 3-5 us per layer and step)
+            stats = torch.empty((2, C), dtype=torch.float32, device=z.device)
+            mean32, inv = stats[0], stats[1]
+            _lib.check(lib.mpsr_batch_norm_finalize(sums[0].data_ptr(), sums[1].data_ptr(), _lib.ptr(z), M, C,
+                                                    float(st.eps), float(st.decay), _lib.ptr(st.moving_mean),
+                                                    _lib.ptr(st.moving_variance), mean32.data_ptr(), inv.data_ptr(),
+                                                    _lib.stream()))
         else:
             # the kernel's sums are of (z - z[0]) per rank: un-shift them to plain first / second moments in fp64, pool
             # [sum z | sum z^2 | count] over the ranks, then mean and (biased) variance of the WHOLE step's batch
@@ -470,12 +526,12 @@ class BatchNormReluFn(torch.autograd.Function):
             Mtot = pooled[2 * C]
             mean = pooled[:C] / Mtot
             var = torch.clamp(pooled[C:2 * C] / Mtot - mean * mean, min=0.0)
-        with torch.no_grad():
-            st.moving_mean.mul_(st.decay).add_(mean.float(), alpha=1.0 - st.decay)
-            unbias = (Mtot / torch.clamp(Mtot - 1, min=1.0)) if torch.is_tensor(Mtot) else M / max(M - 1, 1)
-            st.moving_variance.mul_(st.decay).add_((var * unbias).float(), alpha=1.0 - st.decay)
-        mean32 = mean.float().contiguous()
-        inv = torch.rsqrt(var + st.eps).float().contiguous()
+            with torch.no_grad():
+                st.moving_mean.mul_(st.decay).add_(mean.float(), alpha=1.0 - st.decay)
+                unbias = Mtot / torch.clamp(Mtot - 1, min=1.0)
+                st.moving_variance.mul_(st.decay).add_((var * unbias).float(), alpha=1.0 - st.decay)
+            mean32 = mean.float().contiguous()
+            inv = torch.rsqrt(var + st.eps).float().contiguous()
         y = torch.empty_like(z)
         _lib.check(lib.mpsr_batch_norm_apply(_lib.ptr(z), M, C, _lib.ptr(mean32), _lib.ptr(inv), _lib.ptr(layer.b),
                                              int(layer.relu), _lib.ptr(y), _lib.stream()))
@@ -495,10 +551,17 @@ class BatchNormReluFn(torch.autograd.Function):
         sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
         _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
                                                  _lib.ptr(inv), sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
-        L.db.add_(sums[0].float())  # (this rank's share: the gradient all-reduce pools it like every other parameter's)
-        # the two means of the normalisation's backward are over the rows the statistics came from
-        L.batch_norm.all_reduce_sums(sums)
-        means = (sums / ctx.count).float().contiguous()
+        # d(beta) is this rank's share (the gradient all-reduce pools it like every other parameter's); the two means of
+        # the normalisation's backward are over the rows the statistics came from
+        if L.batch_norm._group() is None:
+            means = torch.empty((2, C), dtype=torch.float32, device=z.device)
+            _lib.check(lib.mpsr_batch_norm_grad_finalize(sums[0].data_ptr(), sums[1].data_ptr(), float(ctx.count), C,
+                                                         _lib.ptr(L.db), means[0].data_ptr(), means[1].data_ptr(),
+                                                         _lib.stream()))
+        else:
+            L.db.add_(sums[0].float())
+            L.batch_norm.all_reduce_sums(sums)
+            means = (sums / ctx.count).float().contiguous()
         dz = torch.empty_like(z)
         _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
                                             _lib.ptr(inv), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),

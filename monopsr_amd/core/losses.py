@@ -20,10 +20,12 @@ class Loss(object):
 
 
 def huber_elementwise(prediction_tensor, target_tensor, delta):
-    """tf.losses.huber_loss term: 0.5 q^2 + delta (|e| - q) with q = min(|e|, delta)."""
-    e = (prediction_tensor - target_tensor).abs()
-    q = torch.clamp(e, max=delta)
-    return 0.5 * q * q + delta * (e - q)
+    """tf.losses.huber_loss term: 0.5 q^2 + delta (|e| - q) with q = min(|e|, delta), i.e. 0.5 e^2 for |e| <= delta and
+    delta (|e| - 0.5 delta) beyond -- torch's huber_loss, ONE launch forward and one backward where the expression
+    written out was 8 and ~12 on these few-KB tensors (r06 launch census of the training step)."""
+    if prediction_tensor.shape != target_tensor.shape:
+        prediction_tensor, target_tensor = torch.broadcast_tensors(prediction_tensor, target_tensor)
+    return F.huber_loss(prediction_tensor, target_tensor, reduction='none', delta=float(delta))
 
 
 class WeightedSmoothL1LocalizationLoss(Loss):

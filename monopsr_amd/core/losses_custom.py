@@ -19,20 +19,20 @@ class _HuberNonZero(torch.autograd.Function):
         p = pred[0].numel() // c if b else 0
         pred, target = pred.contiguous().float(), target.contiguous().float()
         weights = weights.contiguous().float()
-        sums = torch.empty((b,), dtype=torch.float32, device=pred.device)
-        counts = torch.empty((b,), dtype=torch.float32, device=pred.device)
+        both = torch.empty((2, b), dtype=torch.float32, device=pred.device)  # per-instance sums | non-zero counts
         _lib.check(_lib.lib().mpsr_huber_loss_sums(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weights), b, p, c,
-                                                   float(delta), _lib.ptr(sums), _lib.ptr(counts), _lib.stream()))
-        n = counts.sum()
+                                                   float(delta), both[0].data_ptr(), both[1].data_ptr(), _lib.stream()))
+        tot = both.sum(1)
+        n = torch.clamp(tot[1], min=1.0)  # (no non-zero weight: the sum is 0 too, 0 / 1 = the reference's 0)
         ctx.save_for_backward(pred, target, weights, n)
         ctx.meta = (b, p, c, float(delta))
-        return torch.where(n > 0, sums.sum() / torch.clamp(n, min=1.0), torch.zeros_like(n))
+        return tot[0] / n
 
     @staticmethod
     def backward(ctx, g):
         pred, target, weights, n = ctx.saved_tensors
         b, p, c, delta = ctx.meta
-        scale = torch.where(n > 0, g.float() / torch.clamp(n, min=1.0), torch.zeros_like(n)).reshape(1).contiguous()
+        scale = (g.float() / n).reshape(1)  # (all weights zero: the kernel multiplies by them, the gradient is 0)
         grad = torch.empty_like(pred)
         _lib.check(_lib.lib().mpsr_huber_loss_grad(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weights),
                                                    _lib.ptr(scale), b, p, c, delta, _lib.ptr(grad), _lib.stream()))

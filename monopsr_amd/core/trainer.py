@@ -71,6 +71,10 @@ class ReverseBucketReducer:
     def _launch(self, bi):
         self.launched[bi] = True
         if self._active():
+            if self.flat.is_cuda:
+                # the weight gradients run on a side stream (autograd_ops._deposit_weight_grad): the collective must see them
+                from monopsr_amd.core import autograd_ops
+                autograd_ops.join_wgrad_stream(self.flat.device)
             lo, hi = self.buckets[bi]
             world = dist.get_world_size(self.group)
             if self.mode == "direct" and (hi - lo) % world == 0:

@@ -271,6 +271,136 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     }
 }
 
+// The same GEMM for 1x1 layers WITHOUT shared memory (r06).  Both operands are "K-major" -- a pixel's N / C values are
+// contiguous and the reduction runs over pixels -- which is exactly the operand layout of v_mfma_f32_32x32x2_f32: lane
+// (i, k) = (lane & 31, lane >> 5) holds column i of reduction row k, i.e. the 32 lanes of a half-wave read ONE 128-byte
+// segment of pixel row k.  So a wave feeds its 64 x 64 share of the tile with four dword buffer loads per four MFMAs
+// straight from L2 / the vector cache into the MFMA's source registers: no LDS staging, no barriers (the four waves
+// of a workgroup never wait for each other), no register -> LDS -> register round trip.  Loads run a ring of WD_DEPTH
+// reduction pairs ahead.  Same tiles, slices, XCD grouping, atomics and bias gradient as conv_wgrad_kernel.
+// An A/B alternative, not the default (see g_wgrad_direct below): its dword loads cost more than the LDS kernel's
+// float4 loads + staging save.
+#ifndef WD_DEPTH
+#define WD_DEPTH 8
+#endif
+__global__ __launch_bounds__(256) void pw_wgrad_direct_kernel(const WgradParams p)
+{
+    int t = blockIdx.x;
+    const int nsplit = p.per_tap ? p.tap_splits[0] : p.splits;
+    if (p.grouped) {
+        const int tiles = p.ntile_n * p.ntile_c;
+        const int xcd = t & 7, l = t >> 3;
+        const int g = (l / tiles) * 8 + xcd;
+        if (g >= p.ngroups) return;  // block-uniform
+        t = l % tiles + g * tiles;
+    }
+    const int tn = t % p.ntile_n; t /= p.ntile_n;
+    const int tc = t % p.ntile_c; t /= p.ntile_c;
+    const int si = t;
+    const int n0 = tn * WG_T, c0 = tc * WG_T;
+    const int msteps = (p.M + WG_K - 1) / WG_K;
+    const int per_split = (msteps + nsplit - 1) / nsplit;
+    const int ms_begin = si * per_split;
+    const int ms_end = min(msteps, ms_begin + per_split);
+    if (ms_begin >= ms_end) return;
+    // reduction pairs (two pixel rows each) of this slice; rows past M read as zero (their offsets are past the buffers)
+    const int kp_begin = ms_begin * (WG_K / 2), kp_end = ms_end * (WG_K / 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int col = lane & 31, kh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, (int)p.dybytes, 0x00020000);
+    const unsigned NB = (unsigned)p.N * 4u, CB = (unsigned)p.C * 4u;
+    const int na = n0 + wm * 64 + col, cb = c0 + wn * 64 + col;
+    // byte offsets of this lane's element of the first pair; a column outside the tensor keeps an out-of-range offset
+    // (increment 0).  The host keeps (M + 2 * WD_DEPTH + 32) rows of either tensor below 4 GiB: no wrap-around.
+    const unsigned row0 = (unsigned)(kp_begin * 2 + kh);
+    unsigned oa0 = na < p.N ? row0 * NB + (unsigned)na * 4u : 0xfffffff0u;
+    unsigned oa1 = na + 32 < p.N ? row0 * NB + (unsigned)(na + 32) * 4u : 0xfffffff0u;
+    unsigned ob0 = cb < p.C ? row0 * CB + (unsigned)cb * 4u : 0xfffffff0u;
+    unsigned ob1 = cb + 32 < p.C ? row0 * CB + (unsigned)(cb + 32) * 4u : 0xfffffff0u;
+    const unsigned ia0 = na < p.N ? 2u * NB : 0u, ia1 = na + 32 < p.N ? 2u * NB : 0u;
+    const unsigned ib0 = cb < p.C ? 2u * CB : 0u, ib1 = cb + 32 < p.C ? 2u * CB : 0u;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float a0[WD_DEPTH], a1[WD_DEPTH], b0[WD_DEPTH], b1[WD_DEPTH];
+    auto issue = [&](int d) {
+        a0[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, oa0, 0, 0));
+        a1[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, oa1, 0, 0));
+        b0[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ob0, 0, 0));
+        b1[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ob1, 0, 0));
+        oa0 += ia0; oa1 += ia1; ob0 += ib0; ob1 += ib1;
+    };
+    // bias gradient = column sums of dy, by the waves that hold columns n0 .. n0 + 127 of channel tile 0 (wn == 0)
+    const bool do_db = p.db != nullptr && tc == 0 && wn == 0;
+    float cs0 = 0.f, cs1 = 0.f;
+    auto consume = [&](int d) {
+        if (do_db) { cs0 += a0[d]; cs1 += a1[d]; }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[d], b0[d], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[d], b1[d], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[d], b0[d], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[d], b1[d], acc[1][1], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < WD_DEPTH; ++d) issue(d);
+    int kp = kp_begin;
+    for (; kp + WD_DEPTH <= kp_end; kp += WD_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < WD_DEPTH; ++d) {
+            consume(d);
+#ifdef WG_NO_LOAD  // (timing experiment only)
+            asm volatile("" : "+v"(a0[d]), "+v"(a1[d]), "+v"(b0[d]), "+v"(b1[d]));
+            continue;
+#endif
+            issue(d);  // the pair WD_DEPTH ahead (past the slice: rows of the next slice or zeros, never consumed)
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < WD_DEPTH; ++d)
+        if (kp + d < kp_end) consume(d);  // (uniform)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
+
+    if (do_db) {
+        cs0 += __shfl_xor(cs0, 32, 64);
+        cs1 += __shfl_xor(cs1, 32, 64);
+        if (kh == 0) {
+            if (na < p.N) unsafeAtomicAdd(&p.db[na], cs0);
+            if (na + 32 < p.N) unsafeAtomicAdd(&p.db[na + 32], cs1);
+        }
+    }
+    const int rsub = kh * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = c0 + wn * 64 + j * 32 + col;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + i * 32 + rsub + (e & 3) + 8 * (e >> 2);
+#ifdef WG_PLAIN_STORE  // (timing experiments only, tools/README.md: wrong results)
+                if (n < p.N) p.dw[(size_t)n * p.C + c] = acc[i][j][e];
+#elif defined(WG_NO_STORE)
+                asm volatile("" ::"v"(acc[i][j][e]));
+#else
+                if (n < p.N) unsafeAtomicAdd(&p.dw[(size_t)n * p.C + c], acc[i][j][e]);
+#endif
+            }
+    }
+}
+
 // wd[c][(T-1-t)*Nd + n] = w[n][t*C + c] (0 for n >= N): the data gradient of a stride-1 SAME convolution is the same
 // convolution of dY with the taps flipped and the channel roles swapped.  A transpose per tap: a workgroup moves one
 // 64 (n) x 64 (c) tile through LDS, so that the reads run along c and the writes along n (one element per thread
@@ -567,6 +697,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 }
 
 int g_wgrad_grouped = 1;  // mpsr_debug_set_wgrad_grouped: the XCD-aware workgroup order (A/B)
+// mpsr_debug_set_wgrad_direct: 1x1 layers on pw_wgrad_direct_kernel.  Measured and OFF (r06, tools/wgrad_bench.py [--lds],
+// profiles/r06_wgrad_ab.txt): b3 conv1 198 vs 188 us, conv3 190 vs 181 -- the ring's depth (4 / 8 / 16 pairs) changes
+// nothing, and with loads AND stores knocked out both kernels sit at 158-165 us: the loop is matrix-bound at the
+// clock the board sustains, what a launch pays on top is its fixed ramp-up / drain (~30 us), not LDS staging.
+int g_wgrad_direct = 0;
 int g_wgrad_target = 768;  // one round of the 3 workgroups per CU the kernel's registers allow (measured best)
 
 inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
@@ -642,6 +777,14 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
     p.grouped = g_wgrad_grouped && group_ok && groups >= 8 && tiles > 1;
     p.ngroups = (int)groups;
     if (p.grouped) blocks = (groups + 7) / 8 * 8 * tiles;
+    // 1x1 layers: operands straight from memory into the MFMA's source registers (no wrap-around of its running
+    // 32-bit offsets: the ring reads up to 2 * WD_DEPTH rows past a slice, a slice ends up to 31 rows past M)
+    const long long slack = 2 * WD_DEPTH + WG_K;
+    if (g_wgrad_direct && taps == 1 && (M + slack) * C * 4 < 0xfffffff0LL && (M + slack) * N * 4 < 0xfffffff0LL) {
+        hipLaunchKernelGGL(pw_wgrad_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, mpsr::as_stream(stream), p);
+        MPSR_CHECK_LAUNCH("pw_wgrad_direct_kernel");
+        return MPSR_OK;
+    }
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, mpsr::as_stream(stream), p);
     MPSR_CHECK_LAUNCH("conv_wgrad_kernel");
     return MPSR_OK;
@@ -901,3 +1044,4 @@ extern "C" int mpsr_adam_step_lr_dev(float *param, const float *grad, float *m, 
 
 extern "C" void mpsr_debug_set_wgrad_target(int workgroups) { g_wgrad_target = workgroups; }
 extern "C" void mpsr_debug_set_wgrad_grouped(int on) { g_wgrad_grouped = on; }
+extern "C" void mpsr_debug_set_wgrad_direct(int on) { g_wgrad_direct = on; }

@@ -190,6 +190,38 @@ inline hipError_t zero_pair(double *a, double *b, int C, hipStream_t s)
 
 inline int stream_grid(long long n4) { return (int)((n4 + kThreads - 1) / kThreads < 65536 ? (n4 + kThreads - 1) / kThreads : 65536); }
 
+// The per-channel arithmetic between the two passes of a layer, as ONE launch (r06: it was ~16 ATen launches of 3-5 us
+// on C-sized tensors per layer and step): mean / biased variance from the shifted fp64 sums, the moving statistics'
+// update of the fused TensorFlow kernel (unbiased variance into the average), mean and 1 / sqrt(var + eps) as floats.
+__global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                                   const float *__restrict__ z0, double inv_m, double unbias, double eps, float decay,
+                                   int C, float *__restrict__ moving_mean, float *__restrict__ moving_var,
+                                   float *__restrict__ mean, float *__restrict__ inv_std)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double d = sum[c] * inv_m;
+    const double mu = (double)z0[c] + d;
+    const double var = fmax(sumsq[c] * inv_m - d * d, 0.0);
+    mean[c] = (float)mu;
+    inv_std[c] = (float)(1.0 / sqrt(var + eps));
+    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + (1.f - decay) * (float)mu;
+    if (moving_var) moving_var[c] = moving_var[c] * decay + (1.f - decay) * (float)(var * unbias);
+}
+
+// Between the backward's two passes: the beta gradient into its slot of the flat buffer, the two means as floats.
+__global__ void bn_grad_finalize_kernel(const double *__restrict__ sum_g, const double *__restrict__ sum_gz,
+                                        double inv_count, int C, float *__restrict__ dbeta, float *__restrict__ mean_g,
+                                        float *__restrict__ mean_gz)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += (float)sum_g[c];
+    mean_g[c] = (float)(sum_g[c] * inv_count);
+    mean_gz[c] = (float)(sum_gz[c] * inv_count);
+}
+
+
 }  // namespace
 
 extern "C" int mpsr_batch_norm_stats(const float *z, long long M, int C, double *sum, double *sumsq_shifted,
@@ -246,5 +278,31 @@ extern "C" int mpsr_batch_norm_grad(const float *dy, const float *y, const float
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(kThreads), 0, mpsr::as_stream(stream), dy, y, z,
                        n4, C / 4, mean, inv_std, mean_g, mean_gz, dz);
     MPSR_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_finalize(const double *sum, const double *sumsq_shifted, const float *z_row0, long long M,
+                                        int C, float eps, float decay, float *moving_mean, float *moving_variance,
+                                        float *mean, float *inv_std, mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_finalize", M, C)) return rc;
+    MPSR_REQUIRE(sum && sumsq_shifted && z_row0 && mean && inv_std, "batch_norm_finalize: null pointer");
+    MPSR_REQUIRE(eps >= 0.f && decay >= 0.f && decay <= 1.f, "batch_norm_finalize: eps >= 0 and 0 <= decay <= 1");
+    const double unbias = (double)M / (double)(M > 1 ? M - 1 : 1);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, mpsr::as_stream(stream), sum,
+                       sumsq_shifted, z_row0, 1.0 / (double)M, unbias, (double)eps, decay, C, moving_mean, moving_variance,
+                       mean, inv_std);
+    MPSR_CHECK_LAUNCH("bn_finalize_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_grad_finalize(const double *sum_g, const double *sum_gz, double count, int C, float *dbeta,
+                                             float *mean_g, float *mean_gz, mpsr_stream_t stream)
+{
+    MPSR_REQUIRE(C > 0 && count >= 1.0, "batch_norm_grad_finalize: C > 0 and count >= 1");
+    MPSR_REQUIRE(sum_g && sum_gz && mean_g && mean_gz, "batch_norm_grad_finalize: null pointer");
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, mpsr::as_stream(stream), sum_g, sum_gz,
+                       1.0 / count, C, dbeta, mean_g, mean_gz);
+    MPSR_CHECK_LAUNCH("bn_grad_finalize_kernel");
     return MPSR_OK;
 }

@@ -817,3 +817,78 @@ def test_wgrad_winograd3_domain_vs_direct_and_fp64(B, dil, C, N):
     (y * dy[..., 7:11].double().permute(0, 3, 1, 2)).sum().backward()
     ref = w.grad.permute(0, 2, 3, 1).reshape(4, 9 * C)
     assert (outs[1][0][7:11].double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_batch_norm_finalize_kernels_vs_float64():
+    """mpsr_batch_norm_finalize / _grad_finalize (r06: one launch each for the per-channel arithmetic between the passes)
+    against the same expressions in torch float64, at a decay that makes the moving statistics' update visible; NULL
+    moving statistics / NULL beta gradient leave those alone."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    M, C, eps, decay = 4097, 260, 1e-3, 0.5
+    z = torch.randn((M, C), device="cuda", generator=g) * 3 + 7
+    sums = torch.empty((2, C), dtype=torch.float64, device="cuda")
+    _lib.check(lib.mpsr_batch_norm_stats(_lib.ptr(z), M, C, sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
+    mm0 = torch.randn(C, device="cuda", generator=g)
+    mv0 = torch.rand(C, device="cuda", generator=g) + 0.5
+    mm, mv = mm0.clone(), mv0.clone()
+    out = torch.empty((2, C), device="cuda")
+    _lib.check(lib.mpsr_batch_norm_finalize(sums[0].data_ptr(), sums[1].data_ptr(), _lib.ptr(z), M, C, eps, decay,
+                                            _lib.ptr(mm), _lib.ptr(mv), out[0].data_ptr(), out[1].data_ptr(),
+                                            _lib.stream()))
+    z64 = z.double()
+    mean, var = z64.mean(0), z64.var(0, unbiased=False)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    assert rel(out[0], mean) < 1e-6
+    assert rel(out[1], torch.rsqrt(var + eps)) < 1e-6
+    assert rel(mm, mm0.double() * decay + (1 - decay) * mean) < 1e-6
+    assert rel(mv, mv0.double() * decay + (1 - decay) * var * M / (M - 1)) < 1e-6
+    out2 = torch.empty((2, C), device="cuda")
+    _lib.check(lib.mpsr_batch_norm_finalize(sums[0].data_ptr(), sums[1].data_ptr(), _lib.ptr(z), M, C, eps, decay,
+                                            None, None, out2[0].data_ptr(), out2[1].data_ptr(), _lib.stream()))
+    assert torch.equal(out, out2)
+    # backward side
+    sg = torch.randn((2, C), dtype=torch.float64, device="cuda", generator=g) * 100
+    db0 = torch.randn(C, device="cuda", generator=g)
+    db = db0.clone()
+    means = torch.empty((2, C), device="cuda")
+    _lib.check(lib.mpsr_batch_norm_grad_finalize(sg[0].data_ptr(), sg[1].data_ptr(), float(M), C, _lib.ptr(db),
+                                                 means[0].data_ptr(), means[1].data_ptr(), _lib.stream()))
+    assert torch.equal(db, db0 + sg[0].float())
+    assert rel(means, sg / M) < 2e-7
+    assert lib.mpsr_batch_norm_grad_finalize(sg[0].data_ptr(), sg[1].data_ptr(), 0.0, C, None, means[0].data_ptr(),
+                                             means[1].data_ptr(), _lib.stream()) != 0
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 132, 68), (2, 12, 12, 256, 1024), (64, 12, 12, 1024, 256), (5, 1, 1, 520, 36),
+                                   (1, 3, 3, 4, 4)])
+def test_pointwise_wgrad_direct_kernel_vs_float64_and_the_lds_kernel(shape):
+    """pw_wgrad_direct_kernel (r06: 1x1 weight gradients with the operands loaded straight into the MFMA's source
+    registers, no LDS) against float64 and against conv_wgrad_kernel on the same inputs: ragged tiles (N, C not multiples
+    of 128 / 64 / 32), pixel counts that are not multiples of the 32-row step or of the ring depth, slices shorter than the
+    ring, weight AND bias gradient, accumulation into a non-zero buffer."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    B, H, Wd, C, N = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + C)
+    x = torch.randn((B, H, Wd, C), device="cuda", generator=g)
+    dy = torch.randn((B, H, Wd, N), device="cuda", generator=g)
+    dw0 = torch.randn((N, C), device="cuda", generator=g)
+    db0 = torch.randn((N,), device="cuda", generator=g)
+    want_w = dw0.double() + dy.reshape(-1, N).double().t() @ x.reshape(-1, C).double()
+    want_b = db0.double() + dy.reshape(-1, N).double().sum(0)
+    got = {}
+    try:
+        for direct in (1, 0):
+            lib.mpsr_debug_set_wgrad_direct(direct)
+            dw, db = dw0.clone(), db0.clone()
+            _lib.check(lib.mpsr_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(dy), B, H, Wd, C, N, 1, 1, 1, _lib.ptr(dw),
+                                                 _lib.ptr(db), _lib.stream()))
+            got[direct] = (dw, db)
+            scale_w, scale_b = float(want_w.abs().max()), float(want_b.abs().max())
+            assert float((dw.double() - want_w).abs().max()) < 2e-6 * scale_w * max(1.0, (B * H * Wd) ** 0.5 / 16), direct
+            assert float((db.double() - want_b).abs().max()) < 2e-6 * scale_b * max(1.0, (B * H * Wd) ** 0.5 / 16), direct
+    finally:
+        lib.mpsr_debug_set_wgrad_direct(0)
+    assert float((got[1][0] - got[0][0]).abs().max()) < 1e-5 * float(want_w.abs().max())

@@ -281,3 +281,51 @@ def test_save_restore_step_keeps_the_schedule_and_the_moving_average():
         assert tr.optimizer.shadow is None
         float(tr.step(data[1]))
         assert tr.optimizer.shadow is not None
+
+
+def test_weight_gradients_on_the_side_stream_are_complete_when_backward_returns():
+    """r06: weight gradients run on a second HIP stream (autograd_ops._deposit_weight_grad).  The flat gradient buffer
+    must be complete on the CALLER'S stream the moment backward() returns -- the end-of-pass callback joins the side
+    stream -- so a reduction enqueued right behind backward() (no host synchronisation in between) sees every launch:
+    its sum equals the sum taken after a device-wide synchronisation, and the gradients equal the ones computed with every
+    launch on the main stream (up to the order of the kernels' atomics)."""
+    from monopsr_amd.core import autograd_ops as ops
+    from monopsr_amd.core import config_utils, train_net, trainer
+    from monopsr_amd.core import weights as W
+    B, div = 8, 4
+    cfg = config_utils.default_config()
+    weights = W.synthetic_weights(seed=131, width_div=div)
+    rng = np.random.default_rng(132)
+    y1, x1 = rng.uniform(100, 200, B), rng.uniform(100, 900, B)
+    boxes = np.stack([y1, x1, y1 + rng.uniform(40, 120, B), x1 + rng.uniform(60, 200, B)], 1).astype(np.float32)
+    sample = dict(rgb_image_crops=_dev((rng.standard_normal((B, 48, 48, 3)) * 50).astype(np.float32)),
+                  full_img_feature_crop=_dev(np.maximum(rng.standard_normal((B, 12, 12, 1024 // div)), 0).astype(np.float32)),
+                  boxes_2d=_dev(boxes),
+                  cam_p=_dev(np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.003]], np.float32)),
+                  est_view_angs=_dev(rng.uniform(-0.5, 0.5, B).astype(np.float32)),
+                  class_indices=torch.ones((B, 1), dtype=torch.int32, device="cuda"),
+                  mean_lwh=_dev(np.tile(np.array([[3.88, 1.63, 1.53]], np.float32), (B, 1))),
+                  prop_cen_z_offset=torch.full((B,), 2.178, device="cuda"))
+    sample.update(trainer.synthetic_ground_truth(sample, seed=133))
+    grads = {}
+    assert ops.WGRAD_SIDE_STREAM
+    try:
+        for side in (True, False):
+            ops.WGRAD_SIDE_STREAM = side
+            net = train_net.TrainNet(weights, width_div=div, decoder_bn='batch')
+            tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, lr=1e-4)
+            for _ in range(3):  # (repeated: a missing join shows as a sum that changes after the synchronisation)
+                net.zero_grad()
+                _, total = tr.loss(tr.forward(sample), sample)
+                total.backward()
+                early = net.grads.double().abs().sum()  # enqueued on the caller's stream, no host sync before it
+                assert not ops._JOIN_QUEUED
+                torch.cuda.synchronize()
+                late = net.grads.double().abs().sum()
+                assert float(early) == float(late)
+            grads[side] = net.grads.clone()
+    finally:
+        ops.WGRAD_SIDE_STREAM = True
+    assert any(ops._WGRAD_STREAMS.values())
+    scale = float(grads[False].abs().max())
+    assert float((grads[True] - grads[False]).abs().max()) < 2e-5 * scale

@@ -33,31 +33,50 @@ def main():
     for _ in range(3):
         tr.step(sample)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    # which source line asked for each operator: a dispatch mode sees every ATen call of the step (forward, and the
+    # backward's calls under the autograd engine's own thread are attributed to the backward formula's node instead)
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    calls = collections.Counter()
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            site = "(autograd engine)"
+            for fr in reversed(traceback.extract_stack()):
+                if fr.filename.startswith(os.path.join(root, "monopsr_amd")):
+                    site = "%s:%d %s" % (os.path.relpath(fr.filename, root), fr.lineno, fr.name)
+                    break
+            calls[(site, str(func))] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Census():
         tr.step(sample)
         torch.cuda.synchronize()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    skip = ("aten.view", "aten._unsafe_view", "aten.t.", "aten.transpose", "aten.expand", "aten.slice", "aten.select",
+            "aten.unsqueeze", "aten.squeeze", "aten.detach", "aten.alias", "aten.as_strided", "aten.permute",
+            "aten.empty", "aten.reshape", "aten.unbind", "aten.split", "aten._local_scalar_dense", "aten.is_", "aten.sym_",
+            "aten.lift_fresh", "aten.new_empty", "aten.narrow", "aten.unfold", "aten.stride", "aten.size")
     by_site = collections.Counter()
+    for (site, op), n in calls.items():
+        if not op.startswith(skip):
+            by_site[site] += n
+    print("ATen calls that launch, by source line (views and allocations left out): total", sum(by_site.values()))
+    for site, n in by_site.most_common(args.top):
+        ops = collections.Counter({op: k for (s_, op), k in calls.items() if s_ == site and not op.startswith(skip)})
+        print("%4d  %-70s %s" % (n, site, ", ".join("%s x%d" % (o.replace("aten.", ""), k) for o, k in ops.most_common(6))))
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        tr.step(sample)
+        torch.cuda.synchronize()
     by_op = collections.Counter()
+    t_op = collections.Counter()
     for ev in prof.events():
-        if not ev.name.startswith("aten::"):
+        if not ev.name.startswith("aten::") or any(c.name.startswith("aten::") for c in ev.cpu_children) or not ev.kernels:
             continue
-        # leaf ATen ops that launched something
-        if any(c.name.startswith("aten::") for c in ev.cpu_children):
-            continue
-        if not ev.kernels:
-            continue
-        site = "?"
-        for fr in ev.stack or []:
-            if "monopsr_amd/" in fr and "site-packages" not in fr and "dist-packages" not in fr:
-                site = fr[fr.index("monopsr_amd/"):].split(",")[0].strip()
-                break
-        by_site[(site, ev.name)] += len(ev.kernels)
         by_op[ev.name] += len(ev.kernels)
-    print("launches by ATen operator:", dict(by_op.most_common(25)))
-    print("total ATen launches in the step:", sum(by_op.values()))
-    for (site, op), n in by_site.most_common(args.top):
-        print("%4d  %-28s %s" % (n, op, site))
+        t_op[ev.name] += sum(k.duration for k in ev.kernels)
+    print("launches by ATen operator (device us):", {k: (n, round(t_op[k], 1)) for k, n in by_op.most_common(25)})
+    print("total ATen launches in the step: %d, %.1f us on the device" % (sum(by_op.values()), sum(t_op.values())))
 
 
 if __name__ == "__main__":

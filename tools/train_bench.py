@@ -46,6 +46,11 @@ def main():
                          "layer), 1 = all layers by one launch per step (autograd_ops.DgradBank)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
+    ap.add_argument("--wgrad-main-stream", action="store_true",
+                    help="A/B: weight gradients on the main stream (autograd_ops.WGRAD_SIDE_STREAM = False)")
+    ap.add_argument("--wgrad-streams", type=int, default=1, help="A/B: side streams the weight gradients rotate over")
+    ap.add_argument("--wgrad-direct", action="store_true",
+                    help="A/B: 1x1 weight gradients on the LDS-free kernel (mpsr_debug_set_wgrad_direct(1))")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +66,11 @@ def main():
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
     _lib.lib().mpsr_debug_set_wgrad_winograd(args.wgrad_winograd)
+    _lib.lib().mpsr_debug_set_wgrad_direct(1 if args.wgrad_direct else 0)
+    from monopsr_amd.core import autograd_ops
+    autograd_ops.WGRAD_SIDE_STREAMS = args.wgrad_streams
+    if args.wgrad_main_stream:
+        autograd_ops.WGRAD_SIDE_STREAM = False
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn, dgrad_bank=bool(args.dgrad_bank))

@@ -35,11 +35,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--target", type=int, default=0, help="debug: workgroups per launch the pixel slicing aims at")
     ap.add_argument("--ungrouped", action="store_true", help="A/B: the workgroup order that ignores the XCDs")
+    ap.add_argument("--direct", action="store_true", help="A/B: 1x1 layers on pw_wgrad_direct_kernel (operands straight "
+                                                          "into the MFMA's source registers) instead of the LDS-staged kernel")
     args = ap.parse_args()
     B = args.batch
     lib = _lib.lib()
     if args.target:
         lib.mpsr_debug_set_wgrad_target(args.target)
+    lib.mpsr_debug_set_wgrad_direct(1 if args.direct else 0)
     if args.ungrouped:
         lib.mpsr_debug_set_wgrad_grouped(0)
     total = 0.0
