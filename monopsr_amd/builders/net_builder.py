@@ -50,10 +50,14 @@ def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_
             large = crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
             return max_pool(large, 2, 2, "VALID")
 
-        if hasattr(net, 'side_stream') and torch.cuda.is_available():
-            # Inference: the two trunks are independent and, at one image / a few dozen boxes, each leaves most
-            # CUs idle (M = 6080 and 32*144 rows) -- run the full-image branch on a second HIP stream next to the
-            # crop trunk.  (A trainable net keeps one stream: autograd replays the graph serially anyway.)
+        # (a trainable net: only while the crop trunk alone leaves CUs idle -- measured, r06: 26.6 vs 27.4 ms per training
+        # step at 32 boxes, 62.0 vs 61.4 at 256, where three streams compete for a chip the crop trunk already fills)
+        few_enough = crop_img.shape[0] <= getattr(net, 'side_stream_max_boxes', 1 << 30)
+        if hasattr(net, 'side_stream') and few_enough and torch.cuda.is_available():
+            # The two trunks are independent and, at one image / a few dozen boxes, each leaves most CUs idle
+            # (M = 6080 and 32*144 rows) -- run the full-image branch on a second HIP stream next to the crop
+            # trunk.  (A trainable net with both trunks does the same since r06: autograd runs a node's backward on
+            # the stream of its forward, so the backward passes of the two trunks overlap too.)
             if net.side_stream is None:
                 net.side_stream = torch.cuda.Stream(device=crop_img.device)
             main = torch.cuda.current_stream()

@@ -126,6 +126,8 @@ WGRAD_SIDE_STREAMS = 1  # how many side streams the launches rotate over
 _WGRAD_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
 _WGRAD_NEXT = {}      # device index -> launches so far (the rotation)
 _JOIN_QUEUED = set()  # device indices whose end-of-backward join is queued in the running pass
+_PASS_STREAMS = {}    # device index -> {stream id: stream} the running pass's deposits were launched FROM (a TrainNet with
+#                       both trunks runs the full-image trunk, forward and therefore backward, on its own stream)
 
 
 def _wgrad_stream(device):
@@ -144,19 +146,24 @@ def join_wgrad_stream(device=None):
     bucket, and by anyone who reads the flat gradient buffer from inside a backward pass."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     _JOIN_QUEUED.discard(idx)
-    for s in _WGRAD_STREAMS.get(idx, ()):
-        torch.cuda.current_stream(idx).wait_stream(s)
+    cur = torch.cuda.current_stream(idx)
+    for s in list(_PASS_STREAMS.pop(idx, {}).values()) + list(_WGRAD_STREAMS.get(idx, ())):
+        if s.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(s)
 
 
 def _deposit_weight_grad(L, x, g):
     """dW (and db) of one layer from its input x and the gradient g at its pre-activation output, accumulated into the
     layer's slices of the flat gradient buffer; then the layer's `on_grad_ready` hook (the data-parallel reducer)."""
-    if WGRAD_SIDE_STREAM and x.is_cuda:
+    if x.is_cuda:
         dev = x.device
-        main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        _PASS_STREAMS.setdefault(dev.index, {})[main.cuda_stream] = main
         if dev.index not in _JOIN_QUEUED:
             _JOIN_QUEUED.add(dev.index)
             torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(dev))
+    if WGRAD_SIDE_STREAM and x.is_cuda:
+        side = _wgrad_stream(dev)
         side.wait_stream(main)  # x, g (and the step's zeroed gradient buffer) are ready on the main stream here
         with torch.cuda.stream(side):
             _launch_weight_grad(L, x, g)

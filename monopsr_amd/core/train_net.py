@@ -42,6 +42,12 @@ class TrainNet:
             raise ValueError("decoder_bn must be 'frozen', 'batch' or 'batch_global'")
         self.decoder_bn = decoder_bn
         self.device = torch.device(device)
+        if full_trunk and self.two_stream_trunks:
+            # builders/net_builder.py runs the full-image branch on this stream next to the crop trunk (created on first
+            # use).  Autograd runs a node's backward on the stream of its forward, so the two trunks' backward passes
+            # overlap as well; their deposits are joined at the end of the pass (autograd_ops.join_wgrad_stream).
+            self.side_stream = None
+            self.side_stream_max_boxes = 64
         parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
         fc_names = [n for n, _, _, _ in W.head_fc_specs()] if with_heads else []
         blobs, recs, base = [], [], 0
@@ -117,6 +123,8 @@ class TrainNet:
                                                   if decoder_bn == 'batch_global' else None)
 
     # ------------------------------------------------------------------ forward pieces
+    # full_trunk: the full-image trunk (6080 pixel rows: <= 190 tiles for 256 CUs) on its own stream at up to 64 boxes
+    two_stream_trunks = True
     fused_units = True  # trunk(): bottleneck units as single autograd nodes (ops.BottleneckFn); False = layer by layer
     linked_units = True  # ... and chained: a unit's input gradient leaves through the previous unit's ReLU mask
     fused_upsampled_convs = True  # squash_decoder(): resize -> conv pairs as one tap-GEMM operator, forward and backward

@@ -46,6 +46,8 @@ def main():
                          "layer), 1 = all layers by one launch per step (autograd_ops.DgradBank)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
+    ap.add_argument("--one-stream-trunks", action="store_true",
+                    help="A/B with --full-image: both trunks on one stream (TrainNet.two_stream_trunks = False)")
     ap.add_argument("--wgrad-main-stream", action="store_true",
                     help="A/B: weight gradients on the main stream (autograd_ops.WGRAD_SIDE_STREAM = False)")
     ap.add_argument("--wgrad-streams", type=int, default=1, help="A/B: side streams the weight gradients rotate over")
@@ -71,6 +73,8 @@ def main():
     autograd_ops.WGRAD_SIDE_STREAMS = args.wgrad_streams
     if args.wgrad_main_stream:
         autograd_ops.WGRAD_SIDE_STREAM = False
+    if args.one_stream_trunks:
+        train_net.TrainNet.two_stream_trunks = False
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn, dgrad_bank=bool(args.dgrad_bank))
