@@ -144,7 +144,9 @@ def join_wgrad_stream(device=None):
     """Make the current stream wait for every weight gradient launched on the side stream so far (no-op when the side
     stream was never used).  Called by the backward pass's own end-of-pass callback, by the reducer before it issues a
     bucket, and by anyone who reads the flat gradient buffer from inside a backward pass."""
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = None if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
     _JOIN_QUEUED.discard(idx)
     cur = torch.cuda.current_stream(idx)
     for s in list(_PASS_STREAMS.pop(idx, {}).values()) + list(_WGRAD_STREAMS.get(idx, ())):
@@ -159,9 +161,13 @@ def _deposit_weight_grad(L, x, g):
         dev = x.device
         main = torch.cuda.current_stream(dev)
         _PASS_STREAMS.setdefault(dev.index, {})[main.cuda_stream] = main
+        in_pass = True
         if dev.index not in _JOIN_QUEUED:
-            _JOIN_QUEUED.add(dev.index)
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(dev))
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(dev))
+                _JOIN_QUEUED.add(dev.index)
+            except RuntimeError:  # not inside a backward pass (a backward formula called by hand): join right away
+                in_pass = False
     if WGRAD_SIDE_STREAM and x.is_cuda:
         side = _wgrad_stream(dev)
         side.wait_stream(main)  # x, g (and the step's zeroed gradient buffer) are ready on the main stream here
@@ -169,6 +175,8 @@ def _deposit_weight_grad(L, x, g):
             _launch_weight_grad(L, x, g)
         x.record_stream(side)
         g.record_stream(side)
+        if not in_pass:
+            join_wgrad_stream(dev)
     else:
         _launch_weight_grad(L, x, g)
     ready = getattr(L, "on_grad_ready", None)

@@ -267,6 +267,10 @@ class TrainNet:
 
     # ------------------------------------------------------------------ optimisation
     def zero_grad(self):
+        # (whatever an earlier backward pass left on the weight-gradient stream is ordered in front of the zeroing, and a
+        # pass that ended in an exception cannot leave its end-of-pass join marked as queued)
+        if self.grads.is_cuda:
+            ops.join_wgrad_stream(self.device)
         self.grads.zero_()
 
     @staticmethod
