@@ -44,3 +44,9 @@ timeout 200 python3 tools/emd_time.py > $OUT/${TAG}_emd_level_culling.txt 2> $OU
 timeout 300 python3 -m pytest tests/test_hostile_inputs_gpu.py -s -q > $OUT/${TAG}_hostile_inputs.txt 2>&1 || echo "hostile inputs run failed"
 # the default bench command, untraced, on the same box as everything above (profiles/<tag>_bench_default_run.json)
 timeout 600 python3 bench.py > $OUT/${TAG}_bench_default_run.json 2> $OUT/default.err || echo "default bench failed"
+# r06 (late): the training step with its weight gradients on the second stream (default) and on the main stream, the
+# both-trunk step, and the framework launches of a step by source line
+{ for V in "" "--wgrad-main-stream" "" "--wgrad-main-stream" "--full-image" "--full-image --batch 32"; do
+    echo "== train_bench.py --steps 10 --warmup 3 $V"; timeout 300 python3 tools/train_bench.py --steps 10 --warmup 3 $V 2>/dev/null | cut -c1-260
+  done; } > $OUT/${TAG}_train_streams_ab.txt
+timeout 300 python3 tools/aten_census.py --top 60 > $OUT/${TAG}_aten_census.txt 2> $OUT/census.err || echo "census failed"
