@@ -401,6 +401,15 @@ int mpsr_batch_norm_grad(const float *dy, const float *y, const float *z, long l
                          const float *inv_std, const float *mean_g, const float *mean_gz, float *dz,
                          mpsr_stream_t stream);
 
+/* ABI 6: the same two passes for a layer with ReLU WITHOUT reading y: the mask y > 0 is rebuilt from z as
+ * relu((z - mean) * inv_std + beta) > 0 with mpsr_batch_norm_apply's own fused multiply-add (the same bits), which takes
+ * one of the three (four) tensor-sized streams out of each pass. */
+int mpsr_batch_norm_grad_sums_z(const float *dy, const float *z, long long M, int C, const float *mean,
+                                const float *inv_std, const float *beta, double *sum_g, double *sum_gz,
+                                mpsr_stream_t stream);
+int mpsr_batch_norm_grad_z(const float *dy, const float *z, long long M, int C, const float *mean, const float *inv_std,
+                           const float *beta, const float *mean_g, const float *mean_gz, float *dz, mpsr_stream_t stream);
+
 /* tf.clip_by_norm applied to every variable of a flat gradient buffer separately, as
  * slim.learning.create_train_op(clip_gradient_norm=1.0) does (core/trainer.py:78-81): g *= clip / max(||g||, clip).
  * The caller describes the variables once as a chunk table (device arrays): chunk i covers

@@ -131,6 +131,8 @@ SIGNATURES = {
     "mpsr_batch_norm_grad_finalize": (c_i, [c_f, c_f, ctypes.c_double, c_i, c_f, c_f, c_f, c_f]),
     "mpsr_batch_norm_apply": (c_i, [c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_i, c_f, c_f]),
     "mpsr_batch_norm_grad_sums": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_batch_norm_grad_sums_z": (c_i, [c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "mpsr_batch_norm_grad_z": (c_i, [c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_batch_norm_grad": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mpsr_clip_by_norm_segments": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, ctypes.c_size_t, c_i, ctypes.c_float, c_f]),
     "mpsr_clip_adam_ema_step": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, ctypes.c_size_t, c_i, ctypes.c_float,

@@ -507,6 +507,9 @@ class ResizeBilinearFn(torch.autograd.Function):
         return dx, None, None
 
 
+BN_MASK_FROM_Z = True  # A/B switch (tools/train_bench.py --bn-mask-from-y): BatchNorm's backward rebuilds the ReLU mask from z
+
+
 class BatchNormReluFn(torch.autograd.Function):
     """y = relu((z - mean) / sqrt(var + eps) + beta) with BATCH statistics over (N, H, W) (slim.batch_norm,
     is_training=True, scale=False, net_builder.py:76-87); updates the layer's moving statistics like the fused
@@ -564,8 +567,17 @@ class BatchNormReluFn(torch.autograd.Function):
         M = z.numel() // C
         lib = _lib.lib()
         sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
-        _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
-                                                 _lib.ptr(inv), sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
+        # with ReLU: the mask y > 0 is rebuilt from z inside both passes (the forward's own fused multiply-add, same
+        # bits) instead of streaming y through them -- 2 of the 7 tensor-sized streams of a layer's backward less
+        from_z = L.relu and BN_MASK_FROM_Z
+        if from_z:
+            _lib.check(lib.mpsr_batch_norm_grad_sums_z(_lib.ptr(dy), _lib.ptr(z), M, C, _lib.ptr(mean32), _lib.ptr(inv),
+                                                       _lib.ptr(L.b), sums[0].data_ptr(), sums[1].data_ptr(),
+                                                       _lib.stream()))
+        else:
+            _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
+                                                     _lib.ptr(inv), sums[0].data_ptr(), sums[1].data_ptr(),
+                                                     _lib.stream()))
         # d(beta) is this rank's share (the gradient all-reduce pools it like every other parameter's); the two means of
         # the normalisation's backward are over the rows the statistics came from
         if L.batch_norm._group() is None:
@@ -578,9 +590,14 @@ class BatchNormReluFn(torch.autograd.Function):
             L.batch_norm.all_reduce_sums(sums)
             means = (sums / ctx.count).float().contiguous()
         dz = torch.empty_like(z)
-        _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
-                                            _lib.ptr(inv), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
-                                            _lib.stream()))
+        if from_z:
+            _lib.check(lib.mpsr_batch_norm_grad_z(_lib.ptr(dy), _lib.ptr(z), M, C, _lib.ptr(mean32), _lib.ptr(inv),
+                                                  _lib.ptr(L.b), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
+                                                  _lib.stream()))
+        else:
+            _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, _lib.ptr(mean32),
+                                                _lib.ptr(inv), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
+                                                _lib.stream()))
         return dz, None, None
 
 

@@ -85,8 +85,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restr
         const float4 v = reinterpret_cast<const float4 *>(z)[i];
         const float4 mu = reinterpret_cast<const float4 *>(mean)[cg], is = reinterpret_cast<const float4 *>(inv_std)[cg],
                      be = reinterpret_cast<const float4 *>(beta)[cg];
-        float4 o = make_float4((v.x - mu.x) * is.x + be.x, (v.y - mu.y) * is.y + be.y, (v.z - mu.z) * is.z + be.z,
-                               (v.w - mu.w) * is.w + be.w);
+        // (one fused multiply-add per element, spelled out: the backward kernels recompute exactly this value to rebuild
+        // the ReLU mask from z when they are not given y)
+        float4 o = make_float4(__fmaf_rn(v.x - mu.x, is.x, be.x), __fmaf_rn(v.y - mu.y, is.y, be.y),
+                               __fmaf_rn(v.z - mu.z, is.z, be.z), __fmaf_rn(v.w - mu.w, is.w, be.w));
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
         reinterpret_cast<float4 *>(y)[i] = o;
     }
@@ -99,17 +101,25 @@ __global__ __launch_bounds__(kRThreads) void bn_bwd_reduce_kernel(const float *_
                                                                  long long rows_per_block,
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ inv_std,
+                                                                 const float *__restrict__ beta,
                                                                  double *__restrict__ sum_g, double *__restrict__ sum_gz)
 {
+    // the ReLU mask: from y when given; else, with beta, recomputed from z as bn_apply_kernel computed y (r06: one of the
+    // three 300 MB streams of the pass less); else none
     const RowMap m(C);
     const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     if (m.r0 < m.rstride) {
         const float4 mu = reinterpret_cast<const float4 *>(mean)[m.cg], is = reinterpret_cast<const float4 *>(inv_std)[m.cg];
+        const float4 be = (!y && beta) ? reinterpret_cast<const float4 *>(beta)[m.cg] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 *gp = reinterpret_cast<const float4 *>(dy), *yp = reinterpret_cast<const float4 *>(y),
                      *zp = reinterpret_cast<const float4 *>(z);
+        const bool masked = y || beta;
         auto acc = [&](float4 g, float4 a, float4 v) __attribute__((always_inline)) {
-            if (y) {
+            if (!y && beta)
+                a = make_float4(__fmaf_rn(v.x - mu.x, is.x, be.x), __fmaf_rn(v.y - mu.y, is.y, be.y),
+                                __fmaf_rn(v.z - mu.z, is.z, be.z), __fmaf_rn(v.w - mu.w, is.w, be.w));
+            if (masked) {
                 g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
                 g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
             }
@@ -146,19 +156,26 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ inv_std,
                                                                 const float *__restrict__ mean_g,
                                                                 const float *__restrict__ mean_gz,
-                                                                float *__restrict__ dz)
+                                                                const float *__restrict__ beta, float *__restrict__ dz)
 {
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
         const int cg = (int)(i % groups);
         float4 g = reinterpret_cast<const float4 *>(dy)[i];
-        if (y) {
-            const float4 a = reinterpret_cast<const float4 *>(y)[i];
-            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
-            g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
-        }
         const float4 v = reinterpret_cast<const float4 *>(z)[i];
         const float4 mu = reinterpret_cast<const float4 *>(mean)[cg], is = reinterpret_cast<const float4 *>(inv_std)[cg],
                      mg = reinterpret_cast<const float4 *>(mean_g)[cg], mz = reinterpret_cast<const float4 *>(mean_gz)[cg];
+        if (y || beta) {
+            float4 a;
+            if (y) {
+                a = reinterpret_cast<const float4 *>(y)[i];
+            } else {  // the mask recomputed from z, as bn_apply_kernel computed y
+                const float4 be = reinterpret_cast<const float4 *>(beta)[cg];
+                a = make_float4(__fmaf_rn(v.x - mu.x, is.x, be.x), __fmaf_rn(v.y - mu.y, is.y, be.y),
+                                __fmaf_rn(v.z - mu.z, is.z, be.z), __fmaf_rn(v.w - mu.w, is.w, be.w));
+            }
+            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
+            g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+        }
         reinterpret_cast<float4 *>(dz)[i] =
             make_float4(is.x * (g.x - mg.x - (v.x - mu.x) * is.x * mz.x), is.y * (g.y - mg.y - (v.y - mu.y) * is.y * mz.y),
                         is.z * (g.z - mg.z - (v.z - mu.z) * is.z * mz.z), is.w * (g.w - mg.w - (v.w - mu.w) * is.w * mz.w));
@@ -263,7 +280,7 @@ extern "C" int mpsr_batch_norm_grad_sums(const float *dy, const float *y, const 
     long long rows;
     slicing(M, blocks, rows);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kRThreads), 0, s, dy, y, z, M, C, rows, mean, inv_std,
-                       sum_g, sum_gz);
+                       (const float *)nullptr, sum_g, sum_gz);
     MPSR_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return MPSR_OK;
 }
@@ -276,7 +293,7 @@ extern "C" int mpsr_batch_norm_grad(const float *dy, const float *y, const float
     MPSR_REQUIRE(dy && z && mean && inv_std && mean_g && mean_gz && dz, "batch_norm_grad: null pointer");
     const long long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(kThreads), 0, mpsr::as_stream(stream), dy, y, z,
-                       n4, C / 4, mean, inv_std, mean_g, mean_gz, dz);
+                       n4, C / 4, mean, inv_std, mean_g, mean_gz, (const float *)nullptr, dz);
     MPSR_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return MPSR_OK;
 }
@@ -304,5 +321,37 @@ extern "C" int mpsr_batch_norm_grad_finalize(const double *sum_g, const double *
     hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, mpsr::as_stream(stream), sum_g, sum_gz,
                        1.0 / count, C, dbeta, mean_g, mean_gz);
     MPSR_CHECK_LAUNCH("bn_grad_finalize_kernel");
+    return MPSR_OK;
+}
+
+// The two backward passes with the ReLU mask REBUILT from z (y is not read: relu((z - mean) * inv_std + beta) > 0 is
+// recomputed with bn_apply_kernel's own fused multiply-add, so the mask is the one y > 0 gives, bit for bit).
+extern "C" int mpsr_batch_norm_grad_sums_z(const float *dy, const float *z, long long M, int C, const float *mean,
+                                           const float *inv_std, const float *beta, double *sum_g, double *sum_gz,
+                                           mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_grad_sums_z", M, C)) return rc;
+    MPSR_REQUIRE(dy && z && mean && inv_std && beta && sum_g && sum_gz, "batch_norm_grad_sums_z: null pointer");
+    hipStream_t s = mpsr::as_stream(stream);
+    MPSR_CHECK_HIP(zero_pair(sum_g, sum_gz, C, s));
+    int blocks;
+    long long rows;
+    slicing(M, blocks, rows);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kRThreads), 0, s, dy, (const float *)nullptr, z, M, C, rows,
+                       mean, inv_std, beta, sum_g, sum_gz);
+    MPSR_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return MPSR_OK;
+}
+
+extern "C" int mpsr_batch_norm_grad_z(const float *dy, const float *z, long long M, int C, const float *mean,
+                                      const float *inv_std, const float *beta, const float *mean_g, const float *mean_gz,
+                                      float *dz, mpsr_stream_t stream)
+{
+    if (int rc = check_mc("batch_norm_grad_z", M, C)) return rc;
+    MPSR_REQUIRE(dy && z && mean && inv_std && beta && mean_g && mean_gz && dz, "batch_norm_grad_z: null pointer");
+    const long long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(kThreads), 0, mpsr::as_stream(stream), dy,
+                       (const float *)nullptr, z, n4, C / 4, mean, inv_std, mean_g, mean_gz, beta, dz);
+    MPSR_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return MPSR_OK;
 }

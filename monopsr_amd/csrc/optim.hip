@@ -22,7 +22,17 @@ __global__ __launch_bounds__(kThreads) void seg_sumsq_kernel(const float *__rest
     const float *p = g + chunk_begin[c];
     const int n = chunk_len[c];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += kThreads) s += p[i] * p[i];
+    if ((((uintptr_t)p) & 15) == 0) {  // 16-byte loads (every tensor of the flat buffer is 256-byte aligned, chunks 64 KiB)
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += kThreads) {
+            const float4 v = p4[i];
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += kThreads) s += p[i] * p[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += kThreads) s += p[i] * p[i];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = s;

@@ -892,3 +892,65 @@ def test_pointwise_wgrad_direct_kernel_vs_float64_and_the_lds_kernel(shape):
     finally:
         lib.mpsr_debug_set_wgrad_direct(0)
     assert float((got[1][0] - got[0][0]).abs().max()) < 1e-5 * float(want_w.abs().max())
+
+
+@pytest.mark.parametrize("M,C", [(4097, 260), (256 * 24 * 24, 256), (33, 8)])
+def test_batch_norm_backward_with_the_mask_rebuilt_from_z_is_bit_identical(M, C):
+    """mpsr_batch_norm_grad_sums_z / _grad_z (r06: the ReLU mask recomputed from z with the forward's own fused
+    multiply-add, y not read) == the passes that read y, bit for bit, on the y mpsr_batch_norm_apply produced -- including
+    channels whose pre-activation sits at the rounding edge of zero."""
+    from monopsr_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    z = torch.randn((M, C), device="cuda", generator=g) * 2 + 1
+    dy = torch.randn((M, C), device="cuda", generator=g)
+    sums = torch.empty((2, C), dtype=torch.float64, device="cuda")
+    _lib.check(lib.mpsr_batch_norm_stats(_lib.ptr(z), M, C, sums[0].data_ptr(), sums[1].data_ptr(), _lib.stream()))
+    st = torch.empty((2, C), device="cuda")
+    _lib.check(lib.mpsr_batch_norm_finalize(sums[0].data_ptr(), sums[1].data_ptr(), _lib.ptr(z), M, C, 1e-3, 0.999, None,
+                                            None, st[0].data_ptr(), st[1].data_ptr(), _lib.stream()))
+    beta = torch.randn(C, device="cuda", generator=g) * 0.5
+    # put many elements exactly AT the edge: z = mean - beta / inv_std gives a pre-activation of ~0
+    edge = (st[0] - beta / st[1])
+    z[::7] = edge
+    z[3::11] = edge * (1 + 1e-7)
+    y = torch.empty_like(z)
+    _lib.check(lib.mpsr_batch_norm_apply(_lib.ptr(z), M, C, st[0].data_ptr(), st[1].data_ptr(), _lib.ptr(beta), 1,
+                                         _lib.ptr(y), _lib.stream()))
+    assert 0.2 < float((y > 0).float().mean()) < 0.9
+    out = {}
+    for mode in ("y", "z"):
+        s2 = torch.empty((2, C), dtype=torch.float64, device="cuda")
+        if mode == "y":
+            _lib.check(lib.mpsr_batch_norm_grad_sums(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, st[0].data_ptr(),
+                                                     st[1].data_ptr(), s2[0].data_ptr(), s2[1].data_ptr(), _lib.stream()))
+        else:
+            _lib.check(lib.mpsr_batch_norm_grad_sums_z(_lib.ptr(dy), _lib.ptr(z), M, C, st[0].data_ptr(), st[1].data_ptr(),
+                                                       _lib.ptr(beta), s2[0].data_ptr(), s2[1].data_ptr(), _lib.stream()))
+        means = (s2 / M).float().contiguous()
+        dz = torch.empty_like(z)
+        if mode == "y":
+            _lib.check(lib.mpsr_batch_norm_grad(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z), M, C, st[0].data_ptr(),
+                                                st[1].data_ptr(), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
+                                                _lib.stream()))
+        else:
+            _lib.check(lib.mpsr_batch_norm_grad_z(_lib.ptr(dy), _lib.ptr(z), M, C, st[0].data_ptr(), st[1].data_ptr(),
+                                                  _lib.ptr(beta), means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz),
+                                                  _lib.stream()))
+        out[mode] = (s2, dz)
+    # the masks are the same bits; the fp64 column sums are combined with atomics (order), so they agree to rounding
+    assert float(((out["y"][0] - out["z"][0]).abs() / (out["y"][0].abs() + 1e-9)).max()) < 1e-12
+    mask = (y > 0)
+    gz = torch.where(mask, dy, torch.zeros_like(dy))
+    # dz elementwise: recompute both from ONE set of means to compare the masks exactly
+    means = (out["y"][0] / M).float().contiguous()
+    dzs = []
+    for fn, args in ((lib.mpsr_batch_norm_grad, (_lib.ptr(dy), _lib.ptr(y), _lib.ptr(z))),
+                     (lib.mpsr_batch_norm_grad_z, (_lib.ptr(dy), _lib.ptr(z)))):
+        dz = torch.empty_like(z)
+        tail = (st[0].data_ptr(), st[1].data_ptr()) + ((_lib.ptr(beta),) if fn is lib.mpsr_batch_norm_grad_z else ()) + \
+            (means[0].data_ptr(), means[1].data_ptr(), _lib.ptr(dz), _lib.stream())
+        _lib.check(fn(*args, M, C, *tail))
+        dzs.append(dz)
+    assert torch.equal(dzs[0], dzs[1])
+    assert float(gz.abs().sum()) > 0

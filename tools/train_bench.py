@@ -48,6 +48,8 @@ def main():
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
     ap.add_argument("--one-stream-trunks", action="store_true",
                     help="A/B with --full-image: both trunks on one stream (TrainNet.two_stream_trunks = False)")
+    ap.add_argument("--bn-mask-from-y", action="store_true",
+                    help="A/B: BatchNorm's backward reads y for the ReLU mask instead of rebuilding it from z")
     ap.add_argument("--wgrad-main-stream", action="store_true",
                     help="A/B: weight gradients on the main stream (autograd_ops.WGRAD_SIDE_STREAM = False)")
     ap.add_argument("--wgrad-streams", type=int, default=1, help="A/B: side streams the weight gradients rotate over")
@@ -73,6 +75,8 @@ def main():
     autograd_ops.WGRAD_SIDE_STREAMS = args.wgrad_streams
     if args.wgrad_main_stream:
         autograd_ops.WGRAD_SIDE_STREAM = False
+    if args.bn_mask_from_y:
+        autograd_ops.BN_MASK_FROM_Z = False
     if args.one_stream_trunks:
         train_net.TrainNet.two_stream_trunks = False
     scopes = (W.CROP_SCOPE, W.FULL_SCOPE) if args.full_image else (W.CROP_SCOPE,)
