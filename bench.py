@@ -949,7 +949,9 @@ def _training_step_object(device, batch, inp, steps, warmup, dist, red_dev, make
                    "BN: %s" % ("batch statistics pooled over all ranks (fp64 sums all-reduced per layer and direction: the "
                                "whole step's batch, as the reference's single-process step)" if decoder_bn == "batch_global"
                                else "per-rank batch statistics (no cross-rank statistics exchange; --decoder-bn "
-                                    "batch_global pools them)")}
+                                    "batch_global pools them)"),
+           "streams": "weight gradients on a second HIP stream of the same GPU (leaves of the backward pass), joined "
+                      "at the end of backward and before every gradient bucket leaves"}
     losses = [float(tr.step(sample)) for _ in range(warmup)]
     if world > 1:
         tr.reducer.enabled = False
