@@ -26,7 +26,7 @@ def _json_lines(out):
     return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])  # (8: the node the driver's scaling run uses)
 def test_gpus_n_starts_n_ranks(n):
     r = _run(["--gpus", str(n)], {"MPSR_BENCH_RENDEZVOUS_ONLY": "1"})
     assert r.returncode == 0, r.stderr[-2000:]

@@ -87,3 +87,8 @@ def test_two_ranks_even_split():
 
 def test_two_ranks_ragged_split():
     _run(2, 7)
+
+
+def test_eight_ranks_even_and_ragged_split():
+    _run(8, 2048)  # BASELINE cfg4 / cfg5: 256 instances per rank
+    _run(8, 13)    # fewer than two instances on some ranks

@@ -81,6 +81,23 @@ def test_reverse_bucket_reducer_direct_mode_two_and_three_ranks():
         assert all(res.values()), (world, res)
 
 
+def test_reverse_bucket_reducer_eight_ranks_both_modes():
+    """The node the scaling run uses has eight GPUs: the same exchange at world_size 8 ("direct": 250-element buckets do
+    not divide by eight and fall back to all_reduce, as a last odd bucket of the real 64 MiB ones may)."""
+    ctx = mp.get_context("spawn")
+    for mode in ("rccl", "direct"):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 8, port, q, mode)) for r in range(8)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        res = dict(q.get(timeout=5) for _ in range(8))
+        assert all(res.values()), (mode, res)
+
+
 def test_reducer_rejects_an_unknown_mode():
     import pytest
     from monopsr_amd.core.trainer import ReverseBucketReducer
