@@ -50,6 +50,8 @@ def main():
                     help="A/B with --full-image: both trunks on one stream (TrainNet.two_stream_trunks = False)")
     ap.add_argument("--bn-mask-from-y", action="store_true",
                     help="A/B: BatchNorm's backward reads y for the ReLU mask instead of rebuilding it from z")
+    ap.add_argument("--wgrad-target", type=int, default=0,
+                    help="debug: workgroups per weight-gradient launch the pixel slicing aims at (default 768)")
     ap.add_argument("--wgrad-main-stream", action="store_true",
                     help="A/B: weight gradients on the main stream (autograd_ops.WGRAD_SIDE_STREAM = False)")
     ap.add_argument("--wgrad-streams", type=int, default=1, help="A/B: side streams the weight gradients rotate over")
@@ -71,6 +73,8 @@ def main():
     _lib.set_conv_math(args.math)
     _lib.lib().mpsr_debug_set_wgrad_winograd(args.wgrad_winograd)
     _lib.lib().mpsr_debug_set_wgrad_direct(1 if args.wgrad_direct else 0)
+    if args.wgrad_target:
+        _lib.lib().mpsr_debug_set_wgrad_target(args.wgrad_target)
     from monopsr_amd.core import autograd_ops
     autograd_ops.WGRAD_SIDE_STREAMS = args.wgrad_streams
     if args.wgrad_main_stream:
