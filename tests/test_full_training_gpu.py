@@ -329,3 +329,35 @@ def test_weight_gradients_on_the_side_stream_are_complete_when_backward_returns(
     assert any(ops._WGRAD_STREAMS.values())
     scale = float(grads[False].abs().max())
     assert float((grads[True] - grads[False]).abs().max()) < 2e-5 * scale
+
+
+def test_autograd_end_of_pass_callbacks_run_on_the_callers_stream():
+    """What the weight-gradient stream's join relies on (autograd_ops._deposit_weight_grad): a callback queued from inside a
+    backward formula runs at the end of the pass with the stream that was current where backward() was CALLED -- not the
+    stream of the node that queued it -- so `current_stream().wait_stream(side)` there orders the caller behind the side
+    stream.  A torch release that changes this must fail here, not as a race."""
+    seen = {}
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["node"] = torch.cuda.current_stream().cuda_stream
+            torch.autograd.Variable._execution_engine.queue_callback(
+                lambda: seen.__setitem__("callback", torch.cuda.current_stream().cuda_stream))
+            return g * 2
+
+    fwd, bwd = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.ones(4, device="cuda", requires_grad=True)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(fwd):
+        y = F.apply(x).sum()
+    bwd.wait_stream(fwd)
+    with torch.cuda.stream(bwd):
+        y.backward()
+    torch.cuda.synchronize()
+    assert seen["node"] == fwd.cuda_stream          # a node's backward runs on the stream of its forward
+    assert seen["callback"] == bwd.cuda_stream      # the end-of-pass callback on the caller's
