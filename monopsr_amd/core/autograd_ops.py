@@ -123,6 +123,7 @@ def _pad4(L, g):
 # A/B switch (tools/train_bench.py --wgrad-main-stream).
 WGRAD_SIDE_STREAM = True
 WGRAD_SIDE_STREAMS = 1  # how many side streams the launches rotate over
+WGRAD_STREAM_PRIORITY = 0  # A/B: -1 = a high-priority side stream
 _WGRAD_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
 _WGRAD_NEXT = {}      # device index -> launches so far (the rotation)
 _JOIN_QUEUED = set()  # device indices whose end-of-backward join is queued in the running pass
@@ -136,7 +137,7 @@ def _wgrad_stream(device):
     _WGRAD_NEXT[device.index] = k + 1
     k %= max(1, WGRAD_SIDE_STREAMS)
     while len(pool) <= k:
-        pool.append(torch.cuda.Stream(device=device))
+        pool.append(torch.cuda.Stream(device=device, priority=WGRAD_STREAM_PRIORITY))
     return pool[k]
 
 

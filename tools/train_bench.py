@@ -50,6 +50,9 @@ def main():
                     help="A/B with --full-image: both trunks on one stream (TrainNet.two_stream_trunks = False)")
     ap.add_argument("--bn-mask-from-y", action="store_true",
                     help="A/B: BatchNorm's backward reads y for the ReLU mask instead of rebuilding it from z")
+    ap.add_argument("--main-high-priority", action="store_true",
+                    help="A/B: the whole step on a high-priority stream (the weight-gradient stream stays normal)")
+    ap.add_argument("--wgrad-priority", type=int, default=0, help="A/B: priority of the weight-gradient stream (-1 high)")
     ap.add_argument("--wgrad-target", type=int, default=0,
                     help="debug: workgroups per weight-gradient launch the pixel slicing aims at (default 768)")
     ap.add_argument("--wgrad-main-stream", action="store_true",
@@ -77,6 +80,7 @@ def main():
         _lib.lib().mpsr_debug_set_wgrad_target(args.wgrad_target)
     from monopsr_amd.core import autograd_ops
     autograd_ops.WGRAD_SIDE_STREAMS = args.wgrad_streams
+    autograd_ops.WGRAD_STREAM_PRIORITY = args.wgrad_priority
     if args.wgrad_main_stream:
         autograd_ops.WGRAD_SIDE_STREAM = False
     if args.bn_mask_from_y:
@@ -105,6 +109,10 @@ def main():
         sample["boxes_2d_norm"] = sample["boxes_2d"] / torch.tensor([375.0, 1242.0, 375.0, 1242.0], device=dev)
     sample.update(trainer.synthetic_ground_truth(sample, seed=7 + rank))
     losses = []
+    if args.main_high_priority:
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hp)
     for _ in range(args.warmup):
         losses.append(float(tr.step(sample)))
     if dist is not None:
