@@ -702,6 +702,7 @@ int g_wgrad_grouped = 1;  // mpsr_debug_set_wgrad_grouped: the XCD-aware workgro
 // nothing, and with loads AND stores knocked out both kernels sit at 158-165 us: the loop is matrix-bound at the
 // clock the board sustains, what a launch pays on top is its fixed ramp-up / drain (~30 us), not LDS staging.
 int g_wgrad_direct = 0;
+int g_wgrad_min_steps = 12;  // mpsr_debug_set_wgrad_min_steps: 32-pixel steps a slice of a 1x1 layer reduces at least (0: off)
 int g_wgrad_target = 768;  // one round of the 3 workgroups per CU the kernel's registers allow (measured best)
 
 inline int grid_for(long long total) { return (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144); }
@@ -746,6 +747,18 @@ extern "C" int mpsr_conv2d_wgrad_f32(const float *x, const float *dy, int B, int
         const int per_xcd = (g_wgrad_target / 8) / tiles;
         if (per_xcd >= 2) slices = 8 * per_xcd;
         else group_ok = false;
+    }
+    // Short reductions (r06, tools/wgrad_small_m.py / wgrad_bench.py --target): a slice pays its 128 x 128 atomics whatever
+    // it reduced, and the slices of a tile contend for the same addresses -- below ~12 steps of 32 pixels per slice more
+    // slices cost more than they parallelise.  One 40x152 map (190 steps): 61.6 us at 48 slices, 44.9 at 16; block2's
+    // conv3 at 256 crops (4 tiles: 192 slices of 6 steps): 84.4 -> 67.6 us at 64.  Floor: 128 workgroups in all (a launch
+    // that small is latency-bound and wants the parallelism back: 128 -> 512 on one map 25.5 us at 32 slices, 28.4 at 24).
+    if (taps == 1 && g_wgrad_min_steps > 0) {
+        int cap = msteps_total / g_wgrad_min_steps;
+        const int floor_slices = mpsr::ceil_div(128, tiles);
+        if (cap < floor_slices) cap = floor_slices;
+        if (tiles > 1 && group_ok) cap = (cap + 7) / 8 * 8;  // whole groups per XCD
+        if (slices > cap) slices = cap;
     }
     if (slices > msteps_total) slices = msteps_total;
     p.splits = slices;
@@ -1044,4 +1057,5 @@ extern "C" int mpsr_adam_step_lr_dev(float *param, const float *grad, float *m, 
 
 extern "C" void mpsr_debug_set_wgrad_target(int workgroups) { g_wgrad_target = workgroups; }
 extern "C" void mpsr_debug_set_wgrad_grouped(int on) { g_wgrad_grouped = on; }
+extern "C" void mpsr_debug_set_wgrad_min_steps(int steps) { g_wgrad_min_steps = steps; }
 extern "C" void mpsr_debug_set_wgrad_direct(int on) { g_wgrad_direct = on; }

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--main-high-priority", action="store_true",
                     help="A/B: the whole step on a high-priority stream (the weight-gradient stream stays normal)")
     ap.add_argument("--wgrad-priority", type=int, default=0, help="A/B: priority of the weight-gradient stream (-1 high)")
+    ap.add_argument("--wgrad-min-steps", type=int, default=-1,
+                    help="debug: 32-pixel steps a slice of a 1x1 weight gradient reduces at least (library default 12; 0 = off)")
     ap.add_argument("--wgrad-target", type=int, default=0,
                     help="debug: workgroups per weight-gradient launch the pixel slicing aims at (default 768)")
     ap.add_argument("--wgrad-main-stream", action="store_true",
@@ -76,6 +78,8 @@ def main():
     _lib.set_conv_math(args.math)
     _lib.lib().mpsr_debug_set_wgrad_winograd(args.wgrad_winograd)
     _lib.lib().mpsr_debug_set_wgrad_direct(1 if args.wgrad_direct else 0)
+    if args.wgrad_min_steps >= 0:
+        _lib.lib().mpsr_debug_set_wgrad_min_steps(args.wgrad_min_steps)
     if args.wgrad_target:
         _lib.lib().mpsr_debug_set_wgrad_target(args.wgrad_target)
     from monopsr_amd.core import autograd_ops

@@ -34,6 +34,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--target", type=int, default=0, help="debug: workgroups per launch the pixel slicing aims at")
+    ap.add_argument("--min-steps", type=int, default=-1, help="debug: 32-pixel steps per slice of a 1x1 layer at least "
+                                                               "(default: the library's 12; 0 = the plain target)")
     ap.add_argument("--ungrouped", action="store_true", help="A/B: the workgroup order that ignores the XCDs")
     ap.add_argument("--direct", action="store_true", help="A/B: 1x1 layers on pw_wgrad_direct_kernel (operands straight "
                                                           "into the MFMA's source registers) instead of the LDS-staged kernel")
@@ -43,6 +45,8 @@ def main():
     if args.target:
         lib.mpsr_debug_set_wgrad_target(args.target)
     lib.mpsr_debug_set_wgrad_direct(1 if args.direct else 0)
+    if args.min_steps >= 0:
+        lib.mpsr_debug_set_wgrad_min_steps(args.min_steps)
     if args.ungrouped:
         lib.mpsr_debug_set_wgrad_grouped(0)
     total = 0.0
