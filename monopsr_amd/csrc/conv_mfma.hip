@@ -1179,14 +1179,20 @@ size_t conv_scratch_floats(long long M, int N)
     return slabs + counters;
 }
 
-constexpr int g_auto_split_target = 768;  // workgroups wanted per launch
+// A launch with at least g_auto_split_enough tiles is left alone; a smaller one is cut along K into enough slices for
+// g_auto_split_target workgroups (mpsr_debug_set_auto_split_target).  r06 sweep of the aim (tools/full_path_bench.py
+// --knob ..., tools/step_knob_run.py; profiles/r06_step_ab.txt): 1152 takes the one-image path from 5.63 to 5.48 ms (the
+// full-image trunk's 380-tile layers in 4 slices instead of 3) and costs the crop trunk alone +1.7 % at 24 boxes and
+// +0.8 % at 48; 1536 loses on both.  Not enough of a pattern to move the default.
+int g_auto_split_target = 768;
+constexpr int g_auto_split_enough = 768;
 constexpr int g_auto_split_min_ksteps = 4;
 
 int auto_split_k(int M, int N, int ksteps, const float *ws, size_t ws_floats)
 {
     if (!ws) return 1;
     const long long tiles = (long long)ceil_div(M, 64) * ceil_div(N, 64);
-    if (tiles >= g_auto_split_target || N <= 32) return 1;
+    if (tiles >= g_auto_split_enough || tiles >= g_auto_split_target || N <= 32) return 1;
     long long s = (g_auto_split_target + tiles - 1) / tiles;
     if (s > 8) s = 8;
     if (s > ksteps / g_auto_split_min_ksteps) s = ksteps / g_auto_split_min_ksteps;
@@ -1426,6 +1432,7 @@ int conv2d(const float *x, int B, int H, int W, int C, const float *w, const flo
 
 // Internal (not part of the ABI in monopsr_hip.h): force a tile configuration / the border-class tiling for tuning
 // and for the tests that sweep every instantiation.  Process-wide, not thread-safe.
+extern "C" void mpsr_debug_set_auto_split_target(int workgroups) { mpsr::g_auto_split_target = workgroups; }
 extern "C" void mpsr_debug_set_conv_tile(int sel) { g_tile_override = sel; }
 extern "C" void mpsr_debug_set_conv_classes(int mode) { g_class_override = mode; }
 extern "C" void mpsr_debug_set_conv_depth(int depth) { g_depth_override = depth; }
