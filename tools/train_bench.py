@@ -123,8 +123,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         losses.append(tr.step(sample))
+        host += time.perf_counter() - h0  # (the call returns when everything is enqueued: the host's share of a step)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -132,6 +135,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "instance-crops/sec (train: fwd+bwd+allreduce+Adam)",
                           "value": round(B * world * args.steps / dt, 1), "unit": "crops/s", "n_gpus": world,
+                          "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2),
                           "ms_per_step": round(1e3 * dt / args.steps, 2), "params": int(net.params.numel()),
                           "grad_bytes": int(net.grads.numel() * 4),
                           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}))
