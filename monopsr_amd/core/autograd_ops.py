@@ -127,6 +127,7 @@ WGRAD_STREAM_PRIORITY = 0  # A/B: -1 = a high-priority side stream
 _WGRAD_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
 _WGRAD_NEXT = {}      # device index -> launches so far (the rotation)
 _JOIN_QUEUED = set()  # device indices whose end-of-backward join is queued in the running pass
+_STREAM_OBJECTS = {}  # (device index, raw stream handle) -> torch.cuda.Stream (a handle names one stream for the process's life)
 _PASS_STREAMS = {}    # device index -> {stream id: stream} the running pass's deposits were launched FROM (a TrainNet with
 #                       both trunks runs the full-image trunk, forward and therefore backward, on its own stream)
 
@@ -160,8 +161,14 @@ def _deposit_weight_grad(L, x, g):
     layer's slices of the flat gradient buffer; then the layer's `on_grad_ready` hook (the data-parallel reducer)."""
     if x.is_cuda:
         dev = x.device
-        main = torch.cuda.current_stream(dev)
-        _PASS_STREAMS.setdefault(dev.index, {})[main.cuda_stream] = main
+        # (host cost matters here -- 109 deposits per step, and a step of 8-32 instances is bound by the host: the stream
+        # OBJECT of a raw handle is looked up, not rebuilt (torch.cuda.current_stream() takes ~8 us), and the side stream
+        # is made current with two set_stream calls instead of a context manager)
+        raw = _lib.stream(dev.index)
+        main = _STREAM_OBJECTS.get((dev.index, raw))
+        if main is None:
+            main = _STREAM_OBJECTS[(dev.index, raw)] = torch.cuda.current_stream(dev)
+        _PASS_STREAMS.setdefault(dev.index, {})[raw] = main
         in_pass = True
         if dev.index not in _JOIN_QUEUED:
             try:
@@ -172,8 +179,11 @@ def _deposit_weight_grad(L, x, g):
     if WGRAD_SIDE_STREAM and x.is_cuda:
         side = _wgrad_stream(dev)
         side.wait_stream(main)  # x, g (and the step's zeroed gradient buffer) are ready on the main stream here
-        with torch.cuda.stream(side):
+        torch.cuda.set_stream(side)
+        try:
             _launch_weight_grad(L, x, g)
+        finally:
+            torch.cuda.set_stream(main)
         x.record_stream(side)
         g.record_stream(side)
         if not in_pass:

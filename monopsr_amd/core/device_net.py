@@ -350,7 +350,7 @@ def stream_scratch(cache, device, floats, keep=8):
     stream): launches on one stream are ordered, so they can share it.  At most `keep` streams are remembered (the
     oldest entry goes first: its memory returns to the caching allocator once the launches using it have run), so
     short-lived streams do not pin 100 MB each for the life of the process."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _lib.stream(device.index))
     ws = cache.get(key)
     if ws is None or ws.numel() < floats:
         cache.pop(key, None)
