@@ -695,7 +695,9 @@ def full_image_path_object(device, boxes=32, images=8, reps=3):
 def two_batches_object(net, inp, args, step):
     """Throughput with two batches in flight on two streams of the one GPU (tools/pipeline_steps.py as a bench object)."""
     steps = [step, Step(net.clone_with_own_scratch(), inp, args.points)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    from monopsr_amd.core import device_net as dn
+    streams = [torch.cuda.Stream()]
+    streams.append(dn.concurrent_stream(streams[0].device, streams[0]))  # (one that does not share its hardware queue)
     main = torch.cuda.current_stream()
     for s in streams:
         s.wait_stream(main)

@@ -59,7 +59,7 @@ def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_
             # trunk.  (A trainable net with both trunks does the same since r06: autograd runs a node's backward on
             # the stream of its forward, so the backward passes of the two trunks overlap too.)
             if net.side_stream is None:
-                net.side_stream = torch.cuda.Stream(device=crop_img.device)
+                net.side_stream = dn.concurrent_stream(crop_img.device)
             main = torch.cuda.current_stream()
             net.side_stream.wait_stream(main)
             with torch.cuda.stream(net.side_stream):

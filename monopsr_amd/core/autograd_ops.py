@@ -132,13 +132,14 @@ _PASS_STREAMS = {}    # device index -> {stream id: stream} the running pass's d
 #                       both trunks runs the full-image trunk, forward and therefore backward, on its own stream)
 
 
-def _wgrad_stream(device):
+def _wgrad_stream(device, main=None):
     pool = _WGRAD_STREAMS.setdefault(device.index, [])
     k = _WGRAD_NEXT.get(device.index, 0)
     _WGRAD_NEXT[device.index] = k + 1
     k %= max(1, WGRAD_SIDE_STREAMS)
     while len(pool) <= k:
-        pool.append(torch.cuda.Stream(device=device, priority=WGRAD_STREAM_PRIORITY))
+        # a stream that shares its hardware queue with `main` would serialise with it: picked by measurement, once
+        pool.append(dn.concurrent_stream(device, main, priority=WGRAD_STREAM_PRIORITY))
     return pool[k]
 
 
@@ -154,6 +155,25 @@ def join_wgrad_stream(device=None):
     for s in list(_PASS_STREAMS.pop(idx, {}).values()) + list(_WGRAD_STREAMS.get(idx, ())):
         if s.cuda_stream != cur.cuda_stream:
             cur.wait_stream(s)
+
+
+def wgrad_stream_if_any(device):
+    """The side stream the weight gradients of `device` run on, or None (switched off / never used / several of them)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    pool = _WGRAD_STREAMS.get(idx, ())
+    return pool[0] if (WGRAD_SIDE_STREAM and len(pool) == 1) else None
+
+
+def order_behind_pass_streams(stream, device):
+    """`stream` waits for every stream the running pass has deposited gradients from so far."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    for s in _PASS_STREAMS.get(idx, {}).values():
+        if s.cuda_stream != stream.cuda_stream:
+            stream.wait_stream(s)
 
 
 def _deposit_weight_grad(L, x, g):
@@ -177,7 +197,7 @@ def _deposit_weight_grad(L, x, g):
             except RuntimeError:  # not inside a backward pass (a backward formula called by hand): join right away
                 in_pass = False
     if WGRAD_SIDE_STREAM and x.is_cuda:
-        side = _wgrad_stream(dev)
+        side = _wgrad_stream(dev, main)
         side.wait_stream(main)  # x, g (and the step's zeroed gradient buffer) are ready on the main stream here
         torch.cuda.set_stream(side)
         try:

@@ -68,35 +68,57 @@ class ReverseBucketReducer:
             if not self.pending[bi] and not self.launched[bi]:
                 self._launch(bi)
 
+    # The weight gradients run on a side stream (autograd_ops._deposit_weight_grad), so the collective must be ordered
+    # behind IT.  True: the collectives are issued with that stream current (it first waits for the caller's stream, which
+    # may hold deposits of its own: BatchNorm's beta, the upsampled convolutions): the exchange starts when the bucket's
+    # last weight gradient is done and the caller's stream -- the data-gradient chain -- is not stalled.  False: the
+    # caller's stream waits for the side stream and issues the collective itself (A/B: tools/train_bench.py --issue-on-main).
+    issue_on_wgrad_stream = True
+
     def _launch(self, bi):
         self.launched[bi] = True
         if self._active():
+            restore = None
             if self.flat.is_cuda:
-                # the weight gradients run on a side stream (autograd_ops._deposit_weight_grad): the collective must see them
                 from monopsr_amd.core import autograd_ops
-                autograd_ops.join_wgrad_stream(self.flat.device)
-            lo, hi = self.buckets[bi]
-            world = dist.get_world_size(self.group)
-            if self.mode == "direct" and (hi - lo) % world == 0:
-                # (the two collectives of one process group run in issue order: the gather reads what the scatter left)
-                shard = self._shards.get(bi)
-                if shard is None:
-                    shard = self._shards[bi] = torch.empty(((hi - lo) // world,), dtype=self.flat.dtype,
-                                                           device=self.flat.device)
-                rs = dist.reduce_scatter_tensor(shard, self.flat[lo:hi], group=self.group, async_op=True)
-                self.issued.append("reduce_scatter_tensor")
-                if dist.get_backend(self.group) == "nccl":
-                    # RCCL runs a communicator's collectives in issue order on its own stream: the gather can follow now
-                    # and both overlap the rest of backward
-                    self.works.append(rs)
-                    self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], shard, group=self.group,
-                                                                  async_op=True))
-                    self.issued.append("all_gather_into_tensor")
-                else:  # gloo runs asynchronous work items concurrently: the gather is issued once the scatter is done
-                    self.deferred.append((rs, bi))
-            else:  # "rccl", or a last bucket that does not divide into world shards
-                self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
-                self.issued.append("all_reduce")
+                side = autograd_ops.wgrad_stream_if_any(self.flat.device) if self.issue_on_wgrad_stream else None
+                if side is None:
+                    autograd_ops.join_wgrad_stream(self.flat.device)
+                else:
+                    cur = torch.cuda.current_stream(self.flat.device)
+                    autograd_ops.order_behind_pass_streams(side, self.flat.device)  # (the caller's stream is one of them)
+                    side.wait_stream(cur)
+                    torch.cuda.set_stream(side)
+                    restore = cur
+            try:
+                self._issue(bi)
+            finally:
+                if restore is not None:
+                    torch.cuda.set_stream(restore)
+
+    def _issue(self, bi):
+        lo, hi = self.buckets[bi]
+        world = dist.get_world_size(self.group)
+        if self.mode == "direct" and (hi - lo) % world == 0:
+            # (the two collectives of one process group run in issue order: the gather reads what the scatter left)
+            shard = self._shards.get(bi)
+            if shard is None:
+                shard = self._shards[bi] = torch.empty(((hi - lo) // world,), dtype=self.flat.dtype,
+                                                       device=self.flat.device)
+            rs = dist.reduce_scatter_tensor(shard, self.flat[lo:hi], group=self.group, async_op=True)
+            self.issued.append("reduce_scatter_tensor")
+            if dist.get_backend(self.group) == "nccl":
+                # RCCL runs a communicator's collectives in issue order on its own stream: the gather can follow now
+                # and both overlap the rest of backward
+                self.works.append(rs)
+                self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], shard, group=self.group,
+                                                              async_op=True))
+                self.issued.append("all_gather_into_tensor")
+            else:  # gloo runs asynchronous work items concurrently: the gather is issued once the scatter is done
+                self.deferred.append((rs, bi))
+        else:  # "rccl", or a last bucket that does not divide into world shards
+            self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+            self.issued.append("all_reduce")
 
     def finish(self, average=True):
         for bi in range(len(self.buckets) - 1, -1, -1):

@@ -361,3 +361,27 @@ def test_autograd_end_of_pass_callbacks_run_on_the_callers_stream():
     torch.cuda.synchronize()
     assert seen["node"] == fwd.cuda_stream          # a node's backward runs on the stream of its forward
     assert seen["callback"] == bwd.cuda_stream      # the end-of-pass callback on the caller's
+
+
+def test_side_streams_are_picked_by_measured_concurrency():
+    """device_net.concurrent_stream: HIP maps streams onto a few hardware queues and two streams on one queue do not overlap
+    at all (r06: with an RCCL communicator alive the weight-gradient stream landed on the main stream's queue and the step got
+    SLOWER than with one stream).  The side streams of the package are therefore picked by a measurement -- two spin
+    kernels behind a common event take one spin when they overlap, two when they are serialised -- and the pick must pass
+    its own test, also with a dozen other streams alive (whatever queue they took)."""
+    from monopsr_amd.core import device_net as dn
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream(dev)
+    others = [torch.cuda.Stream() for _ in range(12)]
+    for s in others:  # make them real (a queue each, as far as the runtime has queues)
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+    side = dn.concurrent_stream(dev)
+    assert side.cuda_stream != main.cuda_stream
+    assert dn.runs_concurrently(main, side)
+    assert not dn.runs_concurrently(main, main)  # (the measurement itself: one stream is serialised with itself)
+    # and relative to a non-default "main"
+    other_main = others[3]
+    side2 = dn.concurrent_stream(dev, other_main)
+    assert dn.runs_concurrently(other_main, side2)

@@ -19,8 +19,18 @@ ap.add_argument("--knob", default="")
 ap.add_argument("--value", type=int, default=-1)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--rccl", action="store_true", help="create a one-rank RCCL communicator first (what an N > 1 rank has alive)")
 args = ap.parse_args()
 device = torch.device("cuda", 0)
+if args.rccl:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    t = torch.ones(4, device=device)
+    dist.all_reduce(t)  # (the communicator is created by its first collective)
+    torch.cuda.synchronize()
 if args.knob:
     getattr(_lib.lib(), args.knob)(args.value)
 net = dn.DeviceNet(W.synthetic_weights(seed=0), device=device)

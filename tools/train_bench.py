@@ -57,6 +57,14 @@ def main():
                     help="debug: 32-pixel steps a slice of a 1x1 weight gradient reduces at least (library default 12; 0 = off)")
     ap.add_argument("--wgrad-target", type=int, default=0,
                     help="debug: workgroups per weight-gradient launch the pixel slicing aims at (default 768)")
+    ap.add_argument("--one-rank-rccl", action="store_true",
+                    help="a one-rank RCCL communicator with the gradient exchange forced on (the N > 1 step's collectives "
+                         "as identities: what issuing them costs on one GPU)")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="with --one-rank-rccl / N > 1: the reducer tracks its buckets but issues nothing (reducer.enabled = False)")
+    ap.add_argument("--issue-on-main", action="store_true",
+                    help="A/B with --one-rank-rccl: the caller's stream waits for the weight-gradient stream and issues the "
+                         "collectives itself (ReverseBucketReducer.issue_on_wgrad_stream = False)")
     ap.add_argument("--wgrad-main-stream", action="store_true",
                     help="A/B: weight gradients on the main stream (autograd_ops.WGRAD_SIDE_STREAM = False)")
     ap.add_argument("--wgrad-streams", type=int, default=1, help="A/B: side streams the weight gradients rotate over")
@@ -69,10 +77,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.one_rank_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        sys.stdout.flush()
+        out_fd = os.dup(1)  # (RCCL prints its version block to the C stdout: keep the JSON line's stdout apart)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(out_fd, "w")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.issue_on_main:
+        trainer.ReverseBucketReducer.issue_on_wgrad_stream = False
     cfg = config_utils.default_config()
     from monopsr_amd import _lib
     _lib.set_conv_math(args.math)
@@ -99,8 +114,10 @@ def main():
         from monopsr_amd.core import autograd_ops
         autograd_ops.FUSED_RELU_GRADS = False
     tr = trainer.InstanceTrainer(net, cfg.model_config, cfg.dataset_config, cfg.train_config,
-                                clip_norm=0.0 if args.no_clip else 1.0)
+                                clip_norm=0.0 if args.no_clip else 1.0, force_collectives=args.one_rank_rccl)
     tr.fused_update = not args.unfused_update
+    if args.no_exchange:
+        tr.reducer.enabled = False
     inp, _ = bench.make_inputs(args.batch, 1024, rank, dev)
     B = args.batch
     sample = dict(rgb_image_crops=inp["crops"], full_img_feature_crop=inp["full_feat"], boxes_2d=inp["boxes"],
