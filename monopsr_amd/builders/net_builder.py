@@ -50,8 +50,8 @@ def build_resnet101_4x_squash(net_config, net_type, model, input_dict, features_
             large = crop_and_resize(full_img_encoder_out, model.pl_boxes_2d_norm, None, half)
             return max_pool(large, 2, 2, "VALID")
 
-        # (a trainable net: only while the crop trunk alone leaves CUs idle -- measured, r06: 26.6 vs 27.4 ms per training
-        # step at 32 boxes, 62.0 vs 61.4 at 256, where three streams compete for a chip the crop trunk already fills)
+        # (a trainable net caps the box count, TrainNet.side_stream_max_boxes = 64: training step with both trunks 24.5 vs
+        # 26.2 ms at 32 boxes; above, a third busy stream wins or loses with the hardware queues it happens to get)
         few_enough = crop_img.shape[0] <= getattr(net, 'side_stream_max_boxes', 1 << 30)
         if hasattr(net, 'side_stream') and few_enough and torch.cuda.is_available():
             # The two trunks are independent and, at one image / a few dozen boxes, each leaves most CUs idle

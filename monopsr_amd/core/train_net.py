@@ -8,6 +8,8 @@ trainable tensors are the folded weight and bias of each layer.  The trunks' Bat
 too (faster_rcnn_resnet_v1_feature_extractor.py:63,238); training the folded weight instead of (w, gamma, beta)
 separately is a re-parameterisation of the same function, stated here because it is not the reference's variable set.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -47,7 +49,11 @@ class TrainNet:
             # use).  Autograd runs a node's backward on the stream of its forward, so the two trunks' backward passes
             # overlap as well; their deposits are joined at the end of the pass (autograd_ops.join_wgrad_stream).
             self.side_stream = None
-            self.side_stream_max_boxes = 64
+            # Up to 64 boxes.  Above, a third busy stream is a gamble on the runtime's four hardware queues: alone
+            # (tools/train_bench.py --full-image) the own stream wins at every size -- 256 boxes 61.05 -> 60.1 ms, 128: 40.7 ->
+            # 39.4, 32: 26.2 -> 24.5 -- but inside bench.py, where a dozen other streams and an RCCL communicator exist,
+            # 256 boxes read 63.7 with it and 61.4 without (same box, twice).  MPSR_DEBUG_TRUNK_STREAM_MAX_BOXES overrides.
+            self.side_stream_max_boxes = int(os.environ.get("MPSR_DEBUG_TRUNK_STREAM_MAX_BOXES", 64))
         parts = [W.pack_trunk(weights, W.CROP_SCOPE, width_div), W.pack_decoder(weights, width_div)]
         fc_names = [n for n, _, _, _ in W.head_fc_specs()] if with_heads else []
         blobs, recs, base = [], [], 0

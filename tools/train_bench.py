@@ -46,6 +46,9 @@ def main():
                          "layer), 1 = all layers by one launch per step (autograd_ops.DgradBank)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the forward and data-gradient convolutions (wgrad stays fp32)")
+    ap.add_argument("--trunk-streams-max-boxes", type=int, default=0,
+                    help="A/B with --full-image: box count up to which the full-image trunk runs on its own stream "
+                         "(TrainNet.side_stream_max_boxes, default 64)")
     ap.add_argument("--one-stream-trunks", action="store_true",
                     help="A/B with --full-image: both trunks on one stream (TrainNet.two_stream_trunks = False)")
     ap.add_argument("--bn-mask-from-y", action="store_true",
@@ -110,6 +113,8 @@ def main():
     net = train_net.TrainNet(W.synthetic_weights(seed=0, scopes=scopes), device=dev, full_trunk=args.full_image,
                              decoder_bn=args.decoder_bn, dgrad_bank=bool(args.dgrad_bank))
     net.linked_units = not args.unlinked_units
+    if args.trunk_streams_max_boxes and hasattr(net, "side_stream_max_boxes"):
+        net.side_stream_max_boxes = args.trunk_streams_max_boxes
     if args.unfused_relu_grads:
         from monopsr_amd.core import autograd_ops
         autograd_ops.FUSED_RELU_GRADS = False
