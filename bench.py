@@ -979,6 +979,10 @@ def _training_step_object(device, batch, inp, steps, warmup, dist, red_dev, make
                                     "batch_global pools them)"),
            "streams": "weight gradients on a second HIP stream of the same GPU (leaves of the backward pass), joined "
                       "at the end of backward and before every gradient bucket leaves"}
+    if getattr(tr, "hardware_queues", None) is not None:
+        out["hardware_queues"] = dict(tr.hardware_queues, what="device_net.blocked_by_collectives: does a waiting collective "
+                                      "hold up launches on that stream (= it shares the communicator stream's hardware "
+                                      "queue); the weight-gradient stream is the first candidate that is not held up")
     losses = [float(tr.step(sample)) for _ in range(warmup)]
     if world > 1:
         tr.reducer.enabled = False

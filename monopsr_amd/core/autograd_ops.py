@@ -157,6 +157,33 @@ def join_wgrad_stream(device=None):
             cur.wait_stream(s)
 
 
+def settle_wgrad_stream(device, group=None, candidates=4):
+    """For a rank whose gradient exchange runs on RCCL: make sure the weight-gradient stream does not share a hardware queue
+    with the communicator's stream (device_net.blocked_by_collectives) -- a waiting or running collective would hold up
+    every weight gradient behind it.  Probes the caller's current stream once and exactly `candidates` streams (one tiny
+    all_reduce each: the SAME number on every rank, whatever they find), keeps the first candidate that overlaps the
+    caller's stream and is not held up.  -> a report for the bench line / logs."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", idx)
+    main = torch.cuda.current_stream(device)
+    helper = dn.concurrent_stream(device, main)
+    report = {"caller_stream_held_up_by_collectives": bool(dn.blocked_by_collectives(main, group, helper))}
+    pool = _WGRAD_STREAMS.setdefault(idx, [])
+    cands = list(pool[:1])
+    while len(cands) < candidates:
+        cands.append(dn.concurrent_stream(device, main, priority=WGRAD_STREAM_PRIORITY))
+    held = [bool(dn.blocked_by_collectives(c, group)) for c in cands]
+    pick = held.index(False) if False in held else 0
+    report["wgrad_stream_candidates_held_up"] = held
+    report["wgrad_stream_picked"] = pick
+    if pool:
+        pool[0] = cands[pick]
+    else:
+        pool.append(cands[pick])
+    return report
+
+
 def wgrad_stream_if_any(device):
     """The side stream the weight gradients of `device` run on, or None (switched off / never used / several of them)."""
     idx = torch.device(device).index

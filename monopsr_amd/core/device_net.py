@@ -406,6 +406,40 @@ def concurrent_stream(device, main=None, priority=0, tries=12):
     return first
 
 
+def blocked_by_collectives(stream, group=None, helper=None, long_cycles=6000000, short_cycles=200000):
+    """Does a collective that is waiting for its inputs hold up launches on `stream`?  It does when the communicator's own
+    stream shares `stream`'s hardware queue: the queue is in order, so the collective's "wait for the producer's event"
+    packet sits in front of whatever `stream` enqueues next -- and on a real node the collective itself (milliseconds)
+    would.  Measured on any world size, ONE tiny all_reduce per call (every rank must make the same calls): a helper stream
+    spins ~3 ms and issues the all_reduce behind the spin, so the communicator's stream waits ~3 ms; a short spin enqueued
+    on `stream` meanwhile finishes in its own time, or after those 3 ms.  -> True when it was held up."""
+    import torch.distributed as dist
+    dev = stream.device
+    if helper is None:
+        helper = concurrent_stream(dev, stream)
+    t = torch.ones(4, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(stream)
+    helper.wait_event(e0)
+    with torch.cuda.stream(helper):
+        torch.cuda._sleep(long_cycles)
+        work = dist.all_reduce(t, group=group, async_op=True)
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(short_cycles)
+        e1.record(stream)
+    work.wait()
+    torch.cuda.synchronize(dev)
+    took = e0.elapsed_time(e1)
+    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(helper):
+        e2.record(helper)
+        torch.cuda._sleep(long_cycles)
+        e3.record(helper)
+    torch.cuda.synchronize(dev)
+    return took > 0.5 * e2.elapsed_time(e3)
+
+
 _CONSTANTS = {}
 
 

@@ -7,6 +7,8 @@ of per-output losses) -> Adam with the exponential-decay learning rate and the p
 per-variable clip_by_norm(1.0) as slim.learning.create_train_op(clip_gradient_norm=1.0) applies it.
 Not mirrored: TF summaries and the checkpoint schedule.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -208,6 +210,13 @@ class InstanceTrainer:
                                             force_active=force_collectives)
         for li, L in enumerate(net.layers):
             L.on_grad_ready = (lambda i=li: self.reducer.layer_ready(i))
+        # a rank that exchanges over RCCL: the weight-gradient stream must not share a hardware queue with the communicator's
+        # stream (every rank makes the same probe calls); the report travels in the bench line
+        self.hardware_queues = None
+        if self.reducer._active() and net.grads.is_cuda and dist.get_backend(group) == "nccl":
+            from monopsr_amd.core import autograd_ops
+            if autograd_ops.WGRAD_SIDE_STREAM and not os.environ.get("MPSR_DEBUG_NO_QUEUE_PROBE"):
+                self.hardware_queues = autograd_ops.settle_wgrad_stream(net.grads.device, group)
 
     def forward(self, sample):
         out, _ = self.model.build(sample)

@@ -40,4 +40,10 @@ def test_one_rank_rccl_runs_the_n_rank_collective_sequence():
         assert sum(rec["step_issued"].values()) == (nb if mode == "rccl" else 2 * nb)
         # same step, same weights, with and without the collectives: equal up to the atomics' summation order
         assert rec["grad_max_rel_diff_vs_no_collectives"] < 1e-3, (mode, rec)
+        # the trainer probed the hardware queues (r06): the weight-gradient stream it kept is one a waiting collective does
+        # not hold up (one of four candidates; every rank makes the same five probe calls)
+        hq = rec["hardware_queues"]
+        assert len(hq["wgrad_stream_candidates_held_up"]) == 4
+        assert hq["wgrad_stream_candidates_held_up"][hq["wgrad_stream_picked"]] is False
+        assert hq["caller_stream_held_up_by_collectives"] in (True, False)
     assert out["gather_instances_identity"] and out["reduce_metric_sums"] == [1.5, 2.0]

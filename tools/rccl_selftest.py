@@ -86,6 +86,7 @@ def main():
                                      allreduce="rccl" if mode == "none" else mode, force_collectives=(mode != "none"))
         rec = {}
         if mode != "none":
+            rec["hardware_queues"] = tr.hardware_queues  # (the trainer probed which streams a waiting collective holds up)
             red = tr.reducer
             assert red._active(), "a forced reducer must be active on a one-rank group"
             # (1) the bare reducer over the whole flat buffer, driven like backward drives it
