@@ -216,7 +216,10 @@ class InstanceTrainer:
         if self.reducer._active() and net.grads.is_cuda and dist.get_backend(group) == "nccl":
             from monopsr_amd.core import autograd_ops
             if autograd_ops.WGRAD_SIDE_STREAM and not os.environ.get("MPSR_DEBUG_NO_QUEUE_PROBE"):
-                self.hardware_queues = autograd_ops.settle_wgrad_stream(net.grads.device, group)
+                try:
+                    self.hardware_queues = autograd_ops.settle_wgrad_stream(net.grads.device, group)
+                except Exception as e:  # (a diagnostic and a tuning step: never the reason a trainer cannot be built)
+                    self.hardware_queues = {"error": repr(e)[:300]}
 
     def forward(self, sample):
         out, _ = self.model.build(sample)
